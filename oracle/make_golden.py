@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (CPU) in the build container.
+
+TEST INFRASTRUCTURE ONLY.  Run from the repo root:   python oracle/make_golden.py
+Needs /root/reference (read-only; imported with sys.dont_write_bytecode).  The reference cannot travel
+to the GPU box, so only the produced vectors (inputs are re-derived from numpy PCG64 seeds, outputs are
+stored) are committed.  No reference source text is stored in the fixtures.
+
+What is exercised from the reference (paths relative to /root/reference/moco_pretraining/moco):
+  model/module.py                      PreNorm, CrossAttention              (imported as is)
+  model/crossvit_2vits_..._sum.py      MultiScaleTransformerEncoder, Fus_CrossViT
+        imports ``timm.models.layers`` only for the initialiser ``trunc_normal_`` (its line 9/119); timm is
+        not installed, so a 3-symbol in-memory module providing torch's own ``trunc_normal_`` is registered
+        (SURVEY.md §8c).  Every weight is overwritten with seeded values afterwards, so the initialiser
+        cannot influence any stored number.
+  moco/builder_vit_mocov3structure_mocov2loss.py   MoCo._build_mlp, _momentum_update_key_encoder,
+        _dequeue_and_enqueue (1-rank gloo group), concat_all_gather
+  moco/optimizer.py                    LARS
+The ViT backbone is absent from the reference; where a backbone is needed the oracle's own restatement
+(oracle/ref_vit.py, parity unpinned) is wrapped in an object exposing ``features3D`` / ``__call__``.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/moco_pretraining/moco"
+sys.path.insert(0, REF)
+
+from oracle import ref_fusion, ref_moco, ref_vit  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+FUS_MOD = ("model.crossvit_2vits_2additionaloutputs_changenormlayer_location_removeextralclayer_"
+           "changemodelinputlocation_std002_sum")
+
+
+def rng_tensor(seed, shape, scale=1.0, dtype=torch.float32):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy(g.standard_normal(size=shape, dtype=np.float64) * scale).to(dtype)
+
+
+def sample(t, n=4096):
+    """Strided subsample + moments, to keep fixtures small while still pinning a whole tensor."""
+    f = t.detach().double().flatten()
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return dict(idx=idx.numpy(), val=f[idx].numpy(), sum=np.float64(f.sum()), abssum=np.float64(f.abs().sum()))
+
+
+def put(d, key, t, full=False):
+    if full:
+        d[key] = t.detach().double().numpy()
+    else:
+        for k, v in sample(t).items():
+            d[f"{key}.{k}"] = v
+
+
+def install_timm_stub():
+    m_timm = types.ModuleType("timm")
+    m_models = types.ModuleType("timm.models")
+    m_layers = types.ModuleType("timm.models.layers")
+    m_layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    m_layers.DropPath = torch.nn.Identity
+    m_layers.to_2tuple = lambda x: (x, x)
+    sys.modules.setdefault("timm", m_timm)
+    sys.modules.setdefault("timm.models", m_models)
+    sys.modules.setdefault("timm.models.layers", m_layers)
+
+
+def golden_cross_attention():
+    from model.module import CrossAttention, PreNorm
+    torch.manual_seed(0)
+    B, T, D = 2, 197, 384
+    fp = ref_fusion.seeded_fusion_params(101, dtype=torch.float64)
+    mod = PreNorm(D, CrossAttention(D, num_heads=3)).double()
+    L = ref_fusion._L
+    sd = {"norm.weight": fp[L + "0.norm.weight"], "norm.bias": fp[L + "0.norm.bias"],
+          "fn.wq.weight": fp[L + "0.fn.wq.weight"], "fn.wk.weight": fp[L + "0.fn.wk.weight"],
+          "fn.wv.weight": fp[L + "0.fn.wv.weight"], "fn.proj.weight": fp[L + "0.fn.proj.weight"],
+          "fn.proj.bias": fp[L + "0.fn.proj.bias"]}
+    mod.load_state_dict(sd, strict=True)
+    x = rng_tensor(102, (B, T, D), dtype=torch.float64).requires_grad_(True)
+    r = rng_tensor(103, (B, 1, D), dtype=torch.float64)
+    y = mod(x)
+    (y * r).sum().backward()
+    d = dict(seed_params=101, seed_x=102, seed_r=103)
+    put(d, "y", y, full=True)
+    put(d, "dx", x.grad)
+    for n, p in mod.named_parameters():
+        put(d, "d." + n, p.grad)
+    np.savez_compressed(os.path.join(OUT, "fusion_cross_attention.npz"), **d)
+    print("fusion_cross_attention.npz", y.abs().mean().item())
+
+
+class OracleBackbone:
+    """Stands in for the absent vits_returnftrs model (oracle restatement; parity unpinned)."""
+
+    def __init__(self, params):
+        self.p = params
+
+    def features3D(self, img):
+        return ref_vit.features3d(self.p, img)
+
+    def __call__(self, img):
+        return ref_vit.forward(self.p, img)
+
+    def to(self, *_a, **_k):
+        return self
+
+
+def golden_fusion():
+    install_timm_stub()
+    import importlib
+    fus = importlib.import_module(FUS_MOD)
+    B, T, D = 2, 197, 384
+    fp = ref_fusion.seeded_fusion_params(201, dtype=torch.float64)
+    # (a) exchange alone on seeded feature tensors
+    enc = fus.MultiScaleTransformerEncoder().double()
+    pre = "multi_scale_transformers.0."
+    enc.load_state_dict({k[len(pre):]: v for k, v in fp.items() if k.startswith(pre)}, strict=True)
+    xs = rng_tensor(202, (B, T, D), dtype=torch.float64)
+    xl = rng_tensor(203, (B, T, D), dtype=torch.float64)
+    xs_o, xl_o = enc(xs, xl)
+    d = dict(seed_params=201, seed_xs=202, seed_xl=203)
+    put(d, "xs_out", xs_o)
+    put(d, "xl_out", xl_o)
+    put(d, "xs_out_cls", xs_o[:, 0], full=True)
+    put(d, "xl_out_cls", xl_o[:, 0], full=True)
+    np.savez_compressed(os.path.join(OUT, "fusion_exchange.npz"), **d)
+    print("fusion_exchange.npz")
+
+    # (b) Fus_CrossViT end to end on seeded feature providers + CA-step loss and fusion grads
+    #     depth-2 oracle backbones keep generation fast; the fusion code under test is the reference's.
+    vit_c = ref_vit.seeded_params(211, num_classes=3, depth=2, dtype=torch.float64)
+    vit_e = ref_vit.seeded_params(212, num_classes=3, depth=2, dtype=torch.float64)
+    model = fus.Fus_CrossViT(OracleBackbone(vit_c), OracleBackbone(vit_e)).double()
+    model.load_state_dict(fp, strict=True)
+    assert sorted(model.state_dict().keys()) == sorted(fp.keys())
+    img_c = rng_tensor(213, (B, 3, 224, 224), dtype=torch.float64)
+    img_e = rng_tensor(214, (B, 3, 224, 224), dtype=torch.float64)
+    target = torch.tensor([2, 0])
+    fused, x_cxr, x_enh = model(OracleBackbone(vit_c), OracleBackbone(vit_e), img_c, img_e)
+    output = fused + x_cxr + x_enh                         # main_..._crossvit_..._sum.py:868
+    loss = torch.nn.CrossEntropyLoss()(output, target)     # :432,873
+    loss.backward()
+    d = dict(seed_params=201, seed_vit_cxr=211, seed_vit_enh=212, seed_img_cxr=213, seed_img_enh=214,
+             vit_depth=2, target=target.numpy())
+    put(d, "fused", fused, full=True)
+    put(d, "x_cxr", x_cxr, full=True)
+    put(d, "x_enh", x_enh, full=True)
+    put(d, "output", output, full=True)
+    put(d, "loss", loss, full=True)
+    d["preds"] = output.argmax(1).numpy()
+    for n, p in model.named_parameters():
+        put(d, "d." + n, p.grad)
+    d["n_params"] = sum(p.numel() for p in model.parameters())
+    d["keys"] = np.array(sorted(model.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "fusion_e2e.npz"), **d)
+    print("fusion_e2e.npz loss", loss.item(), "n_params", d["n_params"])
+
+
+def golden_moco():
+    import torch.distributed as dist
+    import moco.builder_vit_mocov3structure_mocov2loss as bld
+    d = {}
+    # (a) projector / predictor MLPs (train-mode BN) built by the reference's own _build_mlp
+    n, hid, mlp_dim, dim = 8, 384, 512, 256      # mlp_dim shrunk from 4096 to keep the fixture small
+    proj = bld.MoCo._build_mlp(None, 3, hid, mlp_dim, dim).double().train()
+    pred = bld.MoCo._build_mlp(None, 2, dim, mlp_dim, dim).double().train()
+    pp = ref_moco.seeded_mlp_params(301, "", 3, hid, mlp_dim, dim, dtype=torch.float64)
+    qp = ref_moco.seeded_mlp_params(302, "", 2, dim, mlp_dim, dim, dtype=torch.float64)
+    proj.load_state_dict(pp, strict=False)
+    pred.load_state_dict(qp, strict=False)
+    x = rng_tensor(303, (n, hid), dtype=torch.float64).requires_grad_(True)
+    z = proj(x)
+    q = pred(z)
+    qn = torch.nn.functional.normalize(q, dim=1)
+    r = rng_tensor(304, (n, dim), dtype=torch.float64)
+    (qn * r).sum().backward()
+    d.update(seed_proj=301, seed_pred=302, seed_x=303, seed_r=304, n=n, hid=hid, mlp_dim=mlp_dim, dim=dim)
+    put(d, "proj_out", z, full=True)
+    put(d, "pred_out", q, full=True)
+    put(d, "q_norm", qn, full=True)
+    put(d, "dx", x.grad, full=True)
+    for name, p in proj.named_parameters():
+        put(d, "dproj." + name, p.grad)
+    for name, p in pred.named_parameters():
+        put(d, "dpred." + name, p.grad)
+    for name, b in list(proj.named_buffers()) + [("pred." + k, v) for k, v in pred.named_buffers()]:
+        put(d, "buf." + name, b.double(), full=True)
+
+    # (b) EMA + enqueue through a real MoCo_ViT instance built on a toy encoder
+    class Toy(torch.nn.Module):
+        def __init__(self, num_classes=1000, **_):
+            super().__init__()
+            self.body = torch.nn.Linear(12, 16)
+            self.head = torch.nn.Linear(16, num_classes)
+
+        def forward(self, x):
+            return self.head(self.body(x))
+
+    args = types.SimpleNamespace(arch="vit_small")
+    torch.manual_seed(0)
+    m = bld.MoCo_ViT(Toy, args, dim=256, mlp_dim=64, T=0.2)
+    base = {k: rng_tensor(310 + i, v.shape) for i, (k, v) in enumerate(m.base_encoder.named_parameters())}
+    mom = {k: rng_tensor(340 + i, v.shape) for i, (k, v) in enumerate(m.momentum_encoder.named_parameters())}
+    with torch.no_grad():
+        for k, v in m.base_encoder.named_parameters():
+            v.copy_(base[k])
+        for k, v in m.momentum_encoder.named_parameters():
+            v.copy_(mom[k])
+    m._momentum_update_key_encoder(0.99)
+    d["ema_m"] = 0.99
+    d["ema_names"] = np.array(list(base.keys()))
+    d["ema_seed_base0"] = 310
+    d["ema_seed_mom0"] = 340
+    for k, v in m.momentum_encoder.named_parameters():
+        put(d, "ema." + k, v, full=True)
+    d["state_keys"] = np.array(sorted(m.state_dict().keys()))
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    K = m.K
+    d["K"] = K
+    q0 = rng_tensor(360, (256, K))
+    m.queue.copy_(torch.nn.functional.normalize(q0, dim=0))
+    m.queue_ptr[0] = K - 32                       # next enqueue wraps the pointer to 0
+    keys = torch.nn.functional.normalize(rng_tensor(361, (32, 256)), dim=1)
+    qv = torch.nn.functional.normalize(rng_tensor(362, (4, 256)), dim=1)
+    kv = torch.nn.functional.normalize(rng_tensor(363, (4, 256)), dim=1)
+    # logits exactly as builder:183-191 evaluates them (einsum forms), on the reference's own queue buffer
+    l_pos = torch.einsum('nc,nc->n', [qv, kv]).unsqueeze(-1)
+    l_neg = torch.einsum('nc,ck->nk', [qv, m.queue.clone().detach()])
+    logits = torch.cat([l_pos, l_neg], dim=1)
+    logits /= m.T
+    put(d, "nce_logits", logits)
+    put(d, "nce_loss", torch.nn.CrossEntropyLoss()(logits, torch.zeros(4, dtype=torch.long)), full=True)
+    m._dequeue_and_enqueue(keys)
+    d["enq_ptr_before"] = K - 32
+    d["enq_ptr_after"] = int(m.queue_ptr)
+    put(d, "enq_cols", m.queue[:, K - 32:], full=True)
+    put(d, "enq_untouched", m.queue[:, :64], full=True)
+    d.update(seed_queue=360, seed_keys=361, seed_q=362, seed_k=363, T=0.2)
+    dist.destroy_process_group()
+    np.savez_compressed(os.path.join(OUT, "moco_pieces.npz"), **d)
+    print("moco_pieces.npz ptr", d["enq_ptr_after"])
+
+
+def golden_lars():
+    from moco.optimizer import LARS
+    shapes = [(6, 5), (5,), (4, 3), (3, 2)]
+    ps = [torch.nn.Parameter(rng_tensor(400 + i, s)) for i, s in enumerate(shapes)]
+    with torch.no_grad():
+        ps[3].zero_()                                       # param_norm == 0 branch (optimizer.py:31-34)
+    wd = 2.0 ** -6                                           # exact in binary: g = -wd*p cancels exactly
+    opt = LARS(ps, lr=0.3, weight_decay=wd, momentum=0.9)
+    d = dict(lr=0.3, weight_decay=wd, momentum=0.9, trust=0.001, n=len(shapes),
+             shapes=np.array([str(s) for s in shapes]))
+    for step in range(3):
+        for i, p in enumerate(ps):
+            p.grad = rng_tensor(410 + 10 * step + i, p.shape)
+            if step == 1 and i == 2:
+                p.grad.zero_()
+                with torch.no_grad():
+                    p.grad -= wd * p                      # update_norm == 0 branch
+        opt.step()
+        for i, p in enumerate(ps):
+            d[f"p{i}.step{step}"] = p.detach().double().numpy()
+    np.savez_compressed(os.path.join(OUT, "lars.npz"), **d)
+    print("lars.npz")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    golden_cross_attention()
+    golden_fusion()
+    golden_moco()
+    golden_lars()
