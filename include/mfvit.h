@@ -1,0 +1,128 @@
+/* libmfvit_hip.so - C ABI of the MI355X-native (gfx950) Multi-Feature-ViT hot path.
+ *
+ * The reference (endiqq/Multi-Feature-ViT) is pure Python on stock PyTorch: it has no FFI.  Its drop-in boundary
+ * is the Python constructor / train-step API.  This C ABI is the layer underneath that API: every
+ * entry point replaces a group of ATen ops dispatched by a cited piece of reference Python, takes plain device
+ * pointers and sizes, never allocates, never synchronises, launches on the given HIP stream, and returns
+ * 0 or a negative errno-style code (MFVIT_E*).  The caller owns all memory.  Thread-safe and stream-ordered.
+ *
+ * Paths below are relative to the reference root; MOD = moco_pretraining/moco/model/module.py,
+ * FUS = moco_pretraining/moco/model/crossvit_2vits_2additionaloutputs_..._std002_sum.py,
+ * BLD = moco_pretraining/moco/moco/builder_vit_mocov3structure_mocov2loss.py, OPT = moco_pretraining/moco/moco/optimizer.py,
+ * MAIN_CA / MAIN_SS / MAIN_MOCO = the three main_*.py drivers (SURVEY.md alias table).
+ */
+#ifndef MFVIT_H
+#define MFVIT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mfvit_stream_t; /* hipStream_t */
+
+#define MFVIT_OK 0
+#define MFVIT_EINVAL (-22)
+#define MFVIT_ENOSYS (-38)
+#define MFVIT_ELAUNCH (-5)
+
+#define MFVIT_F32 0  /* exact-f32 MFMA path (parity mode: logits within 1e-3 of the f32 CPU oracle) */
+#define MFVIT_BF16 1 /* bf16 operands, f32 accumulate / residual / statistics (throughput mode) */
+
+int mfvit_abi_version(void);
+const char* mfvit_build_info(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ViT-S/16 encoder (the backbone the reference imports as `vits` / `vits_returnftrs`, ABSENT from its tree;
+ * call sites MAIN_SS:276,711  MAIN_CA:289-290  FUS:80,83,128-135  BLD:29-30,164,174; spec SURVEY.md Appendix A).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct mfvit_vit_cfg {
+    int dtype;           /* MFVIT_F32 | MFVIT_BF16 : storage / MFMA operand type of activations and weight shadows */
+    int batch;           /* images */
+    int img_h, img_w;    /* multiples of 16 */
+    int dim;             /* 384 (vit_small) */
+    int depth;           /* 12 */
+    int heads;           /* 12 -> head_dim 32 */
+    int mlp_dim;         /* 1536 */
+    int save_for_backward; /* 1: keep per-layer activations in the workspace */
+    int stop_grad_conv1; /* 1: no gradient for patch_embed.proj.{weight,bias} (MAIN_MOCO:127-128,274) */
+    float ln_eps;        /* 1e-6 */
+} mfvit_vit_cfg;
+
+/* Parameter arena: one contiguous f32 buffer, tensors in timm registration order
+ *   cls_token, pos_embed, patch_embed.proj.weight, patch_embed.proj.bias,
+ *   blocks.i.{norm1.weight, norm1.bias, attn.qkv.weight, attn.qkv.bias, attn.proj.weight, attn.proj.bias,
+ *             norm2.weight, norm2.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias} (i = 0..depth-1),
+ *   norm.weight, norm.bias          (the classifier `head` is NOT part of the arena: BLD:218-222 replaces it)
+ * The gradient arena has the same layout. */
+size_t mfvit_vit_param_count(const mfvit_vit_cfg* cfg);
+/* offsets (in floats) of: [0] cls_token [1] pos_embed [2] pe.weight [3] pe.bias [4] blocks.0 [5] block stride
+ * [6] norm.weight [7] norm.bias [8] total */
+int mfvit_vit_param_layout(const mfvit_vit_cfg* cfg, int64_t out[9]);
+
+/* Weight shadow: dtype-typed copies the MFMA kernels read (bf16: W and W^T of every Linear; f32: W^T only).
+ * Must be refreshed (mfvit_vit_prepare_shadow) after every parameter update. */
+size_t mfvit_vit_shadow_bytes(const mfvit_vit_cfg* cfg);
+int mfvit_vit_prepare_shadow(const mfvit_vit_cfg* cfg, const float* params, void* shadow, mfvit_stream_t stream);
+
+size_t mfvit_vit_workspace_bytes(const mfvit_vit_cfg* cfg);
+
+/* features3D(img): (B,3,H,W) f32 NCHW -> tokens (B, 1+HW/256, dim) f32 after the final LayerNorm
+ * (replaces patch_embed -> cat(cls) -> +pos_embed -> 12 x Block -> norm; FUS:128,133; crossvit.py:130-146). */
+int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, const float* img, void* workspace,
+                      float* features, mfvit_stream_t stream);
+
+/* Backward of mfvit_vit_forward.  Stages are numbered depth (final norm), depth-1 .. 0 (blocks), -1 (patch embed +
+ * cls token); [stage_hi .. stage_lo] are run in descending order so the host can interleave per-block gradient
+ * all-reduce with the remaining backward.  dparams is ACCUMULATED into (zero it for a fresh gradient).
+ * dfeatures: (B,T,dim) f32, read only when stage_hi == depth. */
+int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, void* workspace, const float* dfeatures,
+                       float* dparams, int stage_hi, int stage_lo, mfvit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Single ops (exposed for parity tests and for the MoCo projector / predictor path).
+ * ------------------------------------------------------------------------------------------------------------ */
+/* y[M][N] = x[M][K] W[N][K]^T + bias   (nn.Linear forward; x, W, y of `dtype`; epilogue 0 bias, 1 bias+GELU(erf)
+ * writing pre-activation to y and activation to y2, 3 none).  N % 128 == 0, K % 64 == 0. */
+int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
+                     int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream);
+/* dW[N][K] (f32, accumulated) += dy[M][N]^T x[M][K]   (nn.Linear weight gradient).  N % 128 == 0, K % 128 == 0. */
+int mfvit_linear_wgrad(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N, int K,
+                       mfvit_stream_t stream);
+/* proj / fc2 (+ residual + following LayerNorm): x_out = a W^T + bias + res ; y = LN(x_out).  N == 384. */
+int mfvit_linear_res_ln_fwd(int dtype, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res,
+                            int64_t ldres, float* x_out, void* y, int y_f32, const float* gamma, const float* beta, float eps,
+                            float* mean, float* rstd, int M, int K, mfvit_stream_t stream);
+/* dgrad of a Linear feeding a LayerNorm, fused with the LN backward and the residual-gradient add:
+ *   dyln = dy W (W given transposed: wt[N=384][K]) ; dx = LNbwd(dyln; x, mean, rstd, gamma) + dres
+ *   column sums (accumulated): dgamma, dbeta, dcol = sum_rows dx.  dx_t (dtype copy of dx) optional. */
+int mfvit_linear_dgrad_ln_bwd(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, const float* mean,
+                              const float* rstd, const float* gamma, const float* dres, float* dx, void* dx_t, float* dgamma,
+                              float* dbeta, float* dcol, int M, int K, mfvit_stream_t stream);
+/* softmax(q k^T / sqrt(d)) v per (image, head); qkv [B][T][3][H][d], out [B][T][H*d], lse [B][H][T]. */
+int mfvit_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int head_dim, mfvit_stream_t stream);
+int mfvit_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias_qkv,
+                        int B, int T, int H, int head_dim, mfvit_stream_t stream);
+/* LayerNorm over rows of width N in {384, 768} (f32 in; y of dtype or f32). */
+int mfvit_layernorm_fwd(int dtype, const float* x, void* y, int y_f32, const float* gamma, const float* beta, float eps, float* mean,
+                        float* rstd, int rows, int N, mfvit_stream_t stream);
+int mfvit_layernorm_bwd(int dtype, const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* dres, float* dx, void* dx_t, float* dgamma, float* dbeta, float* dcol, int rows, int N,
+                        mfvit_stream_t stream);
+/* f32 [R][C] -> dtype [R][C] (dst, optional) and dtype [C][R] (dst_t, optional). */
+int mfvit_cast_transpose(int dtype, const float* src, void* dst, void* dst_t, int R, int C, mfvit_stream_t stream);
+/* classifier heads with a handful of classes (MAIN_CA:309-310, FUS:105-113): y = x W^T + b over rows x[m*ldx]. */
+int mfvit_head_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int M, int N, int K, int accumulate,
+                   mfvit_stream_t stream);
+int mfvit_head_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* w, float* dx, int64_t lddx, int dx_accumulate,
+                   float* dw, float* db, int M, int N, int K, mfvit_stream_t stream);
+/* nn.CrossEntropyLoss (mean) for C <= 64 classes (MAIN_CA:873, MAIN_SS:714): loss_mean[1], dlogits = dloss/dlogits,
+ * preds = argmax (MAIN_CA:870). */
+int mfvit_cross_entropy(const float* logits, const int64_t* target, float* loss_mean, float* dlogits, int64_t* preds, int B, int C,
+                        mfvit_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFVIT_H */

@@ -1,0 +1,86 @@
+// Shared device helpers for the MF-ViT gfx950 kernels (wave64, MFMA, LDS).
+// gfx950 only: no CUDA / multi-backend paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mfvit.h"
+
+namespace mfvit {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// error codes (MFVIT_OK / MFVIT_E*) and dtype tags (MFVIT_F32 / MFVIT_BF16) come from the public header
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }  // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx [ x * Phi(x) ] = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x == NT (multiple of 64); scratch must hold NT/64 floats. All threads get the result.
+template <int NT> __device__ __forceinline__ float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += scratch[i];
+    return t;
+}
+template <int NT> __device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = v;
+    __syncthreads();
+    float t = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) t = fmaxf(t, scratch[i]);
+    return t;
+}
+
+// XCD-aware bijective block remap (8 XCDs, blocks dealt round-robin): blocks that are neighbours in the
+// remapped id share an XCD / L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}
+
+#define MFVIT_CHECK_LAUNCH()                                  \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return MFVIT_ELAUNCH;         \
+    } while (0)
+
+}  // namespace mfvit

@@ -1,0 +1,344 @@
+// HBM-bound helper kernels of the encoder path (gfx950): patch gather, cls row, LayerNorm rows (fwd / bwd),
+// weight cast + transpose, small linear heads, small-C cross entropy.  All wave64, 16-B vector access where the
+// layout allows it.  Roofline for every kernel here: HBM bytes (each tensor touched once).
+#include "common.cuh"
+
+namespace mfvit {
+
+// ---------------------------------------------------------------------------------------------- im2col
+// img (B,3,H,W) f32 NCHW -> P [B*gh*gw][3*16*16] (k = c*256 + py*16 + px, the flatten order of Conv2d weight
+// (D,3,16,16)); one thread moves 8 consecutive pixels (32 B in, 16/32 B out).
+template <typename T>
+__global__ void im2col16_kernel(const float* __restrict__ img, T* __restrict__ P, int B, int Hh, int Ww) {
+    const int gh = Hh / 16, gw = Ww / 16;
+    const long total = (long)B * gh * gw * 3 * 16 * 2;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const int half = q & 1;
+        long r = q >> 1;
+        const int py = r % 16; r /= 16;
+        const int c = r % 3; r /= 3;
+        const int pw = r % gw; r /= gw;
+        const int ph = r % gh; r /= gh;
+        const int b = (int)r;
+        const float* s = img + (((long)b * 3 + c) * Hh + ph * 16 + py) * Ww + pw * 16 + half * 8;
+        const float4 v0 = *(const float4*)s, v1 = *(const float4*)(s + 4);
+        T* d = P + ((long)(b * gh + ph) * gw + pw) * 768 + c * 256 + py * 16 + half * 8;
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 o;
+            o[0] = (bf16)v0.x; o[1] = (bf16)v0.y; o[2] = (bf16)v0.z; o[3] = (bf16)v0.w;
+            o[4] = (bf16)v1.x; o[5] = (bf16)v1.y; o[6] = (bf16)v1.z; o[7] = (bf16)v1.w;
+            *(bf16x8*)d = o;
+        } else {
+            *(float4*)d = v0;
+            *(float4*)(d + 4) = v1;
+        }
+    }
+}
+int im2col16(int dtype, const float* img, void* P, int B, int H, int W, hipStream_t st) {
+    if (H % 16 || W % 16) return MFVIT_EINVAL;
+    const long total = (long)B * (H / 16) * (W / 16) * 96;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == MFVIT_BF16)
+        hipLaunchKernelGGL(im2col16_kernel<bf16>, dim3(blocks), dim3(256), 0, st, img, (bf16*)P, B, H, W);
+    else
+        hipLaunchKernelGGL(im2col16_kernel<float>, dim3(blocks), dim3(256), 0, st, img, (float*)P, B, H, W);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------- LayerNorm rows (fwd)
+// One wave per row.  x_row = in0[row*ld0] (+ in1[(row % mod1)*ld1] if in1).  Writes optional xout (f32), y (T or f32),
+// mean, rstd.  Rows are addressed through (row_stride, row_off): global row g = r * row_stride + row_off.
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ in0, long ld0, const float* __restrict__ in1, long ld1,
+                                                      int mod1, float* __restrict__ xout, long ldx, void* __restrict__ y, long ldy, int y_f32,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int row_stride,
+                                                      int row_off, int in0_bcast) {
+    constexpr int N = NPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long g = (long)r * row_stride + row_off;
+    float v[NPL];
+    const float* p0 = in0 + (in0_bcast ? 0 : g * ld0);
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] = p0[lane + 64 * i];
+    if (in1) {
+        const float* p1 = in1 + (long)(mod1 ? g % mod1 : g) * ld1;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) v[i] += p1[lane + 64 * i];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) s += v[i];
+    const float mu = wave_sum(s) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { const float d = v[i] - mu; q += d * d; }
+    const float rs = rsqrtf(wave_sum(q) * (1.0f / N) + eps);
+    if (lane == 0) {
+        if (mean) mean[g] = mu;
+        if (rstd) rstd[g] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int n = lane + 64 * i;
+        if (xout) xout[g * ldx + n] = v[i];
+        const float o = (v[i] - mu) * rs * gamma[n] + beta[n];
+        if (y) {
+            if (y_f32) ((float*)y)[g * ldy + n] = o;
+            else ((T*)y)[g * ldy + n] = from_f32<T>(o);
+        }
+    }
+}
+int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long ld1, int mod1, float* xout, long ldx, void* y, long ldy,
+            int y_f32, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int rows, int row_stride, int row_off,
+            int in0_bcast, hipStream_t st) {
+    if (rows <= 0) return MFVIT_OK;
+    const dim3 grid((rows + 3) / 4), blk(256);
+#define MFVIT_LN(TT, NPL)                                                                                                        \
+    hipLaunchKernelGGL((ln_rows_kernel<TT, NPL>), grid, blk, 0, st, in0, ld0, in1, ld1, mod1, xout, ldx, y, ldy, y_f32, gamma, beta, eps, \
+                       mean, rstd, rows, row_stride, row_off, in0_bcast)
+    if (N == 384) { if (dtype == MFVIT_BF16) MFVIT_LN(bf16, 6); else MFVIT_LN(float, 6); }
+    else if (N == 768) { if (dtype == MFVIT_BF16) MFVIT_LN(bf16, 12); else MFVIT_LN(float, 12); }
+    else return MFVIT_EINVAL;
+#undef MFVIT_LN
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------- LayerNorm rows (bwd)
+// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)) (+ dres);  column sums: dgamma, dbeta, sum(dx).
+// One wave per row, rows grid-strided; column partials are kept per lane and reduced over the block's 4 waves in LDS.
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ dres, long ldres,
+                                                          float* __restrict__ dx, long lddx, T* __restrict__ dxT, long lddxT,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dcol,
+                                                          int rows, int row_stride, int row_off) {
+    constexpr int N = NPL * 64;
+    __shared__ float red[3][4][N];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float gm[NPL], ag[NPL], ab[NPL], ax[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { gm[i] = gamma[lane + 64 * i]; ag[i] = ab[i] = ax[i] = 0.f; }
+    for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+        const long g = (long)r * row_stride + row_off;
+        const float mu = mean[g], rs = rstd[g];
+        float d[NPL], h[NPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int n = lane + 64 * i;
+            d[i] = dy[g * lddy + n];
+            h[i] = (x[g * ldx + n] - mu) * rs;
+            const float t = d[i] * gm[i];
+            s1 += t;
+            s2 += t * h[i];
+            ag[i] += d[i] * h[i];
+            ab[i] += d[i];
+        }
+        const float c1 = wave_sum(s1) * (1.0f / N), c2 = wave_sum(s2) * (1.0f / N);
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int n = lane + 64 * i;
+            float o = rs * (d[i] * gm[i] - c1 - h[i] * c2);
+            if (dres) o += dres[g * ldres + n];
+            if (dx) dx[g * lddx + n] = o;
+            if (dxT) dxT[g * lddxT + n] = from_f32<T>(o);
+            ax[i] += o;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        red[0][w][lane + 64 * i] = ag[i];
+        red[1][w][lane + 64 * i] = ab[i];
+        red[2][w][lane + 64 * i] = ax[i];
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float a = red[0][0][n] + red[0][1][n] + red[0][2][n] + red[0][3][n];
+        const float b = red[1][0][n] + red[1][1][n] + red[1][2][n] + red[1][3][n];
+        const float c = red[2][0][n] + red[2][1][n] + red[2][2][n] + red[2][3][n];
+        if (dgamma) atomicAdd(dgamma + n, a);
+        if (dbeta) atomicAdd(dbeta + n, b);
+        if (dcol) atomicAdd(dcol + n, c);
+    }
+}
+int ln_bwd_rows(int dtype, int N, const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
+                const float* gamma, const float* dres, long ldres, float* dx, long lddx, void* dxT, long lddxT, float* dgamma, float* dbeta,
+                float* dcol, int rows, int row_stride, int row_off, hipStream_t st) {
+    if (rows <= 0) return MFVIT_OK;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+#define MFVIT_LNB(TT, NPL)                                                                                                         \
+    hipLaunchKernelGGL((ln_bwd_rows_kernel<TT, NPL>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres, ldres, dx, \
+                       lddx, (TT*)dxT, lddxT, dgamma, dbeta, dcol, rows, row_stride, row_off)
+    if (N == 384) { if (dtype == MFVIT_BF16) MFVIT_LNB(bf16, 6); else MFVIT_LNB(float, 6); }
+    else if (N == 768) { if (dtype == MFVIT_BF16) MFVIT_LNB(bf16, 12); else MFVIT_LNB(float, 12); }
+    else return MFVIT_EINVAL;
+#undef MFVIT_LNB
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
+// --------------------------------------------------------------------------------------- cast + transpose
+// src f32 [R][C] -> dst T [R][C] (optional) and dstT T [C][R] (optional); 64x64 tiles through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, T* __restrict__ dstT, int R,
+                                                             int C) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int q = threadIdx.x; q < 64 * 64; q += 256) {
+        const int r = q >> 6, c = q & 63;
+        float v = 0.f;
+        if (r0 + r < R && c0 + c < C) {
+            v = src[(long)(r0 + r) * C + c0 + c];
+            if (dst) dst[(long)(r0 + r) * C + c0 + c] = from_f32<T>(v);
+        }
+        tile[r][c] = v;
+    }
+    __syncthreads();
+    if (dstT) {
+        for (int q = threadIdx.x; q < 64 * 64; q += 256) {
+            const int c = q >> 6, r = q & 63;
+            if (r0 + r < R && c0 + c < C) dstT[(long)(c0 + c) * R + r0 + r] = from_f32<T>(tile[r][c]);
+        }
+    }
+}
+int cast_transpose(int dtype, const float* src, void* dst, void* dstT, int R, int C, hipStream_t st) {
+    const dim3 grid((C + 63) / 64, (R + 63) / 64);
+    if (dtype == MFVIT_BF16)
+        hipLaunchKernelGGL(cast_transpose_kernel<bf16>, grid, dim3(256), 0, st, src, (bf16*)dst, (bf16*)dstT, R, C);
+    else
+        hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, (float*)dstT, R, C);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
+// --------------------------------------------------------------------------------------- small linear heads
+// y[m][n] = x[m*ldx .. +K] . W[n][K] + b[n]   (f32; one wave per output; for heads with a handful of classes)
+__global__ __launch_bounds__(256) void linear_small_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W,
+                                                               const float* __restrict__ b, float* __restrict__ y, long ldy, int M, int N,
+                                                               int K, int accumulate) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= M * N) return;
+    const int m = o / N, n = o % N;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(x[(long)m * ldx + k], W[(long)n * K + k], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+        s += b ? b[n] : 0.f;
+        if (accumulate) y[(long)m * ldy + n] += s; else y[(long)m * ldy + n] = s;
+    }
+}
+// dx[m][k] (+)= sum_n dy[m][n] W[n][k];  dW[n][k] += sum_m dy[m][n] x[m][k];  db[n] += sum_m dy[m][n]
+__global__ __launch_bounds__(256) void linear_small_bwd_kernel(const float* __restrict__ dy, long lddy, const float* __restrict__ x, long ldx,
+                                                               const float* __restrict__ W, float* __restrict__ dx, long lddx,
+                                                               int dx_accumulate, float* __restrict__ dW, float* __restrict__ db, int M,
+                                                               int N, int K) {
+    const long id = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (dx && id < (long)M * K) {
+        const int m = id / K, k = id % K;
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s = fmaf(dy[(long)m * lddy + n], W[(long)n * K + k], s);
+        if (dx_accumulate) dx[(long)m * lddx + k] += s; else dx[(long)m * lddx + k] = s;
+    }
+    if (dW && id < (long)N * K) {
+        const int n = id / K, k = id % K;
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s = fmaf(dy[(long)m * lddy + n], x[(long)m * ldx + k], s);
+        dW[(long)n * K + k] += s;
+    }
+    if (db && id < N) {
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += dy[(long)m * lddy + id];
+        db[id] += s;
+    }
+}
+int linear_small_fwd(const float* x, long ldx, const float* W, const float* b, float* y, long ldy, int M, int N, int K, int accumulate,
+                     hipStream_t st) {
+    hipLaunchKernelGGL(linear_small_fwd_kernel, dim3((M * N + 3) / 4), dim3(256), 0, st, x, ldx, W, b, y, ldy, M, N, K, accumulate);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int linear_small_bwd(const float* dy, long lddy, const float* x, long ldx, const float* W, float* dx, long lddx, int dx_accumulate, float* dW,
+                     float* db, int M, int N, int K, hipStream_t st) {
+    long work = (long)M * K;
+    if ((long)N * K > work) work = (long)N * K;
+    hipLaunchKernelGGL(linear_small_bwd_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dy, lddy, x, ldx, W, dx, lddx,
+                       dx_accumulate, dW, db, M, N, K);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
+// --------------------------------------------------------------------------------------- small-C cross entropy
+// nn.CrossEntropyLoss (mean) over logits [B][C], C <= 64: one thread per sample.  loss_sum must be zeroed by the caller;
+// writes dlogits = (softmax - onehot) / B and preds (argmax, first maximum like torch.max).
+__global__ void ce_small_kernel(const float* __restrict__ logits, const long* __restrict__ target, float* __restrict__ loss_mean,
+                                float* __restrict__ dlogits, long* __restrict__ preds, int B, int C) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    float li = 0.f;
+    if (b < B) {
+        const float* z = logits + (long)b * C;
+        float m = z[0];
+        int am = 0;
+        for (int c = 1; c < C; ++c) if (z[c] > m) { m = z[c]; am = c; }
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += __expf(z[c] - m);
+        const float lse = m + __logf(s);
+        const int t = (int)target[b];
+        li = (lse - z[t]) / (float)B;
+        if (dlogits)
+            for (int c = 0; c < C; ++c) dlogits[(long)b * C + c] = (__expf(z[c] - lse) - (c == t ? 1.f : 0.f)) / (float)B;
+        if (preds) preds[b] = am;
+    }
+    li = wave_sum(li);
+    if ((threadIdx.x & 63) == 0 && li != 0.f) atomicAdd(loss_mean, li);
+}
+int ce_small(const float* logits, const long* target, float* loss_mean, float* dlogits, long* preds, int B, int C, hipStream_t st) {
+    if (C > 64 || C < 1) return MFVIT_EINVAL;
+    if (hipMemsetAsync(loss_mean, 0, sizeof(float), st) != hipSuccess) return MFVIT_ELAUNCH;
+    hipLaunchKernelGGL(ce_small_kernel, dim3((B + 255) / 256), dim3(256), 0, st, logits, target, loss_mean, dlogits, preds, B, C);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
+// --------------------------------------------------------------------------------------- misc
+__global__ void add_rows_kernel(float* __restrict__ dst, long ldd, const float* __restrict__ src, long lds_, int rows, int N) {
+    const long id = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (id < (long)rows * N) dst[(id / N) * ldd + id % N] += src[(id / N) * lds_ + id % N];
+}
+int add_rows(float* dst, long ldd, const float* src, long lds_, int rows, int N, hipStream_t st) {
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)(((long)rows * N + 255) / 256)), dim3(256), 0, st, dst, ldd, src, lds_, rows, N);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fmaf(a, x[i], y[i]);
+}
+int axpy(float* y, const float* x, float a, long n, hipStream_t st) {
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, a, n);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+// column sum of selected rows: out[n] += sum_r x[(r*row_stride + row_off)*ld + n]   (f32)
+__global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restrict__ x, long ld, float* __restrict__ out, int rows,
+                                                          int row_stride, int row_off, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) s += x[((long)r * row_stride + row_off) * ld + n];
+    atomicAdd(out + n, s);
+}
+int colsum_rows(const float* x, long ld, float* out, int rows, int row_stride, int row_off, int N, hipStream_t st) {
+    int gy = rows < 64 ? rows : 64;
+    hipLaunchKernelGGL(colsum_rows_kernel, dim3((N + 255) / 256, gy), dim3(256), 0, st, x, ld, out, rows, row_stride, row_off, N);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
+}  // namespace mfvit

@@ -1,0 +1,266 @@
+// MFMA GEMM building blocks for gfx950 (CDNA4): LDS tile images, fragment loaders, main loops.
+//
+// Two operand images per element type T:
+//   * "K-contiguous" operands (activations [M][K], weights [N][K]):
+//       bf16: LDS image [row][BK] with 16-B chunks XOR-swizzled so that the ds_read_b128 fragment reads of
+//             16 consecutive rows hit 16 distinct 16-B slots of the 256-B bank row (conflict-free);
+//       f32 : LDS image [k][row + pad] (k-major) read with ds_read_b32, one float per lane, as the
+//             v_mfma_f32_32x32x2_f32 operand map wants (A[i = lane&31][k = lane>>5]).
+//   * "K-strided" operands (wgrad: dY [m][n] and X [m][k], reduction index m is the slow axis):
+//       bf16: LDS image [m][row + 32] copied as is (rows 16-B aligned, 320-B pitch) and read with the
+//             transposing ds_read_b64_tr_b16 (two per fragment);
+//       f32 : LDS image [m][row + 4], again one ds_read_b32 per fragment.
+// MFMA shapes: v_mfma_f32_32x32x16_bf16 (8 bf16 per lane per operand) and v_mfma_f32_32x32x2_f32.
+// C/D map (both): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma once
+#include "common.cuh"
+
+namespace mfvit {
+
+template <typename T> struct MmaTraits;
+template <> struct MmaTraits<bf16> {
+    typedef bf16x8 frag_t;
+    static constexpr int KSTEP = 16;  // k elements consumed per MFMA
+    static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct MmaTraits<float> {
+    typedef float frag_t;
+    static constexpr int KSTEP = 2;
+    static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// K-contiguous tile image: R rows, BKB bytes of k per row (64 or 128).
+template <typename T, int R, int BKB> struct KTile;
+
+template <int R, int BKB> struct KTile<bf16, R, BKB> {
+    static constexpr int CPR = BKB / 16;            // 16-B chunks per row
+    static constexpr int RPW = 16 / CPR;            // rows per 256-B bank row
+    static constexpr int BYTES = R * BKB;
+    static constexpr int KSTEPS = BKB / 32;         // 16 bf16 = 32 B per MFMA step
+    static __device__ __forceinline__ int off(int row, int c) { return row * BKB + 16 * (c ^ ((row / RPW) % CPR)); }
+    static __device__ __forceinline__ void put(char* t, int row, int c, uint4 v) { *(uint4*)(t + off(row, c)) = v; }
+    // fragment for MFMA step s: lane holds row (rowbase + lane&31), k = 16 s + 8 (lane>>5) .. +8
+    static __device__ __forceinline__ bf16x8 frag(const char* t, int rowbase, int s, int lane) {
+        return *(const bf16x8*)(t + off(rowbase + (lane & 31), 2 * s + (lane >> 5)));
+    }
+};
+
+template <int R, int BKB> struct KTile<float, R, BKB> {
+    static constexpr int CPR = BKB / 16;
+    static constexpr int BK = BKB / 4;
+    static constexpr int PAD = (CPR == 4) ? 2 : 1;  // makes the 4 x ds_write_b32 of a staged chunk conflict-free
+    static constexpr int LDR = R + PAD;
+    static constexpr int BYTES = BK * LDR * 4;
+    static constexpr int KSTEPS = BK / 2;
+    static __device__ __forceinline__ void put(char* t, int row, int c, uint4 v) {
+        float* f = (float*)t;
+        const int k = 4 * c;
+        f[(k + 0) * LDR + row] = __uint_as_float(v.x);
+        f[(k + 1) * LDR + row] = __uint_as_float(v.y);
+        f[(k + 2) * LDR + row] = __uint_as_float(v.z);
+        f[(k + 3) * LDR + row] = __uint_as_float(v.w);
+    }
+    static __device__ __forceinline__ float frag(const char* t, int rowbase, int s, int lane) {
+        return ((const float*)t)[(2 * s + (lane >> 5)) * LDR + rowbase + (lane & 31)];
+    }
+};
+
+// Register-staged global -> LDS copy of a K-contiguous tile (R rows x BKB bytes) by NT threads.
+template <typename T, int R, int BKB, int NT> struct KStage {
+    typedef KTile<T, R, BKB> Tile;
+    static constexpr int CPR = BKB / 16;
+    static constexpr int NCH = R * CPR / NT;
+    static constexpr int EPC = 16 / sizeof(T);  // elements per chunk
+    static_assert(R * CPR % NT == 0, "tile chunks must divide over the block");
+    uint4 reg[NCH];
+    // rows >= rmax are clamped (their products are never stored)
+    __device__ __forceinline__ void load(const T* base, long ld, int row0, int rmax, int k0, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int q = tid + i * NT, row = q / CPR, c = q % CPR;
+            int gr = row0 + row;
+            gr = gr < rmax ? gr : rmax - 1;
+            reg[i] = *(const uint4*)(base + (long)gr * ld + k0 + c * EPC);
+        }
+    }
+    __device__ __forceinline__ void store(char* t, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int q = tid + i * NT, row = q / CPR, c = q % CPR;
+            Tile::put(t, row, c, reg[i]);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// K-strided tile image (wgrad operands): KR reduction rows x R "row" elements, global layout [m][row].
+template <typename T, int R, int KR> struct STile;
+
+template <int R, int KR> struct STile<bf16, R, KR> {
+    static constexpr int LD = R + 32;               // 320-B pitch for R = 128: the 4 rows of a tr-read block land
+    static constexpr int BYTES = KR * LD * 2;       // in 4 disjoint 64-B windows of the 256-B bank row
+    static constexpr int KSTEPS = KR / 16;
+    // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(row) block; lane 4q+p supplies &img[k0+q][row0+4p],
+    // lane i receives column i, element q = row k0+q.  Two of them give k = 8h .. 8h+7 for row (lane&31).
+    static __device__ __forceinline__ bf16x8 frag(const char* t, int rowbase, int s, int lane) {
+        const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+        const int k0 = 16 * s + 8 * h + q;
+        const int col = rowbase + 16 * g1 + 4 * p;
+        typedef __attribute__((address_space(3))) s16x4* lptr;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(t + ((k0)*LD + col) * 2));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(t + ((k0 + 4) * LD + col) * 2));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo;
+        u.s.b = hi;
+        return u.v;
+    }
+};
+template <int R, int KR> struct STile<float, R, KR> {
+    static constexpr int LD = R + 4;
+    static constexpr int BYTES = KR * LD * 4;
+    static constexpr int KSTEPS = KR / 2;
+    static __device__ __forceinline__ float frag(const char* t, int rowbase, int s, int lane) {
+        return ((const float*)t)[(2 * s + (lane >> 5)) * LD + rowbase + (lane & 31)];
+    }
+};
+
+// Register-staged copy of a K-strided tile: KR rows (m) x R elements, straight 16-B copies.
+template <typename T, int R, int KR, int NT> struct SStage {
+    typedef STile<T, R, KR> Tile;
+    static constexpr int EPC = 16 / sizeof(T);
+    static constexpr int CPRW = R / EPC;  // chunks per m-row
+    static constexpr int NCH = KR * CPRW / NT;
+    static_assert(KR * CPRW % NT == 0, "tile chunks must divide over the block");
+    uint4 reg[NCH];
+    // m rows >= mmax are zero-filled (they would otherwise add into the reduction)
+    // (rin, rout, roff): optional row remap  m -> (m / rin) * rout + m % rin + roff  (patch rows -> token rows)
+    __device__ __forceinline__ void load(const T* base, long ld, int m0, int mmax, int c0, int tid, int rin = 0, int rout = 0,
+                                         int roff = 0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int q = tid + i * NT, m = q / CPRW, c = q % CPRW;
+            const int mm = m0 + m;
+            const long gr = rin ? (long)(mm / rin) * rout + (mm % rin) + roff : mm;
+            if (mm < mmax)
+                reg[i] = *(const uint4*)(base + gr * ld + c0 + c * EPC);
+            else
+                reg[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void store(char* t, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int q = tid + i * NT, m = q / CPRW, c = q % CPRW;
+            *(uint4*)(t + ((long)m * Tile::LD + c * EPC) * sizeof(T)) = reg[i];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Parameter block shared by every GEMM kernel (plain C layout; filled by the C ABI entry points).
+struct GemmP {
+    const void* A; long lda;
+    const void* W; long ldw;
+    int M, N, K;
+    const float* bias;
+    void* out0; long ldo0;
+    void* out1; long ldo1;
+    const void* aux; long ldaux;
+    const float* res; long ldres;
+    int res_mod, res_off;
+    int orow_in, orow_out, orow_off;
+    const float* gamma; const float* beta; float eps;
+    float* mean; float* rstd;
+    float* cs0; float* cs1; float* cs2;
+    int y_f32;
+    int splits;        // wgrad: number of m-splits (grid.y)
+    // two-level batch over blockIdx.z = zo * nbi + zi (element offsets; bias/out0 only)
+    int nb, nbi;
+    long sAo, sAi, sWo, sWi, sOo, sOi, sBo, sBi;
+};
+
+// apply the batch offsets of blockIdx.z to a by-value copy of the parameter block
+template <typename T> __device__ __forceinline__ void apply_batch(GemmP& p, int out_elem_bytes) {
+    if (p.nb <= 1) return;
+    const int z = blockIdx.z, zo = z / p.nbi, zi = z % p.nbi;
+    p.A = (const T*)p.A + zo * p.sAo + zi * p.sAi;
+    p.W = (const T*)p.W + zo * p.sWo + zi * p.sWi;
+    p.out0 = (char*)p.out0 + (zo * p.sOo + zi * p.sOi) * out_elem_bytes;
+    if (p.bias) p.bias += zo * p.sBo + zi * p.sBi;
+}
+
+__device__ __forceinline__ int out_row(const GemmP& p, int m) {
+    return p.orow_in ? (m / p.orow_in) * p.orow_out + (m % p.orow_in) + p.orow_off : m;
+}
+
+// C/D register -> row within a 32x32 tile
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// ---------------------------------------------------------------------------------------------------
+// NT main loop:  acc[TM][TN] (32x32 tiles) += A[m0.., :] * W[n0.., :]^T, double-buffered LDS, one barrier
+// per K tile, next tile's global loads issued before the MFMAs of the current one (write after).
+template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int BK = BKB / (int)sizeof(T);
+    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    typedef KTile<T, BM, BKB> TA;
+    typedef KTile<T, BN, BKB> TB;
+    static constexpr int STAGE_BYTES = TA::BYTES + TB::BYTES;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+
+    static __device__ __forceinline__ void run(const GemmP& p, int m0, int n0, char* lds, f32x16 (&acc)[TM][TN]) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const T* A = (const T*)p.A;
+        const T* W = (const T*)p.W;
+        KStage<T, BM, BKB, NT> sa;
+        KStage<T, BN, BKB, NT> sb;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int nk = p.K / BK;
+        sa.load(A, p.lda, m0, p.M, 0, tid);
+        sb.load(W, p.ldw, n0, p.N, 0, tid);
+        sa.store(lds, tid);
+        sb.store(lds + TA::BYTES, tid);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* ta = lds + cur * STAGE_BYTES;
+            const char* tb = ta + TA::BYTES;
+            if (kt + 1 < nk) {
+                sa.load(A, p.lda, m0, p.M, (kt + 1) * BK, tid);
+                sb.load(W, p.ldw, n0, p.N, (kt + 1) * BK, tid);
+            }
+#pragma unroll
+            for (int s = 0; s < TA::KSTEPS; ++s) {
+                typename MmaTraits<T>::frag_t a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = TA::frag(ta, (wm * TM + i) * 32, s, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = TB::frag(tb, (wn * TN + j) * 32, s, lane);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(a[i], b[j], acc[i][j]);
+            }
+            if (kt + 1 < nk) {
+                char* na = lds + (cur ^ 1) * STAGE_BYTES;
+                sa.store(na, tid);
+                sb.store(na + TA::BYTES, tid);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+};
+
+}  // namespace mfvit

@@ -1,0 +1,407 @@
+// MFMA GEMM kernels of the MF-ViT encoder path (gfx950).
+//
+//   gemm_nt_tile  : C[M][N] = epi(A[M][K] * W[N][K]^T), 128x128 block tile, 4 waves (2x2), 64x64 per wave.
+//                   epilogues: bias | bias+GELU (pre & act) | GELU' * (.) + column sums | none
+//                   replaces torch nn.Linear fwd / dgrad of timm Block (qkv, fc1, fc2-dgrad, proj-dgrad)
+//   gemm_nt_row   : same product with a ROW-COMPLETE 64x384 tile (N == 384 == embed dim), 4 waves (1x4), so the
+//                   epilogue owns whole token rows:  +bias +residual -> LayerNorm (forward)  or
+//                   LayerNorm-backward + residual-gradient add + dgamma/dbeta/dbias column sums (backward).
+//                   replaces proj/fc2/patch-embed (+ the following nn.LayerNorm) and qkv-/fc1-dgrad (+ LN bwd)
+//   gemm_tn       : dW[N][K] += dY[m][N]^T * X[m][K] over an m-range (split over grid.y, f32 atomics),
+//                   operands K-strided -> transposing LDS reads.  replaces nn.Linear wgrad
+// Both element types: bf16 (v_mfma_f32_32x32x16_bf16) and f32 (v_mfma_f32_32x32x2_f32, exact f32).
+#include "kernels.h"
+
+namespace mfvit {
+
+
+
+
+// ------------------------------------------------------------------------------------------ tile kernel
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
+    constexpr int BM = 128, BN = 128, BKB = 128, WM = 2, WN = 2;
+    typedef NtLoop<T, BM, BN, BKB, WM, WN> Loop;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    apply_batch<T>(p, sizeof(T));
+    const int ntn = p.N / BN;
+    const int ntm = (p.M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, ntn * ntm);
+    const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
+    f32x16 acc[Loop::TM][Loop::TN];
+    Loop::run(p, m0, n0, lds, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    T* o0 = (T*)p.out0;
+    T* o1 = (T*)p.out1;
+#pragma unroll
+    for (int j = 0; j < Loop::TN; ++j) {
+        const int n = n0 + (wn * Loop::TN + j) * 32 + (lane & 31);
+        float b = 0.f;
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) b = p.bias ? p.bias[n] : 0.f;
+        float csum = 0.f;
+#pragma unroll
+        for (int i = 0; i < Loop::TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * Loop::TM + i) * 32 + acc_row(r, lane);
+                if (m >= p.M) continue;
+                float v = acc[i][j][r];
+                if (EPI == EPI_BIAS) {
+                    o0[(long)m * p.ldo0 + n] = from_f32<T>(v + b);
+                } else if (EPI == EPI_BIAS_GELU) {
+                    v += b;
+                    o0[(long)m * p.ldo0 + n] = from_f32<T>(v);            // pre-activation (saved for backward)
+                    o1[(long)m * p.ldo1 + n] = from_f32<T>(gelu_erf(v));  // activation
+                } else if (EPI == EPI_GELU_BWD) {
+                    const float pre = to_f32(((const T*)p.aux)[(long)m * p.ldaux + n]);
+                    v *= gelu_erf_grad(pre);
+                    o0[(long)m * p.ldo0 + n] = from_f32<T>(v);
+                    csum += v;
+                } else {
+                    o0[(long)m * p.ldo0 + n] = from_f32<T>(v);
+                }
+            }
+        }
+        if (EPI == EPI_GELU_BWD && p.cs0) {
+            csum += __shfl_xor(csum, 32, 64);
+            if (lane < 32) atomicAdd(p.cs0 + n, csum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- row kernel
+constexpr int ROW_BM = 64, ROW_BN = 384, ROW_BKB = 64, ROW_RS = 132;
+
+// Full-row totals of per-lane partials p[i][r] (row = i*32 + acc_row(r)), summed over the 32 column lanes of the
+// 4 waves, through LDS (red: [64][132] floats, tot: [64]).  Three barriers; all 256 threads must call it.
+template <int TM>
+__device__ __forceinline__ void row_reduce(float (&p)[TM][16], float* red, float* tot, int lane, int wave, int tid) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(i * 32 + acc_row(r, lane)) * ROW_RS + wave * 32 + (lane & 31)] = p[i][r];
+    __syncthreads();
+    {
+        const int row = tid >> 2, q = tid & 3;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 v = *(const float4*)&red[row * ROW_RS + 32 * q + 4 * k];
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (q == 0) tot[row] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[i][r] = tot[i * 32 + acc_row(r, lane)];
+    __syncthreads();
+}
+
+template <typename T, int REPI>
+__global__ __launch_bounds__(256) void gemm_nt_row_kernel(GemmP p) {
+    constexpr int BM = ROW_BM, BN = ROW_BN, WM = 1, WN = 4;
+    typedef NtLoop<T, BM, BN, ROW_BKB, WM, WN> Loop;
+    constexpr int TM = Loop::TM, TN = Loop::TN;  // 2 x 3
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int m0 = blockIdx.x * BM;
+    f32x16 acc[TM][TN];
+    Loop::run(p, m0, 0, lds, acc);  // ends with a barrier: the staging LDS is free from here on
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* red = (float*)lds;
+    float* tot = red + BM * ROW_RS;
+    const float invN = 1.0f / (float)BN;
+    int ncol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) ncol[j] = (wave * TN + j) * 32 + (lane & 31);
+
+    if (REPI == REPI_RES_LN) {
+        float bj[TN], gj[TN], btj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bj[j] = p.bias ? p.bias[ncol[j]] : 0.f;
+            gj[j] = p.gamma[ncol[j]];
+            btj[j] = p.beta[ncol[j]];
+        }
+        float part[TM][16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + acc_row(r, lane);
+                const bool ok = m < p.M;
+                const int mm = ok ? m : p.M - 1;
+                const int orow = out_row(p, mm);
+                const long rrow = p.res_mod ? (mm % p.res_mod) + p.res_off : orow;
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v = acc[i][j][r] + bj[j];
+                    if (p.res) v += p.res[rrow * p.ldres + ncol[j]];
+                    acc[i][j][r] = v;
+                    if (ok && p.out0) ((float*)p.out0)[(long)orow * p.ldo0 + ncol[j]] = v;
+                    s += v;
+                }
+                part[i][r] = s;
+            }
+        row_reduce<TM>(part, red, tot, lane, wave, tid);
+        float mu[TM][16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                mu[i][r] = part[i][r] * invN;
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float d = acc[i][j][r] - mu[i][r];
+                    s += d * d;
+                }
+                part[i][r] = s;
+            }
+        row_reduce<TM>(part, red, tot, lane, wave, tid);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + acc_row(r, lane);
+                if (m >= p.M) continue;
+                const int orow = out_row(p, m);
+                const float rs = rsqrtf(part[i][r] * invN + p.eps);
+                if (wave == 0 && (lane & 31) == 0 && p.mean) {
+                    p.mean[orow] = mu[i][r];
+                    p.rstd[orow] = rs;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float y = (acc[i][j][r] - mu[i][r]) * rs * gj[j] + btj[j];
+                    if (p.y_f32)
+                        ((float*)p.out1)[(long)orow * p.ldo1 + ncol[j]] = y;
+                    else
+                        ((T*)p.out1)[(long)orow * p.ldo1 + ncol[j]] = from_f32<T>(y);
+                }
+            }
+    } else {  // REPI_LNBWD_RES: acc = dL/dy (y = LN output); aux = saved LN input x (f32)
+        float gj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) gj[j] = p.gamma[ncol[j]];
+        f32x16 xh[TM][TN];
+        float p1[TM][16], p2[TM][16], rsv[TM][16];
+        float cs_g[TN], cs_b[TN], cs_x[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) cs_g[j] = cs_b[j] = cs_x[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + acc_row(r, lane);
+                const bool ok = m < p.M;
+                const int mm = ok ? m : p.M - 1;
+                const float mu = p.mean[mm], rs = p.rstd[mm];
+                rsv[i][r] = rs;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float x = ((const float*)p.aux)[(long)mm * p.ldaux + ncol[j]];
+                    const float h = (x - mu) * rs;
+                    const float dy = ok ? acc[i][j][r] : 0.f;
+                    acc[i][j][r] = dy;
+                    xh[i][j][r] = h;
+                    const float g = dy * gj[j];
+                    s1 += g;
+                    s2 += g * h;
+                    cs_g[j] += dy * h;
+                    cs_b[j] += dy;
+                }
+                p1[i][r] = s1;
+                p2[i][r] = s2;
+            }
+        row_reduce<TM>(p1, red, tot, lane, wave, tid);
+        row_reduce<TM>(p2, red, tot, lane, wave, tid);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + i * 32 + acc_row(r, lane);
+                if (m >= p.M) continue;
+                const float c1 = p1[i][r] * invN, c2 = p2[i][r] * invN, rs = rsv[i][r];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float dx = rs * (acc[i][j][r] * gj[j] - c1 - xh[i][j][r] * c2);
+                    if (p.res) dx += p.res[(long)m * p.ldres + ncol[j]];
+                    ((float*)p.out0)[(long)m * p.ldo0 + ncol[j]] = dx;
+                    if (p.out1) ((T*)p.out1)[(long)m * p.ldo1 + ncol[j]] = from_f32<T>(dx);
+                    cs_x[j] += dx;
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float a = cs_g[j], b = cs_b[j], c = cs_x[j];
+            a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 32, 64);
+            c += __shfl_xor(c, 32, 64);
+            if (lane < 32) {
+                if (p.cs0) atomicAdd(p.cs0 + ncol[j], a);
+                if (p.cs1) atomicAdd(p.cs1 + ncol[j], b);
+                if (p.cs2) atomicAdd(p.cs2 + ncol[j], c);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- wgrad (TN)
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
+    // out0[n][k] (f32, atomicAdd) += sum_{m in split} A[m][n] * W[m][k];  p.N = n extent, p.K = k extent, p.M = reduction
+    constexpr int BN = 128, BK2 = 128, NT = 256;
+    constexpr int KR = 64 / (int)sizeof(T);  // 32 bf16 / 16 f32 reduction rows per stage
+    typedef STile<T, BN, KR> TA;
+    typedef STile<T, BK2, KR> TB;
+    constexpr int STAGE = TA::BYTES + TB::BYTES;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    apply_batch<T>(p, 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntk = p.K / BK2;
+    const int n0 = (blockIdx.x / ntk) * BN, k0 = (blockIdx.x % ntk) * BK2;
+    int chunk = (p.M + p.splits - 1) / p.splits;
+    chunk = (chunk + KR - 1) / KR * KR;
+    const int mbeg = blockIdx.y * chunk;
+    const int mend = min(p.M, mbeg + chunk);
+    if (mbeg >= mend) return;
+    const T* A = (const T*)p.A;
+    const T* X = (const T*)p.W;
+    SStage<T, BN, KR, NT> sa;
+    SStage<T, BK2, KR, NT> sb;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nst = (mend - mbeg + KR - 1) / KR;
+    sa.load(A, p.lda, mbeg, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
+    sb.load(X, p.ldw, mbeg, mend, k0, tid);
+    sa.store(lds, tid);
+    sb.store(lds + TA::BYTES, tid);
+    __syncthreads();
+    int cur = 0;
+    for (int st = 0; st < nst; ++st) {
+        const char* ta = lds + cur * STAGE;
+        const char* tb = ta + TA::BYTES;
+        if (st + 1 < nst) {
+            sa.load(A, p.lda, mbeg + (st + 1) * KR, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
+            sb.load(X, p.ldw, mbeg + (st + 1) * KR, mend, k0, tid);
+        }
+#pragma unroll
+        for (int s = 0; s < TA::KSTEPS; ++s) {
+            typename MmaTraits<T>::frag_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = TA::frag(ta, (wm * 2 + i) * 32, s, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = TB::frag(tb, (wn * 2 + j) * 32, s, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<T>::mma(a[i], b[j], acc[i][j]);
+        }
+        if (st + 1 < nst) {
+            char* na = lds + (cur ^ 1) * STAGE;
+            sa.store(na, tid);
+            sb.store(na + TA::BYTES, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* out = (float*)p.out0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + (wm * 2 + i) * 32 + acc_row(r, lane);
+                const int k = k0 + (wn * 2 + j) * 32 + (lane & 31);
+                atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------- launchers
+template <typename T, int EPI> static int launch_tile(const GemmP& p, hipStream_t st) {
+    typedef NtLoop<T, 128, 128, 128, 2, 2> Loop;
+    if (p.N % 128 || p.K % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
+    const int nwg = (p.N / 128) * ((p.M + 127) / 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Loop::LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_tile_kernel<T, EPI>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), Loop::LDS_BYTES, st, p);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_t st) {
+    typedef NtLoop<T, ROW_BM, ROW_BN, ROW_BKB, 1, 4> Loop;
+    if (p.N != ROW_BN || p.K % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
+    constexpr int need = ROW_BM * ROW_RS * 4 + ROW_BM * 4;
+    constexpr int bytes = Loop::LDS_BYTES > need ? Loop::LDS_BYTES : need;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_row_kernel<T, REPI>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_row_kernel<T, REPI>), dim3((p.M + ROW_BM - 1) / ROW_BM), dim3(256), bytes, st, p);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
+    if (p.N % 128 || p.K % 128 || p.M <= 0) return MFVIT_EINVAL;
+    constexpr int KR = 64 / (int)sizeof(T);
+    const int tiles = (p.N / 128) * (p.K / 128);
+    if (p.splits <= 0) {
+        int s = (1024 + tiles - 1) / tiles;              // aim at ~4 blocks per CU
+        const int maxs = (p.M + 4 * KR - 1) / (4 * KR);  // at least 4 stages per split
+        p.splits = s < 1 ? 1 : (s > maxs ? maxs : s);
+        if (p.splits < 1) p.splits = 1;
+    }
+    constexpr int bytes = 2 * (STile<T, 128, KR>::BYTES * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(tiles, p.splits, p.nb > 1 ? p.nb : 1), dim3(256), bytes, st, p);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
+int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
+#define MFVIT_TILE_CASE(E)                                              \
+    case E:                                                             \
+        return dtype == MFVIT_BF16 ? launch_tile<bf16, E>(p, st) : launch_tile<float, E>(p, st);
+    switch (epi) {
+        MFVIT_TILE_CASE(EPI_BIAS)
+        MFVIT_TILE_CASE(EPI_BIAS_GELU)
+        MFVIT_TILE_CASE(EPI_GELU_BWD)
+        MFVIT_TILE_CASE(EPI_NONE)
+    }
+#undef MFVIT_TILE_CASE
+    return MFVIT_EINVAL;
+}
+int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
+    if (repi == REPI_RES_LN) return dtype == MFVIT_BF16 ? launch_row<bf16, REPI_RES_LN>(p, st) : launch_row<float, REPI_RES_LN>(p, st);
+    if (repi == REPI_LNBWD_RES) return dtype == MFVIT_BF16 ? launch_row<bf16, REPI_LNBWD_RES>(p, st) : launch_row<float, REPI_LNBWD_RES>(p, st);
+    return MFVIT_EINVAL;
+}
+int gemm_tn(int dtype, const GemmP& p, hipStream_t st) {
+    return dtype == MFVIT_BF16 ? launch_tn<bf16>(p, st) : launch_tn<float>(p, st);
+}
+
+}  // namespace mfvit

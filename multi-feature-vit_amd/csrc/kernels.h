@@ -1,0 +1,35 @@
+// Internal launcher declarations (host side) shared by the composite encoder and the C ABI.
+#pragma once
+#include "gemm.cuh"
+
+namespace mfvit {
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GELU_BWD = 2, EPI_NONE = 3 };
+enum { REPI_RES_LN = 0, REPI_LNBWD_RES = 1 };
+
+int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st);
+int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st);
+int gemm_tn(int dtype, const GemmP& p, hipStream_t st);
+
+int attn_fwd_exact(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HD, hipStream_t st);
+int attn_bwd_exact(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
+                   int H, int HD, hipStream_t st);
+
+int im2col16(int dtype, const float* img, void* P, int B, int H, int W, hipStream_t st);
+int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long ld1, int mod1, float* xout, long ldx, void* y, long ldy,
+            int y_f32, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int rows, int row_stride, int row_off,
+            int in0_bcast, hipStream_t st);
+int ln_bwd_rows(int dtype, int N, const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
+                const float* gamma, const float* dres, long ldres, float* dx, long lddx, void* dxT, long lddxT, float* dgamma, float* dbeta,
+                float* dcol, int rows, int row_stride, int row_off, hipStream_t st);
+int cast_transpose(int dtype, const float* src, void* dst, void* dstT, int R, int C, hipStream_t st);
+int linear_small_fwd(const float* x, long ldx, const float* W, const float* b, float* y, long ldy, int M, int N, int K, int accumulate,
+                     hipStream_t st);
+int linear_small_bwd(const float* dy, long lddy, const float* x, long ldx, const float* W, float* dx, long lddx, int dx_accumulate, float* dW,
+                     float* db, int M, int N, int K, hipStream_t st);
+int ce_small(const float* logits, const long* target, float* loss_mean, float* dlogits, long* preds, int B, int C, hipStream_t st);
+int add_rows(float* dst, long ldd, const float* src, long lds_, int rows, int N, hipStream_t st);
+int axpy(float* y, const float* x, float a, long n, hipStream_t st);
+int colsum_rows(const float* x, long ld, float* out, int rows, int row_stride, int row_off, int N, hipStream_t st);
+
+}  // namespace mfvit

@@ -1,0 +1,532 @@
+// Composite ViT-S/16 encoder forward / backward: host-side launch sequences over the gfx950 kernels, plus the
+// C ABI entry points of include/mfvit.h for the encoder and the single ops.  No allocation, no synchronisation:
+// every launch goes to the caller's stream, all memory (parameters, shadows, workspace) is caller-owned.
+#include "../../include/mfvit.h"
+#include "kernels.h"
+
+#include <string.h>
+
+using namespace mfvit;
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Dims {
+    int dtype, B, T, np, D, depth, H, HD, F, M, Mp, es;
+    bool save;
+};
+
+bool get_dims(const mfvit_vit_cfg* c, Dims& d) {
+    if (!c) return false;
+    if (c->dtype != MFVIT_F32 && c->dtype != MFVIT_BF16) return false;
+    if (c->batch <= 0 || c->img_h <= 0 || c->img_w <= 0 || c->img_h % 16 || c->img_w % 16) return false;
+    if (c->dim != 384 || c->depth <= 0 || c->heads <= 0 || c->dim % c->heads) return false;
+    if (c->mlp_dim % 128 || c->mlp_dim <= 0) return false;
+    d.dtype = c->dtype;
+    d.B = c->batch;
+    d.np = (c->img_h / 16) * (c->img_w / 16);
+    d.T = d.np + 1;
+    d.D = c->dim;
+    d.depth = c->depth;
+    d.H = c->heads;
+    d.HD = c->dim / c->heads;
+    d.F = c->mlp_dim;
+    d.M = d.B * d.T;
+    d.Mp = d.B * d.np;
+    d.es = c->dtype == MFVIT_BF16 ? 2 : 4;
+    d.save = c->save_for_backward != 0;
+    if (d.HD != 32 && d.HD != 64) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------ parameter arena layout (floats)
+struct ParamLayout {
+    long cls, pos, pe_w, pe_b, blk0, blk_stride, norm_w, norm_b, total;
+    // offsets inside a block
+    long ln1_w, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b;
+};
+ParamLayout param_layout(const Dims& d) {
+    ParamLayout L;
+    const long D = d.D, F = d.F;
+    long o = 0;
+    L.cls = o; o += D;
+    L.pos = o; o += (long)d.T * D;
+    L.pe_w = o; o += D * 768;
+    L.pe_b = o; o += D;
+    L.blk0 = o;
+    long b = 0;
+    L.ln1_w = b; b += D;
+    L.ln1_b = b; b += D;
+    L.qkv_w = b; b += 3 * D * D;
+    L.qkv_b = b; b += 3 * D;
+    L.proj_w = b; b += D * D;
+    L.proj_b = b; b += D;
+    L.ln2_w = b; b += D;
+    L.ln2_b = b; b += D;
+    L.fc1_w = b; b += F * D;
+    L.fc1_b = b; b += F;
+    L.fc2_w = b; b += D * F;
+    L.fc2_b = b; b += D;
+    L.blk_stride = b;
+    o += b * d.depth;
+    L.norm_w = o; o += D;
+    L.norm_b = o; o += D;
+    L.total = o;
+    return L;
+}
+
+// ------------------------------------------------------------------ weight shadow layout (bytes)
+struct ShadowLayout {
+    size_t pe_w;                       // [D][768] dtype (bf16 only; f32 reads the arena)
+    size_t blk0, blk_stride;           // per block:
+    size_t qkv_w, qkv_t, proj_w, proj_t, fc1_w, fc1_t, fc2_w, fc2_t;
+    size_t total;
+};
+ShadowLayout shadow_layout(const Dims& d) {
+    ShadowLayout S;
+    const size_t D = d.D, F = d.F, es = d.es;
+    const bool hw = d.dtype == MFVIT_BF16;  // keep straight copies only when a cast is needed
+    size_t o = 0;
+    S.pe_w = o; o += hw ? align256(D * 768 * es) : 0;
+    S.blk0 = o;
+    size_t b = 0;
+    S.qkv_w = b; b += hw ? align256(3 * D * D * es) : 0;
+    S.qkv_t = b; b += align256(3 * D * D * es);
+    S.proj_w = b; b += hw ? align256(D * D * es) : 0;
+    S.proj_t = b; b += align256(D * D * es);
+    S.fc1_w = b; b += hw ? align256(F * D * es) : 0;
+    S.fc1_t = b; b += align256(F * D * es);
+    S.fc2_w = b; b += hw ? align256(D * F * es) : 0;
+    S.fc2_t = b; b += align256(D * F * es);
+    S.blk_stride = b;
+    o += b * d.depth;
+    S.total = o;
+    return S;
+}
+
+// ------------------------------------------------------------------ workspace layout (bytes)
+struct WsLayout {
+    size_t patches;
+    size_t x0, x_stride;        // f32 [M][D], depth+1 (save) or 1 copies
+    size_t st0, st_stride;      // LN1 / final-norm stats: mean [M] then rstd [M], depth+1 or 1 copies
+    size_t blk0, blk_stride;    // per block (depth or 1 copies):
+    size_t y1, qkv, attn, lse, xmid, st2, y2, hpre, hact;
+    // backward scratch
+    size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch;
+    size_t total;
+};
+WsLayout ws_layout(const Dims& d) {
+    WsLayout W;
+    const size_t M = d.M, D = d.D, F = d.F, es = d.es;
+    const size_t nl = d.save ? d.depth : 1;
+    size_t o = 0;
+    W.patches = o; o += align256((size_t)d.Mp * 768 * es);
+    W.x0 = o; W.x_stride = align256(M * D * 4); o += W.x_stride * (d.save ? d.depth + 1 : 1);
+    W.st0 = o; W.st_stride = align256(2 * M * 4); o += W.st_stride * (d.save ? d.depth + 1 : 1);
+    W.blk0 = o;
+    size_t b = 0;
+    W.y1 = b; b += align256(M * D * es);
+    W.qkv = b; b += align256(M * 3 * D * es);
+    W.attn = b; b += align256(M * D * es);
+    W.lse = b; b += align256((size_t)d.B * d.H * d.T * 4);
+    W.xmid = b; b += align256(M * D * 4);
+    W.st2 = b; b += align256(2 * M * 4);
+    W.y2 = b; b += align256(M * D * es);
+    W.hpre = b; b += align256(M * F * es);
+    W.hact = b; b += align256(M * F * es);
+    W.blk_stride = b;
+    o += b * nl;
+    if (d.save) {
+        W.gx = o; o += align256(M * D * 4);
+        W.gmid = o; o += align256(M * D * 4);
+        W.gxT = o; o += align256(M * D * es);
+        W.gmidT = o; o += align256(M * D * es);
+        W.dhpre = o; o += align256(M * F * es);
+        W.dattn = o; o += align256(M * D * es);
+        W.dqkv = o; o += align256(M * 3 * D * es);
+        W.colscratch = o; o += align256(2 * D * 4);
+    } else {
+        W.gx = W.gmid = W.gxT = W.gmidT = W.dhpre = W.dattn = W.dqkv = W.colscratch = o;
+    }
+    W.total = o;
+    return W;
+}
+
+GemmP zero_gemm() {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    return p;
+}
+
+#define MFVIT_TRY(expr)            \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != MFVIT_OK) return rc__; \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int mfvit_abi_version(void) { return 1; }
+const char* mfvit_build_info(void) { return "libmfvit_hip gfx950 (MFMA bf16 32x32x16 / f32 32x32x2), wave64"; }
+
+size_t mfvit_vit_param_count(const mfvit_vit_cfg* cfg) {
+    Dims d;
+    if (!get_dims(cfg, d)) return 0;
+    return (size_t)param_layout(d).total;
+}
+int mfvit_vit_param_layout(const mfvit_vit_cfg* cfg, int64_t out[9]) {
+    Dims d;
+    if (!get_dims(cfg, d) || !out) return MFVIT_EINVAL;
+    const ParamLayout L = param_layout(d);
+    out[0] = L.cls; out[1] = L.pos; out[2] = L.pe_w; out[3] = L.pe_b; out[4] = L.blk0; out[5] = L.blk_stride;
+    out[6] = L.norm_w; out[7] = L.norm_b; out[8] = L.total;
+    return MFVIT_OK;
+}
+size_t mfvit_vit_shadow_bytes(const mfvit_vit_cfg* cfg) {
+    Dims d;
+    if (!get_dims(cfg, d)) return 0;
+    return shadow_layout(d).total;
+}
+size_t mfvit_vit_workspace_bytes(const mfvit_vit_cfg* cfg) {
+    Dims d;
+    if (!get_dims(cfg, d)) return 0;
+    return ws_layout(d).total;
+}
+
+int mfvit_vit_prepare_shadow(const mfvit_vit_cfg* cfg, const float* params, void* shadow, mfvit_stream_t stream) {
+    Dims d;
+    if (!get_dims(cfg, d) || !params || !shadow) return MFVIT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const ParamLayout L = param_layout(d);
+    const ShadowLayout S = shadow_layout(d);
+    char* sh = (char*)shadow;
+    const bool hw = d.dtype == MFVIT_BF16;
+    if (hw) MFVIT_TRY(cast_transpose(d.dtype, params + L.pe_w, sh + S.pe_w, nullptr, d.D, 768, st));
+    for (int l = 0; l < d.depth; ++l) {
+        const float* pb = params + L.blk0 + (long)l * L.blk_stride;
+        char* sb = sh + S.blk0 + (size_t)l * S.blk_stride;
+        MFVIT_TRY(cast_transpose(d.dtype, pb + L.qkv_w, hw ? sb + S.qkv_w : nullptr, sb + S.qkv_t, 3 * d.D, d.D, st));
+        MFVIT_TRY(cast_transpose(d.dtype, pb + L.proj_w, hw ? sb + S.proj_w : nullptr, sb + S.proj_t, d.D, d.D, st));
+        MFVIT_TRY(cast_transpose(d.dtype, pb + L.fc1_w, hw ? sb + S.fc1_w : nullptr, sb + S.fc1_t, d.F, d.D, st));
+        MFVIT_TRY(cast_transpose(d.dtype, pb + L.fc2_w, hw ? sb + S.fc2_w : nullptr, sb + S.fc2_t, d.D, d.F, st));
+    }
+    return MFVIT_OK;
+}
+
+int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, const float* img, void* workspace,
+                      float* features, mfvit_stream_t stream) {
+    Dims d;
+    if (!get_dims(cfg, d) || !params || !shadow || !img || !workspace || !features) return MFVIT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const ParamLayout L = param_layout(d);
+    const ShadowLayout S = shadow_layout(d);
+    const WsLayout W = ws_layout(d);
+    char* ws = (char*)workspace;
+    const char* sh = (const char*)shadow;
+    const bool hw = d.dtype == MFVIT_BF16;
+    const long D = d.D, F = d.F;
+    const float eps = cfg->ln_eps;
+    auto xbuf = [&](int l) { return (float*)(ws + W.x0 + (d.save ? (size_t)l : 0) * W.x_stride); };
+    auto stat = [&](int l) { return (float*)(ws + W.st0 + (d.save ? (size_t)l : 0) * W.st_stride); };
+    auto blk = [&](int l) { return ws + W.blk0 + (d.save ? (size_t)l : 0) * W.blk_stride; };
+    auto pblk = [&](int l) { return params + L.blk0 + (long)l * L.blk_stride; };
+    auto sblk = [&](int l) { return sh + S.blk0 + (size_t)l * S.blk_stride; };
+
+    // patch embedding: im2col -> row-complete GEMM (+bias +pos_embed) -> x_0, LN1_0 -> y1_0
+    MFVIT_TRY(im2col16(d.dtype, img, ws + W.patches, d.B, cfg->img_h, cfg->img_w, st));
+    {
+        GemmP p = zero_gemm();
+        p.A = ws + W.patches; p.lda = 768;
+        p.W = hw ? (const void*)(sh + S.pe_w) : (const void*)(params + L.pe_w); p.ldw = 768;
+        p.M = d.Mp; p.N = d.D; p.K = 768;
+        p.bias = params + L.pe_b;
+        p.res = params + L.pos; p.ldres = D; p.res_mod = d.np; p.res_off = 1;
+        p.orow_in = d.np; p.orow_out = d.T; p.orow_off = 1;
+        p.out0 = xbuf(0); p.ldo0 = D;
+        p.out1 = blk(0) + W.y1; p.ldo1 = D;
+        p.gamma = pblk(0) + L.ln1_w; p.beta = pblk(0) + L.ln1_b; p.eps = eps;
+        p.mean = stat(0); p.rstd = stat(0) + d.M;
+        MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
+    }
+    // cls rows: x_0[b,0] = cls_token + pos_embed[0]; LN1_0
+    MFVIT_TRY(ln_rows(d.dtype, d.D, params + L.cls, 0, params + L.pos, D, 1, xbuf(0), D, blk(0) + W.y1, D, 0, pblk(0) + L.ln1_w,
+                      pblk(0) + L.ln1_b, eps, stat(0), stat(0) + d.M, d.B, d.T, 0, 1, st));
+
+    for (int l = 0; l < d.depth; ++l) {
+        char* b = blk(l);
+        const float* pb = pblk(l);
+        const char* sb = sblk(l);
+        {   // qkv = y1 Wqkv^T + b
+            GemmP p = zero_gemm();
+            p.A = b + W.y1; p.lda = D;
+            p.W = hw ? (const void*)(sb + S.qkv_w) : (const void*)(pb + L.qkv_w); p.ldw = D;
+            p.M = d.M; p.N = 3 * d.D; p.K = d.D;
+            p.bias = pb + L.qkv_b;
+            p.out0 = b + W.qkv; p.ldo0 = 3 * D;
+            MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS, p, st));
+        }
+        MFVIT_TRY(attn_fwd_exact(d.dtype, b + W.qkv, b + W.attn, (float*)(b + W.lse), d.B, d.T, d.H, d.HD, st));
+        {   // xmid = x + attn Wproj^T + b ; y2 = LN2(xmid)
+            GemmP p = zero_gemm();
+            p.A = b + W.attn; p.lda = D;
+            p.W = hw ? (const void*)(sb + S.proj_w) : (const void*)(pb + L.proj_w); p.ldw = D;
+            p.M = d.M; p.N = d.D; p.K = d.D;
+            p.bias = pb + L.proj_b;
+            p.res = xbuf(l); p.ldres = D;
+            p.out0 = b + W.xmid; p.ldo0 = D;
+            p.out1 = b + W.y2; p.ldo1 = D;
+            p.gamma = pb + L.ln2_w; p.beta = pb + L.ln2_b; p.eps = eps;
+            p.mean = (float*)(b + W.st2); p.rstd = (float*)(b + W.st2) + d.M;
+            MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
+        }
+        {   // hpre = y2 W1^T + b1 ; hact = gelu(hpre)
+            GemmP p = zero_gemm();
+            p.A = b + W.y2; p.lda = D;
+            p.W = hw ? (const void*)(sb + S.fc1_w) : (const void*)(pb + L.fc1_w); p.ldw = D;
+            p.M = d.M; p.N = d.F; p.K = d.D;
+            p.bias = pb + L.fc1_b;
+            p.out0 = b + W.hpre; p.ldo0 = F;
+            p.out1 = b + W.hact; p.ldo1 = F;
+            MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS_GELU, p, st));
+        }
+        {   // x_{l+1} = xmid + hact W2^T + b2 ; y = LN(next norm1 | final norm)
+            const bool last = l + 1 == d.depth;
+            GemmP p = zero_gemm();
+            p.A = b + W.hact; p.lda = F;
+            p.W = hw ? (const void*)(sb + S.fc2_w) : (const void*)(pb + L.fc2_w); p.ldw = F;
+            p.M = d.M; p.N = d.D; p.K = d.F;
+            p.bias = pb + L.fc2_b;
+            p.res = (const float*)(b + W.xmid); p.ldres = D;
+            p.out0 = xbuf(l + 1); p.ldo0 = D;
+            if (last) {
+                p.out1 = features; p.ldo1 = D; p.y_f32 = 1;
+                p.gamma = params + L.norm_w; p.beta = params + L.norm_b;
+            } else {
+                p.out1 = blk(l + 1) + W.y1; p.ldo1 = D;
+                p.gamma = pblk(l + 1) + L.ln1_w; p.beta = pblk(l + 1) + L.ln1_b;
+            }
+            p.eps = eps;
+            p.mean = stat(l + 1); p.rstd = stat(l + 1) + d.M;
+            MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
+        }
+    }
+    return MFVIT_OK;
+}
+
+int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, void* workspace, const float* dfeatures,
+                       float* dparams, int stage_hi, int stage_lo, mfvit_stream_t stream) {
+    Dims d;
+    if (!get_dims(cfg, d) || !params || !shadow || !workspace || !dparams) return MFVIT_EINVAL;
+    if (!d.save) return MFVIT_EINVAL;
+    if (stage_hi > d.depth || stage_lo < -1 || stage_lo > stage_hi) return MFVIT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const ParamLayout L = param_layout(d);
+    const ShadowLayout S = shadow_layout(d);
+    const WsLayout W = ws_layout(d);
+    char* ws = (char*)workspace;
+    const char* sh = (const char*)shadow;
+    const long D = d.D, F = d.F;
+    auto xbuf = [&](int l) { return (float*)(ws + W.x0 + (size_t)l * W.x_stride); };
+    auto stat = [&](int l) { return (float*)(ws + W.st0 + (size_t)l * W.st_stride); };
+    auto blk = [&](int l) { return ws + W.blk0 + (size_t)l * W.blk_stride; };
+    auto pblk = [&](int l) { return params + L.blk0 + (long)l * L.blk_stride; };
+    auto gblk = [&](int l) { return dparams + L.blk0 + (long)l * L.blk_stride; };
+    auto sblk = [&](int l) { return sh + S.blk0 + (size_t)l * S.blk_stride; };
+    float* gx = (float*)(ws + W.gx);
+    float* gmid = (float*)(ws + W.gmid);
+    void* gxT = ws + W.gxT;
+    void* gmidT = ws + W.gmidT;
+    float* colscr = (float*)(ws + W.colscratch);
+
+    for (int s = stage_hi; s >= stage_lo; --s) {
+        if (s == d.depth) {
+            // final LayerNorm backward: dfeatures -> gx (grad of x_depth); dcol = d fc2_b of the last block
+            if (!dfeatures) return MFVIT_EINVAL;
+            MFVIT_TRY(ln_bwd_rows(d.dtype, d.D, dfeatures, D, xbuf(d.depth), D, stat(d.depth), stat(d.depth) + d.M, params + L.norm_w,
+                                  nullptr, 0, gx, D, gxT, D, dparams + L.norm_w, dparams + L.norm_b, gblk(d.depth - 1) + L.fc2_b, d.M, 1,
+                                  0, st));
+        } else if (s >= 0) {
+            const int l = s;
+            char* b = blk(l);
+            const float* pb = pblk(l);
+            float* gb = gblk(l);
+            const char* sb = sblk(l);
+            {   // dW2 += gx^T hact
+                GemmP p = zero_gemm();
+                p.A = gxT; p.lda = D; p.W = b + W.hact; p.ldw = F;
+                p.M = d.M; p.N = d.D; p.K = d.F;
+                p.out0 = gb + L.fc2_w; p.ldo0 = F;
+                MFVIT_TRY(gemm_tn(d.dtype, p, st));
+            }
+            {   // dhpre = (gx W2) * gelu'(hpre) ; d fc1_b += colsum
+                GemmP p = zero_gemm();
+                p.A = gxT; p.lda = D; p.W = sb + S.fc2_t; p.ldw = D;
+                p.M = d.M; p.N = d.F; p.K = d.D;
+                p.aux = b + W.hpre; p.ldaux = F;
+                p.out0 = ws + W.dhpre; p.ldo0 = F;
+                p.cs0 = gb + L.fc1_b;
+                MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_GELU_BWD, p, st));
+            }
+            {   // dW1 += dhpre^T y2
+                GemmP p = zero_gemm();
+                p.A = ws + W.dhpre; p.lda = F; p.W = b + W.y2; p.ldw = D;
+                p.M = d.M; p.N = d.F; p.K = d.D;
+                p.out0 = gb + L.fc1_w; p.ldo0 = D;
+                MFVIT_TRY(gemm_tn(d.dtype, p, st));
+            }
+            {   // gmid = LN2bwd(dhpre W1) + gx ; d ln2_w, d ln2_b, d proj_b
+                GemmP p = zero_gemm();
+                p.A = ws + W.dhpre; p.lda = F; p.W = sb + S.fc1_t; p.ldw = F;
+                p.M = d.M; p.N = d.D; p.K = d.F;
+                p.aux = b + W.xmid; p.ldaux = D;
+                p.mean = (float*)(b + W.st2); p.rstd = (float*)(b + W.st2) + d.M;
+                p.gamma = pb + L.ln2_w;
+                p.res = gx; p.ldres = D;
+                p.out0 = gmid; p.ldo0 = D; p.out1 = gmidT; p.ldo1 = D;
+                p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = gb + L.proj_b;
+                MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
+            }
+            {   // dWproj += gmid^T attn
+                GemmP p = zero_gemm();
+                p.A = gmidT; p.lda = D; p.W = b + W.attn; p.ldw = D;
+                p.M = d.M; p.N = d.D; p.K = d.D;
+                p.out0 = gb + L.proj_w; p.ldo0 = D;
+                MFVIT_TRY(gemm_tn(d.dtype, p, st));
+            }
+            {   // dattn = gmid Wproj
+                GemmP p = zero_gemm();
+                p.A = gmidT; p.lda = D; p.W = sb + S.proj_t; p.ldw = D;
+                p.M = d.M; p.N = d.D; p.K = d.D;
+                p.out0 = ws + W.dattn; p.ldo0 = D;
+                MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, p, st));
+            }
+            MFVIT_TRY(attn_bwd_exact(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), ws + W.dqkv, gb + L.qkv_b,
+                                     d.B, d.T, d.H, d.HD, st));
+            {   // dWqkv += dqkv^T y1
+                GemmP p = zero_gemm();
+                p.A = ws + W.dqkv; p.lda = 3 * D; p.W = b + W.y1; p.ldw = D;
+                p.M = d.M; p.N = 3 * d.D; p.K = d.D;
+                p.out0 = gb + L.qkv_w; p.ldo0 = D;
+                MFVIT_TRY(gemm_tn(d.dtype, p, st));
+            }
+            {   // gx = LN1bwd(dqkv Wqkv) + gmid ; d ln1_w, d ln1_b, d fc2_b of block l-1 (or scratch for the embed stage)
+                if (l == 0 && hipMemsetAsync(colscr, 0, 2 * D * sizeof(float), st) != hipSuccess) return MFVIT_ELAUNCH;
+                GemmP p = zero_gemm();
+                p.A = ws + W.dqkv; p.lda = 3 * D; p.W = sb + S.qkv_t; p.ldw = 3 * D;
+                p.M = d.M; p.N = d.D; p.K = 3 * d.D;
+                p.aux = xbuf(l); p.ldaux = D;
+                p.mean = stat(l); p.rstd = stat(l) + d.M;
+                p.gamma = pb + L.ln1_w;
+                p.res = gmid; p.ldres = D;
+                p.out0 = gx; p.ldo0 = D; p.out1 = gxT; p.ldo1 = D;
+                p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = l > 0 ? gblk(l - 1) + L.fc2_b : colscr;
+                MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
+            }
+        } else {
+            // embed stage: gx = d x_0.  d cls_token = sum_b gx[b,0]; d pe_b = sum over patch rows; d pe_w = gx_patch^T patches.
+            // pos_embed is a fixed table (requires_grad = False upstream): no gradient.
+            MFVIT_TRY(colsum_rows(gx, D, dparams + L.cls, d.B, d.T, 0, d.D, st));
+            if (!cfg->stop_grad_conv1) {
+                // colscr[0:D] = sum of gx over ALL rows (cs2 of the LN1_0 backward); colscr[D:2D] = sum over the cls rows
+                MFVIT_TRY(colsum_rows(gx, D, colscr + D, d.B, d.T, 0, d.D, st));
+                MFVIT_TRY(axpy(dparams + L.pe_b, colscr, 1.0f, d.D, st));
+                MFVIT_TRY(axpy(dparams + L.pe_b, colscr + D, -1.0f, d.D, st));
+                GemmP p = zero_gemm();   // d pe_w += gx[patch rows]^T patches
+                p.A = gxT; p.lda = D; p.W = ws + W.patches; p.ldw = 768;
+                p.M = d.Mp; p.N = d.D; p.K = 768;
+                p.orow_in = d.np; p.orow_out = d.T; p.orow_off = 1;
+                p.out0 = dparams + L.pe_w; p.ldo0 = 768;
+                MFVIT_TRY(gemm_tn(d.dtype, p, st));
+            }
+        }
+    }
+    return MFVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ single ops
+int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
+                     int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream) {
+    if (!x || !w || !y) return MFVIT_EINVAL;
+    if (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU && epilogue != EPI_NONE) return MFVIT_EINVAL;
+    if (epilogue == EPI_BIAS_GELU && !y2) return MFVIT_EINVAL;
+    GemmP p = zero_gemm();
+    p.A = x; p.lda = ldx; p.W = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
+    p.bias = bias; p.out0 = y; p.ldo0 = ldy; p.out1 = y2; p.ldo1 = ldy2;
+    return gemm_nt_tile(dtype, epilogue, p, (hipStream_t)stream);
+}
+int mfvit_linear_wgrad(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N, int K,
+                       mfvit_stream_t stream) {
+    if (!dy || !x || !dw) return MFVIT_EINVAL;
+    GemmP p = zero_gemm();
+    p.A = dy; p.lda = lddy; p.W = x; p.ldw = ldx; p.M = M; p.N = N; p.K = K;
+    p.out0 = dw; p.ldo0 = lddw;
+    return gemm_tn(dtype, p, (hipStream_t)stream);
+}
+int mfvit_linear_res_ln_fwd(int dtype, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res,
+                            int64_t ldres, float* x_out, void* y, int y_f32, const float* gamma, const float* beta, float eps,
+                            float* mean, float* rstd, int M, int K, mfvit_stream_t stream) {
+    if (!a || !w || !y || !gamma || !beta) return MFVIT_EINVAL;
+    GemmP p = zero_gemm();
+    p.A = a; p.lda = lda; p.W = w; p.ldw = ldw; p.M = M; p.N = 384; p.K = K;
+    p.bias = bias; p.res = res; p.ldres = ldres;
+    p.out0 = x_out; p.ldo0 = 384; p.out1 = y; p.ldo1 = 384; p.y_f32 = y_f32;
+    p.gamma = gamma; p.beta = beta; p.eps = eps; p.mean = mean; p.rstd = rstd;
+    return gemm_nt_row(dtype, REPI_RES_LN, p, (hipStream_t)stream);
+}
+int mfvit_linear_dgrad_ln_bwd(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, const float* mean,
+                              const float* rstd, const float* gamma, const float* dres, float* dx, void* dx_t, float* dgamma,
+                              float* dbeta, float* dcol, int M, int K, mfvit_stream_t stream) {
+    if (!dy || !wt || !x || !mean || !rstd || !gamma || !dx) return MFVIT_EINVAL;
+    GemmP p = zero_gemm();
+    p.A = dy; p.lda = lddy; p.W = wt; p.ldw = ldwt; p.M = M; p.N = 384; p.K = K;
+    p.aux = x; p.ldaux = 384; p.mean = (float*)mean; p.rstd = (float*)rstd; p.gamma = gamma;
+    p.res = dres; p.ldres = 384;
+    p.out0 = dx; p.ldo0 = 384; p.out1 = dx_t; p.ldo1 = 384;
+    p.cs0 = dgamma; p.cs1 = dbeta; p.cs2 = dcol;
+    return gemm_nt_row(dtype, REPI_LNBWD_RES, p, (hipStream_t)stream);
+}
+int mfvit_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int head_dim, mfvit_stream_t stream) {
+    if (!qkv || !out || !lse || B <= 0 || T <= 0 || H <= 0) return MFVIT_EINVAL;
+    return attn_fwd_exact(dtype, qkv, out, lse, B, T, H, head_dim, (hipStream_t)stream);
+}
+int mfvit_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias_qkv,
+                        int B, int T, int H, int head_dim, mfvit_stream_t stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || T <= 0 || H <= 0) return MFVIT_EINVAL;
+    return attn_bwd_exact(dtype, qkv, out, dout, lse, dqkv, dbias_qkv, B, T, H, head_dim, (hipStream_t)stream);
+}
+int mfvit_layernorm_fwd(int dtype, const float* x, void* y, int y_f32, const float* gamma, const float* beta, float eps, float* mean,
+                        float* rstd, int rows, int N, mfvit_stream_t stream) {
+    if (!x || !y || !gamma || !beta) return MFVIT_EINVAL;
+    return ln_rows(dtype, N, x, N, nullptr, 0, 0, nullptr, 0, y, N, y_f32, gamma, beta, eps, mean, rstd, rows, 1, 0, 0, (hipStream_t)stream);
+}
+int mfvit_layernorm_bwd(int dtype, const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* dres, float* dx, void* dx_t, float* dgamma, float* dbeta, float* dcol, int rows, int N,
+                        mfvit_stream_t stream) {
+    if (!dy || !x || !mean || !rstd || !gamma) return MFVIT_EINVAL;
+    return ln_bwd_rows(dtype, N, dy, N, x, N, mean, rstd, gamma, dres, N, dx, N, dx_t, N, dgamma, dbeta, dcol, rows, 1, 0,
+                       (hipStream_t)stream);
+}
+int mfvit_cast_transpose(int dtype, const float* src, void* dst, void* dst_t, int R, int C, mfvit_stream_t stream) {
+    if (!src || R <= 0 || C <= 0) return MFVIT_EINVAL;
+    return cast_transpose(dtype, src, dst, dst_t, R, C, (hipStream_t)stream);
+}
+int mfvit_head_fwd(const float* x, int64_t ldx, const float* w, const float* b, float* y, int64_t ldy, int M, int N, int K, int accumulate,
+                   mfvit_stream_t stream) {
+    if (!x || !w || !y) return MFVIT_EINVAL;
+    return linear_small_fwd(x, ldx, w, b, y, ldy, M, N, K, accumulate, (hipStream_t)stream);
+}
+int mfvit_head_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* w, float* dx, int64_t lddx, int dx_accumulate,
+                   float* dw, float* db, int M, int N, int K, mfvit_stream_t stream) {
+    if (!dy || !x || !w) return MFVIT_EINVAL;
+    return linear_small_bwd(dy, lddy, x, ldx, w, dx, lddx, dx_accumulate, dw, db, M, N, K, (hipStream_t)stream);
+}
+int mfvit_cross_entropy(const float* logits, const int64_t* target, float* loss_mean, float* dlogits, int64_t* preds, int B, int C,
+                        mfvit_stream_t stream) {
+    if (!logits || !target || !loss_mean) return MFVIT_EINVAL;
+    return ce_small(logits, (const long*)target, loss_mean, dlogits, (long*)preds, B, C, (hipStream_t)stream);
+}
+
+}  // extern "C"

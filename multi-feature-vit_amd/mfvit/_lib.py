@@ -1,0 +1,107 @@
+"""ctypes binding of libmfvit_hip.so (C ABI declared in include/mfvit.h).
+
+The product path has NO CPU / eager fallback: if the HIP library is missing, cannot be loaded, or an op is asked
+to run on a non-GPU tensor, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmfvit_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_BIAS_GELU, EPI_NONE = 0, 1, 3
+
+
+class VitCfg(Structure):
+    _fields_ = [("dtype", c_int), ("batch", c_int), ("img_h", c_int), ("img_w", c_int), ("dim", c_int), ("depth", c_int),
+                ("heads", c_int), ("mlp_dim", c_int), ("save_for_backward", c_int), ("stop_grad_conv1", c_int),
+                ("ln_eps", c_float)]
+
+
+P = c_void_p
+I = c_int
+L = c_int64
+F = c_float
+
+# name -> (restype, argtypes); must list every symbol of include/mfvit.h (tests/test_boundary_cpu.py checks it)
+SIGNATURES = {
+    "mfvit_abi_version": (I, []),
+    "mfvit_build_info": (c_char_p, []),
+    "mfvit_vit_param_count": (c_size_t, [POINTER(VitCfg)]),
+    "mfvit_vit_param_layout": (I, [POINTER(VitCfg), POINTER(c_int64)]),
+    "mfvit_vit_shadow_bytes": (c_size_t, [POINTER(VitCfg)]),
+    "mfvit_vit_prepare_shadow": (I, [POINTER(VitCfg), P, P, P]),
+    "mfvit_vit_workspace_bytes": (c_size_t, [POINTER(VitCfg)]),
+    "mfvit_vit_forward": (I, [POINTER(VitCfg), P, P, P, P, P, P]),
+    "mfvit_vit_backward": (I, [POINTER(VitCfg), P, P, P, P, P, I, I, P]),
+    "mfvit_linear_fwd": (I, [I, I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
+    "mfvit_linear_wgrad": (I, [I, P, L, P, L, P, L, I, I, I, P]),
+    "mfvit_linear_res_ln_fwd": (I, [I, P, L, P, L, P, P, L, P, P, I, P, P, F, P, P, I, I, P]),
+    "mfvit_linear_dgrad_ln_bwd": (I, [I, P, L, P, L, P, P, P, P, P, P, P, P, P, P, I, I, P]),
+    "mfvit_attention_fwd": (I, [I, P, P, P, I, I, I, I, P]),
+    "mfvit_attention_bwd": (I, [I, P, P, P, P, P, P, I, I, I, I, P]),
+    "mfvit_layernorm_fwd": (I, [I, P, P, I, P, P, F, P, P, I, I, P]),
+    "mfvit_layernorm_bwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
+    "mfvit_cast_transpose": (I, [I, P, P, P, I, I, P]),
+    "mfvit_head_fwd": (I, [P, L, P, P, P, L, I, I, I, I, P]),
+    "mfvit_head_bwd": (I, [P, L, P, L, P, P, L, I, P, P, I, I, I, P]),
+    "mfvit_cross_entropy": (I, [P, P, P, P, P, I, I, P]),
+}
+
+_lib = None
+
+
+class MfvitError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the HIP library; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MfvitError(
+            f"libmfvit_hip.so not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/eager fallback for the MF-ViT hot path.")
+    try:
+        h = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise MfvitError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = h
+    return h
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MfvitError(f"{what} failed with code {rc} (-22 = invalid argument, -5 = launch error)")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MfvitError("MF-ViT HIP ops need tensors on a ROCm GPU ('cuda' device); there is no CPU fallback")
+
+
+def dtype_code(precision):
+    if precision in ("bf16", "bfloat16"):
+        return BF16
+    if precision in ("fp32", "f32", "float32"):
+        return F32
+    raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")

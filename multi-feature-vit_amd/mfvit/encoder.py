@@ -1,0 +1,368 @@
+"""ViT-S/16 backbone module backed by the gfx950 encoder kernels (libmfvit_hip.so).
+
+Stands in for the module the reference imports as ``vits`` / ``vits_returnftrs`` (absent from its tree; SURVEY.md
+§0.2, Appendix A): same constructor kwargs (``num_classes``, ``stop_grad_conv1``), same timm parameter names and
+state-dict keys, ``.head`` a re-assignable ``nn.Linear``, ``forward(img) -> (B, num_classes)`` and
+``features3D(img) -> (B, 1 + HW/256, 384)``.
+
+MI355X-first layout: every backbone parameter is a view into ONE flat f32 arena (timm registration order, the
+layout of include/mfvit.h), so the encoder kernels, the fused optimizers, the EMA update and the gradient
+all-reduce all work on contiguous slices.  Gradients come back from the C ABI as one flat arena as well.
+There is no CPU / eager fallback: forward on a non-GPU tensor raises.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from ._lib import VitCfg, check, lib, ptr, stream
+
+
+def default_precision():
+    return os.environ.get("MFVIT_PRECISION", "bf16")
+
+
+def build_2d_sincos_position_embedding(gh, gw, dim, temperature=10000.0):
+    """Fixed 2-D sin-cos table with a zero cls slot (moco-v3 ``vits.py``).  float64 -> float32."""
+    assert dim % 4 == 0, "embed dim must be divisible by 4 for the 2-D sin-cos position embedding"
+    gw_, gh_ = torch.meshgrid(torch.arange(gw, dtype=torch.float64), torch.arange(gh, dtype=torch.float64), indexing="ij")
+    pos_dim = dim // 4
+    omega = 1.0 / (temperature ** (torch.arange(pos_dim, dtype=torch.float64) / pos_dim))
+    out_w = gw_.flatten()[:, None] * omega[None]
+    out_h = gh_.flatten()[:, None] * omega[None]
+    pe = torch.cat([out_w.sin(), out_w.cos(), out_h.sin(), out_h.cos()], dim=1)[None]
+    return torch.cat([torch.zeros(1, 1, dim, dtype=torch.float64), pe], dim=1).float()
+
+
+class _WB(nn.Module):
+    """Parameter holder with timm-compatible child names (``weight`` / ``bias``)."""
+
+    def __init__(self, w_shape, b_shape=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*w_shape))
+        self.bias = nn.Parameter(torch.empty(*b_shape)) if b_shape is not None else None
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = _WB((3 * dim, dim), (3 * dim,))
+        self.proj = _WB((dim, dim), (dim,))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = _WB((hidden, dim), (hidden,))
+        self.fc2 = _WB((dim, hidden), (dim,))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.norm1 = _WB((dim,), (dim,))
+        self.attn = _Attn(dim)
+        self.norm2 = _WB((dim,), (dim,))
+        self.mlp = _Mlp(dim, hidden)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim, patch):
+        super().__init__()
+        self.proj = _WB((dim, 3, patch, patch), (dim,))
+
+
+class _EncoderFn(torch.autograd.Function):
+    """features3D as one autograd node: forward = mfvit_vit_forward, backward = mfvit_vit_backward (stage by stage)."""
+
+    @staticmethod
+    def forward(ctx, model, img, need_grad, *params):
+        feats, ws = model._run_forward(img, need_grad)
+        ctx.model = model
+        ctx.ws = ws
+        ctx.cfg = model._cfg(img, need_grad)
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeats):
+        model = ctx.model
+        grads = model._run_backward(ctx.cfg, ctx.ws, dfeats)
+        model._release_ws(ctx.ws)
+        ctx.ws = None
+        return (None, None, None) + tuple(grads)
+
+
+class _HeadFn(torch.autograd.Function):
+    """Small classifier head on the cls rows of a token tensor: y = feats[:, 0] @ W.T + b (f32)."""
+
+    @staticmethod
+    def forward(ctx, feats, w, b):
+        B, T, D = feats.shape
+        feats = feats if feats.is_contiguous() else feats.contiguous()
+        y = ops.head_fwd(feats, w, b, ldx=T * D)
+        ctx.save_for_backward(feats, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        feats, w = ctx.saved_tensors
+        B, T, D = feats.shape
+        dy = dy.contiguous()
+        dfe = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dfe = torch.zeros_like(feats)
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(w.shape[0], device=w.device, dtype=torch.float32)
+        ops.head_bwd(dy, feats, w, ldx=T * D, dx=dfe, lddx=T * D, dw=dw, db=db)
+        return dfe, dw, db
+
+
+class VisionTransformerMoCo(nn.Module):
+    def __init__(self, img_size=224, patch_size=16, embed_dim=384, depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True,
+                 num_classes=1000, stop_grad_conv1=False, precision=None, **unused_timm_kwargs):
+        super().__init__()
+        if patch_size != 16:
+            raise NotImplementedError("only patch_size=16 (ViT-S/16) is built")
+        if embed_dim != 384:
+            raise NotImplementedError("the gfx950 row-complete kernels are built for embed_dim=384 (vit_small); "
+                                      "vit_base is not on the hot path (SURVEY.md §8)")
+        if not qkv_bias:
+            raise NotImplementedError("qkv_bias=False is not used by the reference (moco-v3 vits: qkv_bias=True)")
+        self.img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+        self.embed_dim = self.num_features = embed_dim
+        self.depth = depth
+        self.num_heads = num_heads
+        self.mlp_dim = int(embed_dim * mlp_ratio)
+        self.num_classes = num_classes
+        self.stop_grad_conv1 = bool(stop_grad_conv1)
+        self.precision = precision or default_precision()
+        _lib.dtype_code(self.precision)  # validate
+        gh, gw = self.img_size[0] // 16, self.img_size[1] // 16
+        self.num_tokens = gh * gw + 1
+
+        # ---- parameters, timm registration order (== arena order)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(build_2d_sincos_position_embedding(gh, gw, embed_dim), requires_grad=False)
+        self.patch_embed = _PatchEmbed(embed_dim, 16)
+        self.blocks = nn.ModuleList([_Block(embed_dim, self.mlp_dim) for _ in range(depth)])
+        self.norm = _WB((embed_dim,), (embed_dim,))
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        self._init_weights()
+        if self.stop_grad_conv1:
+            self.patch_embed.proj.weight.requires_grad = False
+            self.patch_embed.proj.bias.requires_grad = False
+
+        self._arena = None
+        self._shadow = None
+        self._shadow_key = None
+        self._ws_pool = {}
+        self._feat_cache = None
+        self._flatten()
+
+    # ------------------------------------------------------------------ init (moco-v3 VisionTransformerMoCo)
+    def _init_weights(self):
+        D = self.embed_dim
+        with torch.no_grad():
+            nn.init.normal_(self.cls_token, std=1e-6)
+            val = math.sqrt(6.0 / float(3 * 16 * 16 + D))
+            nn.init.uniform_(self.patch_embed.proj.weight, -val, val)
+            nn.init.zeros_(self.patch_embed.proj.bias)
+            for blk in self.blocks:
+                nn.init.ones_(blk.norm1.weight); nn.init.zeros_(blk.norm1.bias)
+                nn.init.ones_(blk.norm2.weight); nn.init.zeros_(blk.norm2.bias)
+                v = math.sqrt(6.0 / float(blk.attn.qkv.weight.shape[0] // 3 + blk.attn.qkv.weight.shape[1]))
+                nn.init.uniform_(blk.attn.qkv.weight, -v, v)      # q, k, v treated as separate matrices
+                nn.init.zeros_(blk.attn.qkv.bias)
+                for m in (blk.attn.proj, blk.mlp.fc1, blk.mlp.fc2):
+                    nn.init.xavier_uniform_(m.weight)
+                    nn.init.zeros_(m.bias)
+            nn.init.ones_(self.norm.weight); nn.init.zeros_(self.norm.bias)
+            if isinstance(self.head, nn.Linear):
+                nn.init.xavier_uniform_(self.head.weight)
+                nn.init.zeros_(self.head.bias)
+
+    # ------------------------------------------------------------------ flat arena
+    def arena_named_parameters(self):
+        """(name, Parameter) in arena order (include/mfvit.h); the classifier head is not part of the arena."""
+        out = [("cls_token", self.cls_token), ("pos_embed", self.pos_embed),
+               ("patch_embed.proj.weight", self.patch_embed.proj.weight), ("patch_embed.proj.bias", self.patch_embed.proj.bias)]
+        for i, b in enumerate(self.blocks):
+            p = f"blocks.{i}."
+            out += [(p + "norm1.weight", b.norm1.weight), (p + "norm1.bias", b.norm1.bias),
+                    (p + "attn.qkv.weight", b.attn.qkv.weight), (p + "attn.qkv.bias", b.attn.qkv.bias),
+                    (p + "attn.proj.weight", b.attn.proj.weight), (p + "attn.proj.bias", b.attn.proj.bias),
+                    (p + "norm2.weight", b.norm2.weight), (p + "norm2.bias", b.norm2.bias),
+                    (p + "mlp.fc1.weight", b.mlp.fc1.weight), (p + "mlp.fc1.bias", b.mlp.fc1.bias),
+                    (p + "mlp.fc2.weight", b.mlp.fc2.weight), (p + "mlp.fc2.bias", b.mlp.fc2.bias)]
+        out += [("norm.weight", self.norm.weight), ("norm.bias", self.norm.bias)]
+        return out
+
+    def _flatten(self):
+        named = self.arena_named_parameters()
+        total = sum(p.numel() for _, p in named)
+        dev = named[0][1].device
+        arena = torch.empty(total, device=dev, dtype=torch.float32)
+        off = 0
+        self._offsets = {}
+        with torch.no_grad():
+            for name, p in named:
+                n = p.numel()
+                arena[off:off + n].copy_(p.data.reshape(-1).float())
+                p.data = arena[off:off + n].view(p.shape)
+                self._offsets[name] = (off, n)
+                off += n
+        self._arena = arena
+        self._arena_params = [p for _, p in named]
+        self._shadow = None
+        self._shadow_key = None
+        self._ws_pool = {}
+        self._feat_cache = None
+
+    def _arena_intact(self):
+        base = self._arena.data_ptr()
+        for (name, p) in self.arena_named_parameters():
+            off, n = self._offsets[name]
+            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                return False
+        return True
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flatten()  # parameters were moved / cast one by one: rebuild the arena on the new device
+        return out
+
+    def flat_parameters(self):
+        """The flat f32 arena holding every backbone parameter (head excluded)."""
+        if not self._arena_intact():
+            self._flatten()
+        return self._arena
+
+    def arena_slice(self, name):
+        return self._offsets[name]
+
+    def block_slice(self, i):
+        """(offset, length) of block i in the arena / gradient arena (one all-reduce bucket)."""
+        a = self._offsets[f"blocks.{i}.norm1.weight"][0]
+        o, n = self._offsets[f"blocks.{i}.mlp.fc2.bias"]
+        return a, o + n - a
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _cfg(self, img, save):
+        c = VitCfg()
+        c.dtype = _lib.dtype_code(self.precision)
+        c.batch, _, c.img_h, c.img_w = img.shape
+        c.dim, c.depth, c.heads, c.mlp_dim = self.embed_dim, self.depth, self.num_heads, self.mlp_dim
+        c.save_for_backward = int(bool(save))
+        c.stop_grad_conv1 = int(not self.patch_embed.proj.weight.requires_grad)
+        c.ln_eps = 1e-6
+        return c
+
+    def _param_version(self):
+        return sum(p._version for p in self._arena_params)
+
+    def _ensure_shadow(self, cfg):
+        key = (self._param_version(), cfg.dtype, str(self._arena.device))
+        if self._shadow is not None and key == self._shadow_key:
+            return
+        if not self._arena_intact():
+            self._flatten()
+            key = (self._param_version(), cfg.dtype, str(self._arena.device))
+        nbytes = lib().mfvit_vit_shadow_bytes(cfg)
+        if self._shadow is None or self._shadow.numel() != nbytes:
+            self._shadow = torch.empty(nbytes, device=self._arena.device, dtype=torch.uint8)
+        check(lib().mfvit_vit_prepare_shadow(cfg, ptr(self._arena), ptr(self._shadow), stream()), "mfvit_vit_prepare_shadow")
+        self._shadow_key = key
+        self._feat_cache = None
+
+    def _get_ws(self, cfg):
+        nbytes = lib().mfvit_vit_workspace_bytes(cfg)
+        if nbytes == 0:
+            raise _lib.MfvitError("invalid encoder configuration (image size must be a multiple of 16, dim 384)")
+        pool = self._ws_pool.setdefault(nbytes, [])
+        return pool.pop() if pool else torch.empty(nbytes, device=self._arena.device, dtype=torch.uint8)
+
+    def _release_ws(self, ws):
+        if ws is not None:
+            pool = self._ws_pool.setdefault(ws.numel(), [])
+            if len(pool) < 2:
+                pool.append(ws)
+
+    def _run_forward(self, img, save):
+        _lib.require_cuda(img)
+        if img.dtype != torch.float32:
+            img = img.float()
+        img = img.contiguous()
+        if img.shape[1] != 3 or (img.shape[2], img.shape[3]) != self.img_size:
+            raise _lib.MfvitError(f"expected (B,3,{self.img_size[0]},{self.img_size[1]}) images, got {tuple(img.shape)} "
+                                  "(pos_embed is size-bound)")
+        if self._arena.device != img.device:
+            raise _lib.MfvitError(f"model on {self._arena.device} but input on {img.device}")
+        cfg = self._cfg(img, save)
+        self._ensure_shadow(cfg)
+        ws = self._get_ws(cfg)
+        feats = torch.empty(img.shape[0], self.num_tokens, self.embed_dim, device=img.device, dtype=torch.float32)
+        check(lib().mfvit_vit_forward(cfg, ptr(self._arena), ptr(self._shadow), ptr(img), ptr(ws), ptr(feats), stream()),
+              "mfvit_vit_forward")
+        if not save:
+            self._release_ws(ws)
+            ws = None
+        return feats, ws
+
+    def _run_backward(self, cfg, ws, dfeats, on_stage_done=None):
+        """Returns per-parameter gradient views (arena order) of a fresh flat gradient arena."""
+        dfeats = dfeats.contiguous()
+        if dfeats.dtype != torch.float32:
+            dfeats = dfeats.float()
+        gflat = torch.zeros_like(self._arena)
+        hook = on_stage_done or getattr(self, "_grad_stage_hook", None)
+        if hook is None:
+            check(lib().mfvit_vit_backward(cfg, ptr(self._arena), ptr(self._shadow), ptr(ws), ptr(dfeats), ptr(gflat), self.depth, -1,
+                                           stream()), "mfvit_vit_backward")
+        else:
+            for s in range(self.depth, -2, -1):
+                check(lib().mfvit_vit_backward(cfg, ptr(self._arena), ptr(self._shadow), ptr(ws), ptr(dfeats), ptr(gflat), s, s,
+                                               stream()), "mfvit_vit_backward")
+                hook(self, s, gflat)
+        self._last_grad_arena = gflat
+        grads = []
+        for name, p in self.arena_named_parameters():
+            if p.requires_grad:
+                off, n = self._offsets[name]
+                grads.append(gflat[off:off + n].view(p.shape))
+            else:
+                grads.append(None)
+        return grads
+
+    # ------------------------------------------------------------------ public API (reference call sites)
+    def _features(self, x, caller):
+        need = torch.is_grad_enabled() and any(p.requires_grad for p in self._arena_params)
+        key = (x._version, need, self._param_version(), torch.is_grad_enabled())
+        c = self._feat_cache
+        self._feat_cache = None
+        if c is not None and c[0] is x and c[1] == key and c[2] != caller:
+            # the reference runs every backbone twice per step on the same tensor (features3D then __call__, FUS:128+131);
+            # all dropouts are 0, so the second result is head(first[:, 0]): computed once.  Single use: a repeated call of
+            # the SAME method always recomputes.
+            return c[3]
+        feats = _EncoderFn.apply(self, x, need, *self._arena_params)
+        self._feat_cache = (x, key, caller, feats)
+        return feats
+
+    def features3D(self, x):
+        """(B,3,H,W) -> (B, T, 384) tokens after the final LayerNorm (FUS:128,133; crossvit.py:130-146)."""
+        return self._features(x, "features3D")
+
+    def forward_head(self, feats):
+        h = self.head
+        if isinstance(h, nn.Linear) and h.out_features <= 64 and h.weight.dtype == torch.float32:
+            return _HeadFn.apply(feats, h.weight, h.bias)
+        return h(feats[:, 0])
+
+    def forward(self, x):
+        """head(features3D(x)[:, 0])  (timm forward_features + head; all dropouts are 0)."""
+        return self.forward_head(self._features(x, "forward"))

@@ -1,0 +1,179 @@
+"""Tensor-level wrappers over the single-op entry points of libmfvit_hip.so.
+
+Used by the parity tests (tests/test_ops_gpu.py) and by the MoCo projector / predictor path.  Every function
+launches on torch's current HIP stream and returns freshly allocated tensors owned by the caller.
+"""
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_NONE, F32, check, lib, ptr, require_cuda, stream
+
+
+def _tdtype(code):
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def _code_of(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise _lib.MfvitError(f"unsupported dtype {t.dtype}")
+
+
+def linear_fwd(x, w, bias=None, gelu=False):
+    """y = x @ w.T + bias (x [M,K], w [N,K] of the same dtype).  gelu=True returns (pre, act)."""
+    require_cuda(x, w, bias)
+    code = _code_of(x)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=x.dtype)
+    y2 = torch.empty_like(y) if gelu else None
+    epi = EPI_BIAS_GELU if gelu else (EPI_BIAS if bias is not None else EPI_NONE)
+    check(lib().mfvit_linear_fwd(code, epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N, ptr(y2), N, M, N, K,
+                                 stream()), "mfvit_linear_fwd")
+    return (y, y2) if gelu else y
+
+
+def linear_wgrad(dy, x, out=None):
+    """dW [N,K] (f32) += dy[M,N].T @ x[M,K]."""
+    require_cuda(dy, x)
+    code = _code_of(dy)
+    M, N = dy.shape
+    K = x.shape[1]
+    if out is None:
+        out = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
+    check(lib().mfvit_linear_wgrad(code, ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(out), out.stride(0), M, N, K, stream()),
+          "mfvit_linear_wgrad")
+    return out
+
+
+def linear_res_ln_fwd(a, w, bias, res, gamma, beta, eps, y_f32=False):
+    """x_out = a @ w.T + bias + res ; y = LayerNorm(x_out).  Returns (x_out f32, y, mean, rstd)."""
+    require_cuda(a, w, res)
+    code = _code_of(a)
+    M, K = a.shape
+    x_out = torch.empty(M, 384, device=a.device, dtype=torch.float32)
+    y = torch.empty(M, 384, device=a.device, dtype=torch.float32 if y_f32 else a.dtype)
+    mean = torch.empty(M, device=a.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    check(lib().mfvit_linear_res_ln_fwd(code, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(res),
+                                        res.stride(0) if res is not None else 0, ptr(x_out), ptr(y), int(y_f32), ptr(gamma),
+                                        ptr(beta), eps, ptr(mean), ptr(rstd), M, K, stream()), "mfvit_linear_res_ln_fwd")
+    return x_out, y, mean, rstd
+
+
+def linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, gamma, dres, want_copy=True):
+    """dx = LNbwd(dy @ wt.T ; x, mean, rstd, gamma) + dres.  wt is the TRANSPOSED weight [384, K].
+    Returns (dx f32, dx copy in dy.dtype, dgamma, dbeta, dcol)."""
+    require_cuda(dy, wt, x)
+    code = _code_of(dy)
+    M, K = dy.shape
+    dx = torch.empty(M, 384, device=dy.device, dtype=torch.float32)
+    dx_t = torch.empty(M, 384, device=dy.device, dtype=dy.dtype) if want_copy else None
+    dgamma = torch.zeros(384, device=dy.device, dtype=torch.float32)
+    dbeta = torch.zeros_like(dgamma)
+    dcol = torch.zeros_like(dgamma)
+    check(lib().mfvit_linear_dgrad_ln_bwd(code, ptr(dy), dy.stride(0), ptr(wt), wt.stride(0), ptr(x), ptr(mean), ptr(rstd),
+                                          ptr(gamma), ptr(dres), ptr(dx), ptr(dx_t), ptr(dgamma), ptr(dbeta), ptr(dcol), M, K,
+                                          stream()), "mfvit_linear_dgrad_ln_bwd")
+    return dx, dx_t, dgamma, dbeta, dcol
+
+
+def attention_fwd(qkv, heads):
+    """qkv [B,T,3*D] (layout [B][T][3][H][d]) -> (out [B,T,D], lse [B,H,T])."""
+    require_cuda(qkv)
+    code = _code_of(qkv)
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    out = torch.empty(B, T, D, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
+    check(lib().mfvit_attention_fwd(code, ptr(qkv), ptr(out), ptr(lse), B, T, heads, D // heads, stream()), "mfvit_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, heads, want_dbias=True):
+    require_cuda(qkv, out, dout, lse)
+    code = _code_of(qkv)
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    dqkv = torch.empty_like(qkv)
+    dbias = torch.zeros(D3, device=qkv.device, dtype=torch.float32) if want_dbias else None
+    check(lib().mfvit_attention_bwd(code, ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), B, T, heads, D // heads,
+                                    stream()), "mfvit_attention_bwd")
+    return dqkv, dbias
+
+
+def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32):
+    require_cuda(x, gamma, beta)
+    rows, N = x.shape
+    y = torch.empty(rows, N, device=x.device, dtype=out_dtype)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    code = BF16 if out_dtype == torch.bfloat16 else F32
+    check(lib().mfvit_layernorm_fwd(code, ptr(x), ptr(y), int(out_dtype == torch.float32), ptr(gamma), ptr(beta), eps, ptr(mean),
+                                    ptr(rstd), rows, N, stream()), "mfvit_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, copy_dtype=None):
+    require_cuda(dy, x)
+    rows, N = x.shape
+    dx = torch.empty_like(x)
+    dx_t = torch.empty(rows, N, device=x.device, dtype=copy_dtype) if copy_dtype is not None else None
+    dgamma = torch.zeros(N, device=x.device, dtype=torch.float32)
+    dbeta = torch.zeros_like(dgamma)
+    dcol = torch.zeros_like(dgamma)
+    code = BF16 if copy_dtype == torch.bfloat16 else F32
+    check(lib().mfvit_layernorm_bwd(code, ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dx_t), ptr(dgamma),
+                                    ptr(dbeta), ptr(dcol), rows, N, stream()), "mfvit_layernorm_bwd")
+    return dx, dx_t, dgamma, dbeta, dcol
+
+
+def cast_transpose(src, dtype, want_straight=True, want_transposed=True):
+    require_cuda(src)
+    R, C = src.shape
+    code = BF16 if dtype == torch.bfloat16 else F32
+    dst = torch.empty(R, C, device=src.device, dtype=dtype) if want_straight else None
+    dst_t = torch.empty(C, R, device=src.device, dtype=dtype) if want_transposed else None
+    check(lib().mfvit_cast_transpose(code, ptr(src), ptr(dst), ptr(dst_t), R, C, stream()), "mfvit_cast_transpose")
+    return dst, dst_t
+
+
+def head_fwd(x, w, b, ldx=None, out=None, accumulate=False):
+    """y[m] = x[m*ldx : +K] @ w.T + b   (f32, small N)."""
+    require_cuda(x, w, b)
+    N, K = w.shape
+    if ldx is None:
+        ldx = x.stride(0)
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    check(lib().mfvit_head_fwd(ptr(x), ldx, ptr(w), ptr(b), ptr(out), out.stride(0), M, N, K, int(accumulate), stream()),
+          "mfvit_head_fwd")
+    return out
+
+
+def head_bwd(dy, x, w, ldx=None, dx=None, lddx=None, dx_accumulate=False, dw=None, db=None):
+    require_cuda(dy, x, w)
+    N, K = w.shape
+    M = dy.shape[0]
+    if ldx is None:
+        ldx = x.stride(0)
+    if dx is not None and lddx is None:
+        lddx = dx.stride(0)
+    check(lib().mfvit_head_bwd(ptr(dy), dy.stride(0), ptr(x), ldx, ptr(w), ptr(dx), lddx or 0, int(dx_accumulate), ptr(dw), ptr(db),
+                               M, N, K, stream()), "mfvit_head_bwd")
+    return dx, dw, db
+
+
+def cross_entropy(logits, target, want_grad=True):
+    """Returns (loss_mean [1], dlogits or None, preds int64)."""
+    require_cuda(logits, target)
+    B, C = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    dlogits = torch.empty_like(logits) if want_grad else None
+    preds = torch.empty(B, device=logits.device, dtype=torch.int64)
+    check(lib().mfvit_cross_entropy(ptr(logits), ptr(target), ptr(loss), ptr(dlogits), ptr(preds), B, C, stream()),
+          "mfvit_cross_entropy")
+    return loss, dlogits, preds

@@ -1,0 +1,110 @@
+"""GPU parity of the ViT-S/16 encoder (vits.vit_small -> mfvit_vit_forward / mfvit_vit_backward) against the CPU
+oracle (oracle/ref_vit.py) on identical seeded weights and inputs.
+
+Tolerances:
+  precision='fp32' : BASELINE.json north_star - outputs within 1e-3 relative of the f32 CPU path, argmax bit-exact.
+                     (exact-f32 MFMA; measured error is ~1e-5, asserted at 1e-3 / 2e-3 for gradients)
+  precision='bf16' : bf16 operands with f32 accumulation through 12 blocks: asserted at 4e-2 of the output scale
+                     (features are LayerNorm outputs of O(1)); the measured value is logged to gpurun_out/.
+"""
+import os
+
+import pytest
+import torch
+
+from conftest import rng_tensor
+from oracle import ref_vit
+
+pytestmark = pytest.mark.gpu
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_encoder.txt")
+
+
+def log(msg):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(msg + "\n")
+
+
+def build(precision, seed, depth=12, num_classes=3, img=224, **kw):
+    import vits
+    m = vits.vit_small(num_classes=num_classes, depth=depth, precision=precision, img_size=img, **kw)
+    p = ref_vit.seeded_params(seed, num_classes=num_classes, depth=depth, img_size=img)
+    missing = m.load_state_dict(p, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return m.to("cuda:0"), p
+
+
+def scale_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 4e-2)])
+@pytest.mark.parametrize("B,img", [(2, 224), (1, 384), (3, 64)])
+def test_features3d_and_logits(precision, tol, B, img):
+    m, p = build(precision, 501, img=img)
+    x = rng_tensor(502, (B, 3, img, img))
+    with torch.no_grad():
+        ref_f = ref_vit.features3d(p, x)
+        ref_l = ref_vit.head_linear(p, ref_f[:, 0])
+        xg = x.to("cuda:0")
+        f = m.features3D(xg)
+        logits = m(xg)
+    assert f.shape == ref_f.shape and f.dtype == torch.float32
+    e_f, e_l = scale_err(f, ref_f), scale_err(logits, ref_l)
+    log(f"features3D[{precision},B={B},img={img}] err={e_f:.3e} logits err={e_l:.3e}")
+    assert e_f < tol and e_l < tol
+    if precision == "fp32":
+        assert logits.argmax(1).cpu().tolist() == ref_l.argmax(1).tolist()
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("stop_grad_conv1", [False, True])
+def test_backward_all_parameters(precision, tol, stop_grad_conv1):
+    B, depth = 2, 3
+    m, p = build(precision, 511, depth=depth, stop_grad_conv1=stop_grad_conv1)
+    x = rng_tensor(512, (B, 3, 224, 224))
+    r = rng_tensor(513, (B, 197, 384))
+    rl = rng_tensor(514, (B, 3))
+    pd = {k: v.double().requires_grad_(k != "pos_embed") for k, v in p.items()}
+    f_ref = ref_vit.features3d(pd, x.double())
+    loss_ref = (f_ref * r.double()).sum() + (ref_vit.head_linear(pd, f_ref[:, 0]) * rl.double()).sum()
+    loss_ref.backward()
+    xg = x.to("cuda:0")
+    f = m.features3D(xg)
+    loss = (f * r.to("cuda:0")).sum() + (m(xg) * rl.to("cuda:0")).sum()
+    loss.backward()
+    worst = ("", 0.0)
+    for name, prm in m.named_parameters():
+        if name == "pos_embed":
+            assert prm.grad is None
+            continue
+        if stop_grad_conv1 and name.startswith("patch_embed"):
+            assert prm.grad is None
+            continue
+        assert prm.grad is not None, name
+        e = scale_err(prm.grad, pd[name].grad)
+        if e > worst[1]:
+            worst = (name, e)
+        assert e < tol, (name, e)
+    log(f"backward[{precision},stop_grad_conv1={stop_grad_conv1}] worst {worst[0]} err={worst[1]:.3e}")
+
+
+def test_state_dict_roundtrip_and_arena_survives_moves():
+    m, p = build("fp32", 521, depth=2)
+    sd = m.state_dict()
+    assert set(sd.keys()) == set(p.keys())
+    for k in p:
+        assert torch.equal(sd[k].cpu(), p[k]), k
+    assert m._arena_intact() and m.flat_parameters().is_cuda
+    with torch.no_grad():
+        m.blocks[1].mlp.fc1.weight.mul_(0.5)            # in-place update is seen through the arena
+    off, n = m.arena_slice("blocks.1.mlp.fc1.weight")
+    assert torch.equal(m.flat_parameters()[off:off + n].view(1536, 384).cpu(), p["blocks.1.mlp.fc1.weight"] * 0.5)
+
+
+def test_cpu_input_fails_loudly():
+    from mfvit import MfvitError
+    m, _ = build("fp32", 531, depth=1)
+    with pytest.raises(MfvitError):
+        m(torch.zeros(1, 3, 224, 224))
