@@ -122,6 +122,40 @@ int mfvit_head_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, c
 int mfvit_cross_entropy(const float* logits, const int64_t* target, float* loss_mean, float* dlogits, int64_t* preds, int B, int C,
                         mfvit_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Two-stream fusion: bidirectional cls<->patch cross-attention exchange + heads (f32).
+ * Replaces PreNorm / CrossAttention (MOD:15-21,108-137), MultiScaleTransformerEncoder.forward (FUS:35-65) and
+ * Fus_CrossViT.forward (FUS:126-157) for pool='cls', cross_attn_depth = multi_scale_enc_depth = 1.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct mfvit_fusion_cfg {
+    int batch;
+    int tokens;       /* 1 + patches (197 at 224^2) */
+    int dim;          /* 384 */
+    int heads;        /* 3 (FUS:75) -> head_dim 128 */
+    int num_classes;  /* 3 */
+    float eps_pre;    /* 1e-5: PreNorm's nn.LayerNorm default (MOD:18) */
+    float eps_post;   /* 1e-6: FUS:26,31 */
+} mfvit_fusion_cfg;
+
+/* Parameter arena (f32), state-dict order of Fus_CrossViT (22 tensors, 8 D^2 + 10 D + 2 (C D + C) floats):
+ *   cross_attn_layers.0.{0.norm.{weight,bias}, 0.fn.{wq,wk,wv}.weight, 0.fn.proj.{weight,bias}, 1.{weight,bias},
+ *                        2.norm.{weight,bias}, 2.fn.{wq,wk,wv}.weight, 2.fn.proj.{weight,bias}, 3.{weight,bias}},
+ *   mlp_head_cxr.0.{weight,bias}, mlp_head_enh.0.{weight,bias}.   The gradient arena has the same layout. */
+size_t mfvit_fusion_param_count(const mfvit_fusion_cfg* cfg);
+size_t mfvit_fusion_workspace_bytes(const mfvit_fusion_cfg* cfg);
+/* f_cxr / f_enh: (B,T,dim) f32 tokens (features3D of each stream).  hw_* / hb_*: the backbones' own classifier heads
+ * (C x dim, C) or NULL; when given, x_cxr / x_enh = head(f[:,0]) (FUS:131,135).  fused: (B,C) (FUS:147-155).
+ * The workspace keeps what the backward needs. */
+int mfvit_fusion_forward(const mfvit_fusion_cfg* cfg, const float* params, const float* f_cxr, const float* f_enh, const float* hw_cxr,
+                         const float* hb_cxr, const float* hw_enh, const float* hb_enh, void* workspace, float* fused, float* x_cxr,
+                         float* x_enh, mfvit_stream_t stream);
+/* dparams, dhw_*, dhb_* are ACCUMULATED into.  df_cxr / df_enh: (B,T,dim) fully written, or both NULL when the
+ * backbones are frozen (README default, MAIN_CA:298-305). */
+int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, const float* f_cxr, const float* f_enh, const float* hw_cxr,
+                          const float* hw_enh, void* workspace, const float* dfused, const float* dx_cxr, const float* dx_enh,
+                          float* dparams, float* df_cxr, float* df_enh, float* dhw_cxr, float* dhb_cxr, float* dhw_enh, float* dhb_enh,
+                          mfvit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

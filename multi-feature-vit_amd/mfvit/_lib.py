@@ -20,6 +20,11 @@ class VitCfg(Structure):
                 ("ln_eps", c_float)]
 
 
+class FusionCfg(Structure):
+    _fields_ = [("batch", c_int), ("tokens", c_int), ("dim", c_int), ("heads", c_int), ("num_classes", c_int),
+                ("eps_pre", c_float), ("eps_post", c_float)]
+
+
 P = c_void_p
 I = c_int
 L = c_int64
@@ -48,6 +53,10 @@ SIGNATURES = {
     "mfvit_head_fwd": (I, [P, L, P, P, P, L, I, I, I, I, P]),
     "mfvit_head_bwd": (I, [P, L, P, L, P, P, L, I, P, P, I, I, I, P]),
     "mfvit_cross_entropy": (I, [P, P, P, P, P, I, I, P]),
+    "mfvit_fusion_param_count": (c_size_t, [POINTER(FusionCfg)]),
+    "mfvit_fusion_workspace_bytes": (c_size_t, [POINTER(FusionCfg)]),
+    "mfvit_fusion_forward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P, P, P, P]),
+    "mfvit_fusion_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
 }
 
 _lib = None

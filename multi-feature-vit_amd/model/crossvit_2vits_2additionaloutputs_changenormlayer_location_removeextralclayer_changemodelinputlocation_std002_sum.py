@@ -1,0 +1,103 @@
+"""Drop-in for the reference's two-stream fusion model file
+(moco_pretraining/moco/model/crossvit_2vits_2additionaloutputs_changenormlayer_location_removeextralclayer_
+changemodelinputlocation_std002_sum.py): ``MultiScaleTransformerEncoder`` and ``Fus_CrossViT`` with the same constructor
+signatures, the same 22 state-dict keys and the same ``forward(vit_cxr, vit_enh, img_cxr, img_enh) -> (fused, x_cxr,
+x_enh)`` contract, running on the gfx950 kernels of libmfvit_hip.so (csrc/fusion.hip + the ViT encoder).
+
+Reference behaviours kept: the backbones are NOT submodules (Q1: only ``features3D`` bound
+methods are stored, the modules arrive as forward arguments), so ``parameters()`` / ``state_dict()`` hold exactly the
+22 fusion tensors; each backbone's two per-step evaluations on the same image are computed once (Q2); only the cls
+row of the post-exchange LayerNorm / residual is consumed (Q3).
+"""
+import torch
+import torch.nn as nn
+
+from mfvit.arena import ParamArena
+from mfvit.fusion import FusionFn
+from model.module import Attention, CrossAttention, FeedForward, PreNorm  # noqa: F401  (same import list as FUS:6)
+
+
+class MultiScaleTransformerEncoder(nn.Module):
+    """FUS:12-65.  ModuleList per layer: [0] PreNorm(CrossAttention) "cross_attn_s", [1] LayerNorm(eps 1e-6) "n_l",
+    [2] PreNorm(CrossAttention) "cross_attn_l", [3] LayerNorm(eps 1e-6) "n_s"."""
+
+    def __init__(self, small_dim=384, large_dim=384, cross_attn_depth=1, cross_attn_heads=3, dropout=0.):
+        super().__init__()
+        if small_dim != 384 or large_dim != 384 or cross_attn_heads != 3:
+            raise NotImplementedError("the fused exchange is built for dim 384 / 3 heads (FUS:73-75 defaults)")
+        if cross_attn_depth != 1:
+            raise NotImplementedError("cross_attn_depth != 1 is not used by the reference (FUS:74 default)")
+        self.cross_attn_layers = nn.ModuleList([])
+        for _ in range(cross_attn_depth):
+            self.cross_attn_layers.append(nn.ModuleList([
+                PreNorm(large_dim, CrossAttention(large_dim, num_heads=cross_attn_heads, attn_drop=dropout)),
+                nn.LayerNorm(large_dim, eps=1e-6),
+                PreNorm(small_dim, CrossAttention(small_dim, num_heads=cross_attn_heads, attn_drop=dropout)),
+                nn.LayerNorm(small_dim, eps=1e-6),
+            ]))
+
+    def forward(self, xs, xl):
+        from mfvit.xattn import exchange
+        return exchange(self, xs, xl)
+
+
+class Fus_CrossViT(nn.Module):
+    def __init__(self, model_vit_cxr, model_vit_enh, num_classes=3, small_dim=384, large_dim=384, cross_attn_depth=1,
+                 multi_scale_enc_depth=1, heads=3, dropout=0., pool='cls'):
+        super().__init__()
+        if pool != 'cls':
+            raise NotImplementedError("pool='mean' is not used by the reference (FUS:76 default 'cls')")
+        if multi_scale_enc_depth != 1:
+            raise NotImplementedError("multi_scale_enc_depth != 1 is not used by the reference (FUS:74 default)")
+        # bound methods, as in FUS:80,83: the backbones do not become submodules
+        self.vit_features_cxr = model_vit_cxr.features3D
+        self.vit_features_enh = model_vit_enh.features3D
+        self.multi_scale_transformers = nn.ModuleList([
+            MultiScaleTransformerEncoder(small_dim=small_dim, large_dim=large_dim, cross_attn_depth=cross_attn_depth,
+                                         cross_attn_heads=heads, dropout=dropout)
+            for _ in range(multi_scale_enc_depth)])
+        self.pool = pool
+        self.num_classes = num_classes
+        self.mlp_head_cxr = nn.Sequential(nn.Linear(small_dim, num_classes))
+        self.mlp_head_enh = nn.Sequential(nn.Linear(large_dim, num_classes))
+        self.apply(self._init_weights)
+        self._arena = ParamArena(list(self.named_parameters()))
+
+    @staticmethod
+    def _init_weights(m):  # FUS:117-124
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if getattr(self, "_arena", None) is not None:
+            self._arena.rebuild()
+        return out
+
+    def flat_parameters(self):
+        return self._arena.ensure()
+
+    @staticmethod
+    def _plain_head(vit):
+        h = getattr(vit, "head", None)
+        if isinstance(h, nn.Linear) and h.weight.dtype == torch.float32 and h.bias is not None:
+            return h
+        return None
+
+    def forward(self, vit_cxr, vit_enh, img_cxr, img_enh):
+        cxr_ftrs = self.vit_features_cxr(img_cxr)      # (B, 197, 384)   FUS:128
+        enh_ftrs = self.vit_features_enh(img_enh)      #                 FUS:133
+        hc, he = self._plain_head(vit_cxr), self._plain_head(vit_enh)
+        fused_heads = hc is not None and he is not None and hc.out_features == self.num_classes == he.out_features \
+            and getattr(vit_cxr, "features3D", None) == self.vit_features_cxr \
+            and getattr(vit_enh, "features3D", None) == self.vit_features_enh
+        if fused_heads:
+            # x_S = vit_S(img_S) = head_S(features3D(img_S)[:, 0])  (FUS:131,135; dropouts are 0): evaluated inside the fused node
+            return FusionFn.apply(self._arena, cxr_ftrs, enh_ftrs, hc.weight, hc.bias, he.weight, he.bias, *self._arena.params)
+        fused, _, _ = FusionFn.apply(self._arena, cxr_ftrs, enh_ftrs, None, None, None, None, *self._arena.params)
+        return fused, vit_cxr(img_cxr), vit_enh(img_enh)

@@ -1,0 +1,135 @@
+"""GPU parity of the two-stream fusion (Fus_CrossViT drop-in -> mfvit_fusion_forward/backward, f32) against
+  (a) the CPU oracle (oracle/ref_fusion.py) on seeded feature tensors, forward and all gradients incl. d features;
+  (b) the reference-generated golden vector tests/golden/fusion_e2e.npz (reference Fus_CrossViT + CE loss + grads),
+      end to end through the HIP ViT encoders in precision='fp32'.
+Tolerance: BASELINE.json north_star 1e-3 relative (f32), argmax bit-exact; measured values are logged."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, check_sampled, rng_tensor
+from oracle import ref_fusion, ref_vit
+
+pytestmark = pytest.mark.gpu
+FUS_MOD = ("model.crossvit_2vits_2additionaloutputs_changenormlayer_location_removeextralclayer_"
+           "changemodelinputlocation_std002_sum")
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_fusion.txt")
+
+
+def log(msg):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(msg + "\n")
+
+
+def scale_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+class FeatureProvider(torch.nn.Module):
+    """A 'backbone' that returns a stored token tensor: lets the fusion be tested on arbitrary features."""
+
+    def __init__(self, feats, head_w, head_b):
+        super().__init__()
+        self.feats = feats
+        self.head = torch.nn.Linear(384, head_w.shape[0])
+        with torch.no_grad():
+            self.head.weight.copy_(head_w)
+            self.head.bias.copy_(head_b)
+
+    def features3D(self, img):
+        return self.feats
+
+    def forward(self, img):
+        return self.head(self.feats[:, 0])
+
+
+@pytest.mark.parametrize("B,T", [(2, 197), (5, 50), (1, 577)])
+@pytest.mark.parametrize("need_df", [True, False])
+def test_fusion_vs_oracle(B, T, need_df):
+    fus = importlib.import_module(FUS_MOD)
+    dev = torch.device("cuda:0")
+    fp = ref_fusion.seeded_fusion_params(601)
+    hw = [rng_tensor(602 + i, (3, 384), 0.05) for i in range(2)]
+    hb = [rng_tensor(604 + i, (3,), 0.1) for i in range(2)]
+    fc, fe = rng_tensor(606, (B, T, 384)), rng_tensor(607, (B, T, 384))
+    r = [rng_tensor(608 + i, (B, 3)) for i in range(3)]
+    # oracle (float64)
+    fpd = {k: v.double().requires_grad_(True) for k, v in fp.items()}
+    fcd, fed = fc.double().requires_grad_(True), fe.double().requires_grad_(True)
+    hwd = [w.double().requires_grad_(True) for w in hw]
+    hbd = [b.double().requires_grad_(True) for b in hb]
+    fused_r = ref_fusion.fus_from_features(fpd, fcd, fed)
+    xc_r = fcd[:, 0] @ hwd[0].t() + hbd[0]
+    xe_r = fed[:, 0] @ hwd[1].t() + hbd[1]
+    ((fused_r * r[0].double()).sum() + (xc_r * r[1].double()).sum() + (xe_r * r[2].double()).sum()).backward()
+    # HIP
+    fcg, feg = fc.to(dev).requires_grad_(need_df), fe.to(dev).requires_grad_(need_df)
+    vc = FeatureProvider(fcg, hw[0], hb[0]).to(dev)
+    ve = FeatureProvider(feg, hw[1], hb[1]).to(dev)
+    vc.feats, ve.feats = fcg, feg
+    model = fus.Fus_CrossViT(vc, ve)
+    model.load_state_dict(fp, strict=True)
+    model = model.to(dev)
+    assert sum(p.numel() for p in model.parameters()) == 1185798 and len(model.state_dict()) == 22
+    fused, xc, xe = model(vc, ve, None, None)
+    e_f = [scale_err(fused, fused_r), scale_err(xc, xc_r), scale_err(xe, xe_r)]
+    ((fused * r[0].to(dev)).sum() + (xc * r[1].to(dev)).sum() + (xe * r[2].to(dev)).sum()).backward()
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        e = scale_err(p.grad, fpd[k].grad)
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 1e-3, (k, e)
+    for name, got, ref in (("cxr.head.w", vc.head.weight.grad, hwd[0].grad), ("enh.head.w", ve.head.weight.grad, hwd[1].grad),
+                           ("cxr.head.b", vc.head.bias.grad, hbd[0].grad), ("enh.head.b", ve.head.bias.grad, hbd[1].grad)):
+        e = scale_err(got, ref)
+        worst = max(worst, (name, e), key=lambda t: t[1])
+        assert e < 1e-3, (name, e)
+    if need_df:
+        for name, got, ref in (("d f_cxr", fcg.grad, fcd.grad), ("d f_enh", feg.grad, fed.grad)):
+            e = scale_err(got, ref)
+            worst = max(worst, (name, e), key=lambda t: t[1])
+            assert e < 1e-3, (name, e)
+    else:
+        assert fcg.grad is None and feg.grad is None
+    log(f"fusion_vs_oracle[B={B},T={T},df={need_df}] fwd {max(e_f):.3e} worst grad {worst[0]} {worst[1]:.3e}")
+    assert max(e_f) < 1e-3
+
+
+def test_fus_crossvit_end_to_end_against_reference_golden():
+    """Reference-generated vector: reference Fus_CrossViT forward + CE(output) + backward (fusion_e2e.npz)."""
+    import vits_returnftrs as vits
+    fus = importlib.import_module(FUS_MOD)
+    g = np.load(os.path.join(GOLDEN, "fusion_e2e.npz"), allow_pickle=False)
+    dev = torch.device("cuda:0")
+    depth = int(g["vit_depth"])
+    backs = []
+    for seed in (int(g["seed_vit_cxr"]), int(g["seed_vit_enh"])):
+        m = vits.__dict__["vit_small"](num_classes=3, depth=depth, precision="fp32")   # MAIN_CA:289-290,309-310
+        m.load_state_dict(ref_vit.seeded_params(seed, num_classes=3, depth=depth), strict=True)
+        for name, prm in m.named_parameters():                                          # MAIN_CA:298-305 (README default)
+            if name not in ("head.weight", "head.bias"):
+                prm.requires_grad = False
+        backs.append(m.to(dev))
+    model = fus.Fus_CrossViT(backs[0], backs[1])
+    model.load_state_dict(ref_fusion.seeded_fusion_params(int(g["seed_params"])), strict=True)
+    model = model.to(dev)
+    assert sorted(model.state_dict().keys()) == list(g["keys"])
+    ic = rng_tensor(int(g["seed_img_cxr"]), (2, 3, 224, 224)).to(dev)
+    ie = rng_tensor(int(g["seed_img_enh"]), (2, 3, 224, 224)).to(dev)
+    target = torch.from_numpy(g["target"]).to(dev)
+    fused, x_cxr, x_enh = model(backs[0], backs[1], ic, ie)
+    output = fused + x_cxr + x_enh                                   # MAIN_CA:868
+    loss = torch.nn.CrossEntropyLoss()(output, target)               # MAIN_CA:873
+    loss.backward()
+    errs = {n: scale_err(t, torch.from_numpy(g[n])) for n, t in (("fused", fused), ("x_cxr", x_cxr), ("x_enh", x_enh),
+                                                                    ("output", output), ("loss", loss))}
+    log(f"fus_e2e golden: {errs}")
+    assert max(errs.values()) < 1e-3
+    assert output.argmax(1).cpu().tolist() == g["preds"].tolist()
+    for k, p in model.named_parameters():
+        check_sampled(g, "d." + k, p.grad, rtol=2e-3, atol=2e-3 * float(g[f"d.{k}.abssum"]) / p.numel())
