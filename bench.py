@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Contract benchmark: images/sec of the two-stream 224^2 vit_small MF-CA train step (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full pass of the hot path over one synthetic batch that is already resident in HBM:
+  Fus_CrossViT forward (two ViT-S/16 encoders + cross-attention exchange + heads) -> output sum -> cross entropy ->
+  backward -> (N>1: RCCL gradient all-reduce overlapped with backward) -> Adam step.
+--mode T (default): both backbones trainable - full forward + backward, 55.88 GFLOP / pair.
+--mode F: backbones frozen except their heads (reference README default, MAIN_CA:298-305), 19.10 GFLOP / pair.
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel class, timed with HIP events on the launch stream inside
+the timed region) and `cpu_baseline` (the CPU oracle timed on this host's cores on a bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "multi-feature-vit_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FUS_MOD = ("model.crossvit_2vits_2additionaloutputs_changenormlayer_location_removeextralclayer_"
+           "changemodelinputlocation_std002_sum")
+GFLOP_PER_PAIR = {"T": 55.88, "F": 19.10}      # algorithmic work, each ViT counted once
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense MFMA peak per dtype
+PEAK_HBM_GBS = 8000.0
+NCLS = 10
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="pairs per GPU (BASELINE configs[2])")
+    ap.add_argument("--mode", choices=["T", "F"], default="T")
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def build_models(args, dev):
+    import importlib
+    import vits_returnftrs as vits
+    fus = importlib.import_module(FUS_MOD)
+    torch.manual_seed(0)
+    backs = []
+    for _ in range(2):
+        m = vits.__dict__["vit_small"](precision=args.precision, img_size=args.img)      # MAIN_CA:289-290
+        if args.mode == "F":                                                             # MAIN_CA:298-305
+            for name, prm in m.named_parameters():
+                if name not in ("head.weight", "head.bias"):
+                    prm.requires_grad = False
+        m.head = torch.nn.Linear(m.head.in_features, 3)                                  # MAIN_CA:309-310
+        m.head.weight.data.normal_(mean=0.0, std=0.01)
+        m.head.bias.data.zero_()
+        backs.append(m.to(dev))
+    model = fus.Fus_CrossViT(backs[0], backs[1]).to(dev)                                 # MAIN_CA:393
+    return model, backs
+
+
+def cpu_baseline(args, model, backs, x, xe, target):
+    """The CPU oracle (oracle/ref_fusion.ca_step + backward) on this host's cores, bounded sample."""
+    from oracle import ref_fusion
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    ncpu = max(1, min(ncpu, 16))          # a 1-GPU box owns a 16-core share of the host (more threads only oversubscribe)
+    torch.set_num_threads(ncpu)
+    nb = 4
+    fp = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    vits_p = []
+    for m in backs:
+        train = args.mode == "T"
+        vits_p.append({k: v.detach().cpu().clone().requires_grad_((train and k != "pos_embed") or k.startswith("head"))
+                       for k, v in m.state_dict().items()})
+    xc, xec, tc = x[:nb].cpu(), xe[:nb].cpu(), target[:nb].cpu()
+
+    def step():
+        out, preds, loss, _ = ref_fusion.ca_step(fp, vits_p[0], vits_p[1], xc, xec, tc)
+        loss.backward()
+        for d in (fp, vits_p[0], vits_p[1]):
+            for v in d.values():
+                v.grad = None
+        return out.detach()
+
+    t0 = time.perf_counter()
+    out = step()  # warm-up (also the sample if the host is slow)
+    warm = time.perf_counter() - t0
+    print(f"[bench] cpu_baseline warm-up step: {warm:.2f} s on {ncpu} threads", file=sys.stderr, flush=True)
+    n = 0 if warm > 15.0 else max(1, min(args.cpu_steps, int(20.0 / max(warm, 1e-3))))
+    if n:
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = step()
+        dt = (time.perf_counter() - t0) / n
+    else:
+        dt = warm
+    return dict(value=nb / dt, unit="images/sec", cores=ncpu, kind="port",
+                sample=f"oracle (torch f32 CPU restatement) CA step mode {args.mode}: {nb} pairs x {max(n, 1)} step(s)"
+                       f"{' after 1 warm-up' if n else ' (the warm-up itself, host too slow for more)'}, {ncpu} threads"), out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from mfvit import _lib
+    from mfvit.ddp import GradSync
+    from mfvit.losses import cross_entropy
+    lib = _lib.lib()
+
+    model, backs = build_models(args, dev)
+    g = torch.Generator().manual_seed(1234 + rank)                                       # SURVEY.md 8(d) synthetic inputs
+    B = args.batch
+    x = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
+    xe = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
+    target = torch.randint(0, 3, (B,), generator=g).to(dev)
+
+    params = list(model.parameters())
+    for m in backs:
+        params += [p for p in m.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))                          # MAIN_CA:455-459
+    sync = GradSync()
+    for m in backs:
+        sync.attach(m)
+    small = list(model.parameters()) + [p for m in backs for p in m.head.parameters()]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        fused, x_c, x_e = model(backs[0], backs[1], x, xe)                               # MAIN_CA:862
+        output = fused + x_c + x_e                                                       # MAIN_CA:868
+        loss, preds = cross_entropy(output, target)                                      # MAIN_CA:870-873
+        loss.backward()                                                                  # MAIN_CA:880
+        sync.reduce_grads(small)
+        sync.finish()
+        opt.step()                                                                       # MAIN_CA:882
+        return loss, output
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; the first warm-up steps time every kernel class to pick the dominant one
+    buf = (ctypes.c_double * (NCLS * 4))()
+    lib.mfvit_prof_enable((1 << NCLS) - 1)
+    for i in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    lib.mfvit_prof_collect(buf, NCLS)
+    cls_ms = [buf[c * 4 + 1] for c in range(NCLS)]
+    dom = max(range(NCLS), key=lambda c: cls_ms[c])
+    lib.mfvit_prof_enable(1 << dom)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, output = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.mfvit_prof_collect(buf, NCLS)
+    lib.mfvit_prof_enable(0)
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+
+    if rank == 0:
+        launches, ms, flops, bts = (buf[dom * 4 + i] for i in range(4))
+        name = lib.mfvit_prof_class_name(dom).decode()
+        roof = dict(kernel=name, launches_per_step=launches / args.steps, avg_us=1e3 * ms / max(launches, 1))
+        if flops > 0:
+            ach = flops / (ms * 1e-3) / 1e12
+            peak = PEAK_TFLOPS[args.precision]
+            roof.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None)
+        else:
+            ach = bts / (ms * 1e-3) / 1e9
+            roof.update(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None)
+        total = sum(cls_ms) or 1.0
+        roof["warmup_time_share_by_class"] = {lib.mfvit_prof_class_name(c).decode(): round(cls_ms[c] / total, 4)
+                                              for c in range(NCLS) if cls_ms[c] > 0}
+        out = dict(metric="images/sec (two-stream 224^2 vit_small MF-CA train step)", value=B * world * args.steps / dt,
+                   unit="images/sec", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.precision, data="synthetic",
+                   config=dict(workload=f"BASELINE configs[2]: two-stream MF-ViT CA finetune step, {B} CXR+Enh pairs/GPU at "
+                                        f"{args.img}x{args.img}, 2x vit_small + cross-attention fusion + CE + backward + Adam; "
+                                        f"mode {args.mode} ({'full backward through both backbones' if args.mode == 'T' else 'frozen backbones (README default)'})",
+                               global_batch=B * world, mode=args.mode, parallelism=f"dp{world}",
+                               algorithmic_gflop_per_pair=GFLOP_PER_PAIR[args.mode] if args.img == 224 else None),
+                   model_tflops=(GFLOP_PER_PAIR[args.mode] * B * world * args.steps / dt / 1e3) if args.img == 224 else None,
+                   loss=float(loss.detach()), roofline=roof)
+        print("[bench] gpu " + json.dumps(out), file=sys.stderr, flush=True)
+        if not args.no_cpu_baseline:
+            cb, ref_out = cpu_baseline(args, model, backs, x, xe, target)
+            out["cpu_baseline"] = cb
+            with torch.no_grad():                       # same (final) weights as the oracle copy, same first pairs
+                f_, xc_, xe_ = model(backs[0], backs[1], x, xe)
+            got = (f_ + xc_ + xe_)[:ref_out.shape[0]].float().cpu()
+            out["parity_vs_cpu_oracle"] = dict(
+                logits_max_rel_err=float((got - ref_out).abs().max() / ref_out.abs().max()),
+                argmax_equal=bool((got.argmax(1) == ref_out.argmax(1)).all()),
+                note="bench-precision logits vs the f32 CPU oracle on the same first 4 pairs and the same final weights; the "
+                     "1e-3 parity gate is asserted in precision='fp32' by tests/ (bf16 is the throughput mode)")
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -156,6 +156,16 @@ int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, cons
                           float* dparams, float* df_cxr, float* df_enh, float* dhw_cxr, float* dhb_cxr, float* dhw_enh, float* dhb_enh,
                           mfvit_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Opt-in kernel timing (HIP events on the launch stream), used by bench.py for the roofline of the dominant kernel.
+ * Classes: 0 gemm_nt_tile 1 gemm_nt_row_res_ln 2 gemm_nt_row_lnbwd 3 gemm_tn_wgrad 4 attention_fwd 5 attention_bwd
+ *          6 xattn_stream_fwd 7 xattn_stream_bwd 8 infonce 9 other.
+ * mfvit_prof_collect waits for the recorded events and fills out[cls*4 + {0 launches, 1 ms, 2 algorithmic flops,
+ * 3 algorithmic bytes}] (ncls <= 10), then clears the records. */
+int mfvit_prof_enable(int class_mask); /* bit c set = time class c; 0 = off */
+int mfvit_prof_collect(double* out, int ncls);
+const char* mfvit_prof_class_name(int cls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,9 @@
 // thread, online softmax in registers.  f32 arithmetic for both storage types; the f32 instantiation is the
 // parity path (bit-for-bit deterministic, no atomics except the bias-gradient column sums).
 #include "common.cuh"
+#include "prof.h"
+
+#include <stdlib.h>
 
 namespace mfvit {
 
@@ -226,6 +229,7 @@ static int launch_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int
         (void)hipFuncSetAttribute((const void*)attn_fwd_exact_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
     hipLaunchKernelGGL((attn_fwd_exact_kernel<T, HD>), dim3(B * H), dim3(256), bytes, st, (const T*)qkv, (T*)out, lse, Tn, H,
                        1.0f / sqrtf((float)HD));
     MFVIT_CHECK_LAUNCH();
@@ -241,6 +245,7 @@ static int launch_bwd(const void* qkv, const void* out, const void* dout, const 
         (void)hipFuncSetAttribute((const void*)attn_bwd_exact_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
+    ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
     hipLaunchKernelGGL((attn_bwd_exact_kernel<T, HD>), dim3(B * H), dim3(256), bytes, st, (const T*)qkv, (const T*)out, (const T*)dout, lse,
                        (T*)dqkv, dbias, Tn, H, 1.0f / sqrtf((float)HD));
     MFVIT_CHECK_LAUNCH();
@@ -261,6 +266,25 @@ int attn_bwd_exact(int dtype, const void* qkv, const void* out, const void* dout
         return dtype == MFVIT_BF16 ? launch_bwd<bf16, 64>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st)
                                    : launch_bwd<float, 64>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
     return MFVIT_EINVAL;
+}
+
+// ---- dispatch: bf16 / head_dim 32 -> MFMA kernels (attention_mfma.hip); everything else -> exact kernels
+bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward);
+int attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st);
+int attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
+                  hipStream_t st);
+static bool force_exact() {
+    static const bool v = [] { const char* e = getenv("MFVIT_ATTN_EXACT"); return e && e[0] == '1'; }();
+    return v;
+}
+int attn_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, hipStream_t st) {
+    if (!force_exact() && attn_mfma_supported(dtype, Tn, HDim, false)) return attn_fwd_mfma(qkv, out, lse, B, Tn, H, st);
+    return attn_fwd_exact(dtype, qkv, out, lse, B, Tn, H, HDim, st);
+}
+int attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
+             int HDim, hipStream_t st) {
+    if (!force_exact() && attn_mfma_supported(dtype, Tn, HDim, true)) return attn_bwd_mfma(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+    return attn_bwd_exact(dtype, qkv, out, dout, lse, dqkv, dbias, B, Tn, H, HDim, st);
 }
 
 }  // namespace mfvit

@@ -1,0 +1,326 @@
+// MFMA multi-head self-attention core for bf16, head_dim 32 (ViT-S: 12 heads x 32) on gfx950.
+//
+// One workgroup (4 waves) per (image, head); K/V (forward) or Q/K/V/dO (backward) of that head live in LDS as bf16.
+// T = 197 keys fit whole, so the forward does an exact softmax per 32-query tile over register-resident scores
+// (chunks of up to 8 key tiles; longer sequences chain chunks with an online rescale).
+//
+// Operand orientation ("swapped" products, wave64 32x32x16 MFMA):
+//   S^T[key][q]  = K_tile (A, rows = keys)  x  Q^T (B, cols = queries)     -> the query sits on the LANE: row max / row
+//                                                                             sum are in-register + one cross-half shuffle
+//   O^T[d][q]   += V^T (A, rows = d)        x  P^T (B)                       -> P^T is the S^T accumulator itself (registers
+//                  8s..8s+7 = k-step s); V^T fragments come from the [key][d] LDS image with ds_read_b64_tr_b16 in the
+//                  accumulator's k order (key = 16s + 8(j>>2) + 4h + (j&3)).
+// head_dim 32 makes this kernel VALU(exp)-bound, not MFMA-bound (hard parts): per 32x32 tile 4 MFMAs (128
+// cycles) vs ~16 x (fma + exp2 + max + add + cvt) per lane.
+//
+// Backward (flash-style recompute from the saved log-sum-exp, two phases, no atomics, deterministic):
+//   phase A (wave = query tile): dS^T[key][q] -> dQ^T[d][q] += K^T x dS^T       (lse_q, D_q are per-lane scalars)
+//   phase B (wave = key tile)  : P[q][key], dS[q][key] -> dV^T[d][key] += dO^T x P ; dK^T[d][key] += Q^T x dS
+#include "common.cuh"
+#include "prof.h"
+
+namespace mfvit {
+
+namespace {
+
+constexpr int HD = 32;
+constexpr int RSB = 80;  // LDS row pitch in bytes (64 B of data + 16): b128 row reads of 16 consecutive rows are conflict-free
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// natural-order fragment: row (rowbase + lane&31), elements d = 16 s + 8 (lane>>5) .. +8
+__device__ __forceinline__ bf16x8 row_frag(const char* img, int rowbase, int s, int lane) {
+    return *(const bf16x8*)(img + (rowbase + (lane & 31)) * RSB + 32 * s + 16 * (lane >> 5));
+}
+// transposed fragment in ACCUMULATOR k order: lane holds column d = lane&31; element j = row (rowbase + 16 s + 8 (j>>2) + 4 h + (j&3))
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int pitch, int rowbase, int s, int lane) {
+    const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+    const char* a = img + (rowbase + 16 * s + 4 * h + q) * pitch + (16 * g1 + 4 * p) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + 8 * pitch));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[8 * s + j];
+    return o;
+}
+__device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// copy rows [0, Tn) of one (b, which, h) slice (64 B each) into an LDS image with the given pitch; rows [Tn, Tpad) are zeroed
+__device__ __forceinline__ void stage(const bf16* base, long row_stride, int Tn, int Tpad, char* img, int pitch) {
+    for (int q = threadIdx.x; q < Tpad * 4; q += blockDim.x) {
+        const int t = q >> 2, c = q & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t < Tn) v = *(const uint4*)(base + (long)t * row_stride + 8 * c);
+        *(uint4*)(img + t * pitch + 16 * c) = v;
+    }
+}
+// store an accumulator tile X^T[d][col] (col on the lane) as rows of a [.., HD] bf16 tensor: 4 x 8-byte stores per lane
+__device__ __forceinline__ void store_tile_T(bf16* row_ptr, const f32x16& acc, float mul, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[4 * g + j] * mul);
+        *(bf16x4*)(row_ptr + 8 * g + 4 * (lane >> 5)) = o;
+    }
+}
+
+constexpr int NKC = 4;  // key tiles per register-resident chunk (4 x 16 = 64 score registers -> 2 waves per SIMD)
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
+                                                            int Tn, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int Tpad = (Tn + 31) & ~31;
+    char* Ks = lds;
+    char* Vs = lds + Tpad * RSB;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rs = 3L * H * HD;
+    const bf16* base = qkv + (long)b * Tn * rs + h * HD;
+    stage(base + (long)H * HD, rs, Tn, Tpad, Ks, RSB);
+    stage(base + 2L * H * HD, rs, Tn, Tpad, Vs, 64);
+    __syncthreads();
+    const float c = scale * 1.4426950408889634f;
+    const int nt = Tpad >> 5;
+    for (int qt = wave; qt < nt; qt += 4) {
+        const int q = qt * 32 + (lane & 31);
+        const int qc = q < Tn ? q : Tn - 1;
+        bf16x8 qf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[s] = *(const bf16x8*)(base + (long)qc * rs + 16 * s + 8 * (lane >> 5));
+        float m2 = -INFINITY, lsum = 0.f;
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        for (int k0 = 0; k0 < nt; k0 += NKC) {
+            const int n = nt - k0 < NKC ? nt - k0 : NKC;
+            f32x16 sc[NKC];
+#pragma unroll
+            for (int t = 0; t < NKC; ++t) {
+                if (t < n) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) sc[t] = mma(row_frag(Ks, (k0 + t) * 32, s, lane), qf[s], sc[t]);
+                    if ((k0 + t + 1) * 32 > Tn) {  // last key tile: mask the zero-padded keys
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if ((k0 + t) * 32 + acc_row(r, lane) >= Tn) sc[t][r] = -INFINITY;
+                    }
+                }
+            }
+            float cm = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < NKC; ++t)
+                if (t < n) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cm = fmaxf(cm, sc[t][r]);
+                }
+            cm = fmaxf(cm, __shfl_xor(cm, 32, 64)) * c;
+            const float mn = fmaxf(m2, cm);
+            const float alpha = exp2f(m2 - mn);
+            m2 = mn;
+            lsum *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+            for (int t = 0; t < NKC; ++t)
+                if (t < n) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sc[t][r], c, -m2));
+                        sc[t][r] = p;
+                        lsum += p;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) o = mma(tr_frag(Vs, 64, (k0 + t) * 32, s, lane), pack8(sc[t], s), o);
+                }
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        if (q < Tn) {
+            store_tile_T(out + ((long)b * Tn + q) * H * HD + h * HD, o, 1.0f / lsum, lane);
+            if (lane < 32) lse[((long)b * H + h) * Tn + q] = (m2 + log2f(lsum)) * 0.6931471805599453f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                            const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                            bf16* __restrict__ dqkv, int Tn, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int Tpad = (Tn + 31) & ~31;
+    char* Qs = lds;
+    char* Ks = Qs + Tpad * RSB;
+    char* Vs = Ks + Tpad * RSB;
+    char* Os = Vs + Tpad * RSB;  // dO
+    float* Ls = (float*)(Os + Tpad * RSB);
+    float* Ds = Ls + Tpad;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rs = 3L * H * HD, os = (long)H * HD;
+    const bf16* base = qkv + (long)b * Tn * rs + h * HD;
+    bf16* dbase = dqkv + (long)b * Tn * rs + h * HD;
+    const bf16* obase = out + (long)b * Tn * os + h * HD;
+    const bf16* dobase = dout + (long)b * Tn * os + h * HD;
+    stage(base, rs, Tn, Tpad, Qs, RSB);
+    stage(base + (long)H * HD, rs, Tn, Tpad, Ks, RSB);
+    stage(base + 2L * H * HD, rs, Tn, Tpad, Vs, RSB);
+    stage(dobase, os, Tn, Tpad, Os, RSB);
+    const float LOG2E = 1.4426950408889634f;
+    for (int i = threadIdx.x; i < Tpad; i += blockDim.x) {
+        float D = 0.f, L = 1e30f;  // padded queries: p = exp2(s - 1e30) = 0
+        if (i < Tn) {
+            L = lse[((long)b * H + h) * Tn + i] * LOG2E;
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                const bf16x8 a = *(const bf16x8*)(dobase + (long)i * os + 8 * cidx);
+                const bf16x8 o = *(const bf16x8*)(obase + (long)i * os + 8 * cidx);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) D = fmaf((float)a[j], (float)o[j], D);
+            }
+        }
+        Ls[i] = L;
+        Ds[i] = D;
+    }
+    __syncthreads();
+    const float c = scale * LOG2E;
+    const int nt = Tpad >> 5;
+    // ---------------- phase A: dQ, wave = query tile
+    for (int qt = wave; qt < nt; qt += 4) {
+        bf16x8 qf[2], dof[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { qf[s] = row_frag(Qs, qt * 32, s, lane); dof[s] = row_frag(Os, qt * 32, s, lane); }
+        const float L = Ls[qt * 32 + (lane & 31)], Dq = Ds[qt * 32 + (lane & 31)];
+        f32x16 dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+        for (int kt = 0; kt < nt; ++kt) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                st = mma(row_frag(Ks, kt * 32, s, lane), qf[s], st);
+                dp = mma(row_frag(Vs, kt * 32, s, lane), dof[s], dp);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c, -L));
+                st[r] = p * (dp[r] - Dq) * scale;  // dS^T (padded keys: K rows are zero, so their dQ contribution vanishes)
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dq = mma(tr_frag(Ks, RSB, kt * 32, s, lane), pack8(st, s), dq);
+        }
+        const int q = qt * 32 + (lane & 31);
+        if (q < Tn) store_tile_T(dbase + (long)q * rs, dq, 1.0f, lane);
+    }
+    // ---------------- phase B: dK, dV, wave = key tile
+    for (int kt = wave; kt < nt; kt += 4) {
+        bf16x8 kf[2], vf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { kf[s] = row_frag(Ks, kt * 32, s, lane); vf[s] = row_frag(Vs, kt * 32, s, lane); }
+        f32x16 dk, dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
+        for (int qt = 0; qt < nt; ++qt) {
+            f32x16 sm, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm[r] = dp[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                sm = mma(row_frag(Qs, qt * 32, s, lane), kf[s], sm);  // S[q][key]
+                dp = mma(row_frag(Os, qt * 32, s, lane), vf[s], dp);  // dP[q][key]
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int q0 = qt * 32 + 8 * g + 4 * (lane >> 5);
+                const float4 L4 = *(const float4*)(Ls + q0);
+                const float4 D4 = *(const float4*)(Ds + q0);
+                const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sm[4 * g + j], c, -Lr[j]));
+                    sm[4 * g + j] = p;
+                    dp[4 * g + j] = p * (dp[4 * g + j] - Dr[j]) * scale;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                dv = mma(tr_frag(Os, RSB, qt * 32, s, lane), pack8(sm, s), dv);
+                dk = mma(tr_frag(Qs, RSB, qt * 32, s, lane), pack8(dp, s), dk);
+            }
+        }
+        const int k = kt * 32 + (lane & 31);
+        if (k < Tn) {
+            store_tile_T(dbase + (long)k * rs + (long)H * HD, dk, 1.0f, lane);
+            store_tile_T(dbase + (long)k * rs + 2L * H * HD, dv, 1.0f, lane);
+        }
+    }
+}
+
+// column sums of a bf16 [M][N] matrix into f32 out[N] (atomicAdd); N % 8 == 0.  Used for d qkv.bias.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ x, long ld, float* __restrict__ out, int M, int N) {
+    const int r0 = blockIdx.x * 64, r1 = min(M, r0 + 64);
+    for (int cch = threadIdx.x; cch < N / 8; cch += 256) {
+        float a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const bf16x8 v = *(const bf16x8*)(x + (long)r * ld + 8 * cch);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(out + 8 * cch + j, a[j]);
+    }
+}
+
+}  // namespace
+
+bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward) {
+    if (dtype != MFVIT_BF16 || HDim != HD || Tn < 1) return false;
+    const int Tpad = (Tn + 31) & ~31;
+    const int bytes = backward ? 4 * Tpad * RSB + 2 * Tpad * 4 : Tpad * RSB + Tpad * 64;
+    return bytes <= 160 * 1024;
+}
+
+int attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
+    const int Tpad = (Tn + 31) & ~31;
+    const int bytes = Tpad * RSB + Tpad * 64;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (bf16*)out, lse, Tn, H,
+                       1.0f / sqrtf((float)HD));
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
+                  hipStream_t st) {
+    const int Tpad = (Tn + 31) & ~31;
+    const int bytes = 4 * Tpad * RSB + 2 * Tpad * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    {
+        ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
+                           lse, (bf16*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
+        MFVIT_CHECK_LAUNCH();
+    }
+    if (dbias) {
+        const int M = B * Tn, N = 3 * H * HD;
+        hipLaunchKernelGGL(colsum_bf16_kernel, dim3((M + 63) / 64), dim3(256), 0, st, (const bf16*)dqkv, (long)N, dbias, M, N);
+        MFVIT_CHECK_LAUNCH();
+    }
+    return MFVIT_OK;
+}
+
+}  // namespace mfvit

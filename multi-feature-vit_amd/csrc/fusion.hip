@@ -19,6 +19,7 @@
 // Direction 0: CXR cls attends ENH patches through [0], post-norm [3], head cxr   (FUS:57-63)
 // Direction 1: ENH cls attends CXR patches through [2], post-norm [1], head enh   (FUS:48-55)
 #include "kernels.h"
+#include "prof.h"
 
 #include <string.h>
 
@@ -486,6 +487,7 @@ int mfvit_fusion_forward(const mfvit_fusion_cfg* cfg, const float* params, const
         const size_t lds = (size_t)(5 * T + 4 * NH * D) * 4;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)x_stream_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        ProfScope ps(PROF_XATTN_FWD, 0, 2.0 * B * T * D * 4 * 2, st);
         hipLaunchKernelGGL(x_stream_fwd_kernel, dim3(B, 2), dim3(256), lds, st, f_cxr, f_enh, params, L, cfg->eps_pre, scale, B, T,
                            ws + W.kq, ws + W.u, ws + W.a, ws + W.st);
         MFVIT_CHECK_LAUNCH();
@@ -560,6 +562,7 @@ int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, cons
         const size_t lds = (size_t)(8 * T + 4 * 5 * D) * 4;
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)x_stream_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        ProfScope ps(PROF_XATTN_BWD, 0, 2.0 * B * T * D * 4 * 3, st);
         hipLaunchKernelGGL(x_stream_bwd_kernel, dim3(B, 2), dim3(256), lds, st, f_cxr, f_enh, params, L, scale, B, T, ws + W.kq, ws + W.a,
                            ws + W.st, ws + W.du, ws + W.dkq, ws + W.dz0p, dparams, df_cxr, df_enh);
         MFVIT_CHECK_LAUNCH();

@@ -11,6 +11,7 @@
 //                   operands K-strided -> transposing LDS reads.  replaces nn.Linear wgrad
 // Both element types: bf16 (v_mfma_f32_32x32x16_bf16) and f32 (v_mfma_f32_32x32x2_f32, exact f32).
 #include "kernels.h"
+#include "prof.h"
 
 namespace mfvit {
 
@@ -343,6 +344,7 @@ template <typename T, int EPI> static int launch_tile(const GemmP& p, hipStream_
         (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Loop::LDS_BYTES);
         attr_set = true;
     }
+    ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
     hipLaunchKernelGGL((gemm_nt_tile_kernel<T, EPI>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), Loop::LDS_BYTES, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -357,6 +359,7 @@ template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_
         (void)hipFuncSetAttribute((const void*)gemm_nt_row_kernel<T, REPI>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
+    ProfScope ps(REPI == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
     hipLaunchKernelGGL((gemm_nt_row_kernel<T, REPI>), dim3((p.M + ROW_BM - 1) / ROW_BM), dim3(256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -377,6 +380,7 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
+    ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
     hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(tiles, p.splits, p.nb > 1 ? p.nb : 1), dim3(256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;

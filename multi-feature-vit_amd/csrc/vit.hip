@@ -268,7 +268,7 @@ int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void*
             p.out0 = b + W.qkv; p.ldo0 = 3 * D;
             MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS, p, st));
         }
-        MFVIT_TRY(attn_fwd_exact(d.dtype, b + W.qkv, b + W.attn, (float*)(b + W.lse), d.B, d.T, d.H, d.HD, st));
+        MFVIT_TRY(attn_fwd(d.dtype, b + W.qkv, b + W.attn, (float*)(b + W.lse), d.B, d.T, d.H, d.HD, st));
         {   // xmid = x + attn Wproj^T + b ; y2 = LN2(xmid)
             GemmP p = zero_gemm();
             p.A = b + W.attn; p.lda = D;
@@ -403,7 +403,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.out0 = ws + W.dattn; p.ldo0 = D;
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, p, st));
             }
-            MFVIT_TRY(attn_bwd_exact(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), ws + W.dqkv, gb + L.qkv_b,
+            MFVIT_TRY(attn_bwd(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), ws + W.dqkv, gb + L.qkv_b,
                                      d.B, d.T, d.H, d.HD, st));
             {   // dWqkv += dqkv^T y1
                 GemmP p = zero_gemm();
@@ -490,12 +490,12 @@ int mfvit_linear_dgrad_ln_bwd(int dtype, const void* dy, int64_t lddy, const voi
 }
 int mfvit_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int head_dim, mfvit_stream_t stream) {
     if (!qkv || !out || !lse || B <= 0 || T <= 0 || H <= 0) return MFVIT_EINVAL;
-    return attn_fwd_exact(dtype, qkv, out, lse, B, T, H, head_dim, (hipStream_t)stream);
+    return attn_fwd(dtype, qkv, out, lse, B, T, H, head_dim, (hipStream_t)stream);
 }
 int mfvit_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias_qkv,
                         int B, int T, int H, int head_dim, mfvit_stream_t stream) {
     if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || T <= 0 || H <= 0) return MFVIT_EINVAL;
-    return attn_bwd_exact(dtype, qkv, out, dout, lse, dqkv, dbias_qkv, B, T, H, head_dim, (hipStream_t)stream);
+    return attn_bwd(dtype, qkv, out, dout, lse, dqkv, dbias_qkv, B, T, H, head_dim, (hipStream_t)stream);
 }
 int mfvit_layernorm_fwd(int dtype, const float* x, void* y, int y_f32, const float* gamma, const float* beta, float eps, float* mean,
                         float* rstd, int rows, int N, mfvit_stream_t stream) {

@@ -56,6 +56,9 @@ SIGNATURES = {
     "mfvit_fusion_param_count": (c_size_t, [POINTER(FusionCfg)]),
     "mfvit_fusion_workspace_bytes": (c_size_t, [POINTER(FusionCfg)]),
     "mfvit_fusion_forward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P, P, P, P]),
+    "mfvit_prof_enable": (I, [I]),
+    "mfvit_prof_collect": (I, [POINTER(ctypes.c_double), I]),
+    "mfvit_prof_class_name": (c_char_p, [I]),
     "mfvit_fusion_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
 }
 
