@@ -84,7 +84,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
  * Single ops (exposed for parity tests and for the MoCo projector / predictor path).
  * ------------------------------------------------------------------------------------------------------------ */
 /* y[M][N] = x[M][K] W[N][K]^T + bias   (nn.Linear forward; x, W, y of `dtype`; epilogue 0 bias, 1 bias+GELU(erf)
- * writing pre-activation to y and activation to y2, 3 none).  N % 128 == 0, K % 64 == 0. */
+ * writing gelu'(pre-activation) to y (what the backward needs) and the activation to y2, 3 none).  N % 128 == 0, K % 64 == 0. */
 int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                      int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream);
 /* dW[N][K] (f32, accumulated) += dy[M][N]^T x[M][K]   (nn.Linear weight gradient).  N % 128 == 0, K % 128 == 0. */

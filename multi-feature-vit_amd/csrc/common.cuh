@@ -34,6 +34,32 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// Fast erf-GELU for the bf16 path: Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, far below bf16's 2^-9), one v_exp_f32.
+// e = exp(-x^2/2) is shared between erf(x/sqrt2) and the normal pdf in the gradient.
+__device__ __forceinline__ void gelu_parts_fast(float x, float& cdf, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // exp(-x^2/2) = exp(-z^2)
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erf_abs = fmaf(-poly * t, e, 1.0f);
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float cdf, e;
+    gelu_parts_fast(x, cdf, e);
+    return x * cdf;
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float cdf, e;
+    gelu_parts_fast(x, cdf, e);
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x) { return sizeof(T) == 2 ? gelu_fast(x) : gelu_erf(x); }
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { return sizeof(T) == 2 ? gelu_grad_fast(x) : gelu_erf_grad(x); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -13,6 +13,8 @@
 #include "kernels.h"
 #include "prof.h"
 
+#include <stdlib.h>
+
 namespace mfvit {
 
 
@@ -32,43 +34,79 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
     f32x16 acc[Loop::TM][Loop::TN];
     Loop::run(p, m0, n0, lds, acc);
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- epilogue through LDS: per-element math in registers -> [128][128 + pad] tile in LDS -> 16-byte coalesced stores.
+    // Rows >= M replicate row M-1 exactly (the A loads are clamped), so they are stored as identical duplicates: no branches.
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    T* o0 = (T*)p.out0;
-    T* o1 = (T*)p.out1;
+    constexpr int PITCH = BN * (int)sizeof(T) + 16;
+    constexpr int CPRO = BN * (int)sizeof(T) / 16;      // 16-byte chunks per tile row
+    constexpr int NCHO = BM * CPRO / 256;
+    char* tile = lds;                                   // the staging buffers are free after the main loop's last barrier
+    auto elem = [&](int i, int j, int r) -> T* {
+        return (T*)(tile + ((wm * Loop::TM + i) * 32 + acc_row(r, lane)) * PITCH) + (wn * Loop::TN + j) * 32 + (lane & 31);
+    };
+    auto store_tile = [&](void* out, long ldo) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NCHO; ++i) {
+            const int q = tid + i * 256, row = q / CPRO, c = q % CPRO;
+            int m = m0 + row;
+            m = m < p.M ? m : p.M - 1;
+            *(uint4*)((char*)out + ((long)m * ldo + n0) * sizeof(T) + 16 * c) = *(const uint4*)(tile + row * PITCH + 16 * c);
+        }
+    };
+    if (EPI == EPI_GELU_BWD) {   // aux = gelu'(pre-activation) saved by the forward: load its tile with 16-byte reads
+#pragma unroll
+        for (int i = 0; i < NCHO; ++i) {
+            const int q = tid + i * 256, row = q / CPRO, c = q % CPRO;
+            int m = m0 + row;
+            m = m < p.M ? m : p.M - 1;
+            *(uint4*)(tile + row * PITCH + 16 * c) = *(const uint4*)((const char*)p.aux + ((long)m * p.ldaux + n0) * sizeof(T) + 16 * c);
+        }
+        __syncthreads();
+    }
+    float bj[Loop::TN];
 #pragma unroll
     for (int j = 0; j < Loop::TN; ++j) {
         const int n = n0 + (wn * Loop::TN + j) * 32 + (lane & 31);
-        float b = 0.f;
-        if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) b = p.bias ? p.bias[n] : 0.f;
+        bj[j] = ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.bias) ? p.bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < Loop::TN; ++j) {
         float csum = 0.f;
 #pragma unroll
-        for (int i = 0; i < Loop::TM; ++i) {
+        for (int i = 0; i < Loop::TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * Loop::TM + i) * 32 + acc_row(r, lane);
-                if (m >= p.M) continue;
-                float v = acc[i][j][r];
-                if (EPI == EPI_BIAS) {
-                    o0[(long)m * p.ldo0 + n] = from_f32<T>(v + b);
-                } else if (EPI == EPI_BIAS_GELU) {
-                    v += b;
-                    o0[(long)m * p.ldo0 + n] = from_f32<T>(v);            // pre-activation (saved for backward)
-                    o1[(long)m * p.ldo1 + n] = from_f32<T>(gelu_erf(v));  // activation
+                float v = acc[i][j][r] + bj[j];
+                T* e = elem(i, j, r);
+                if (EPI == EPI_BIAS_GELU) {
+                    acc[i][j][r] = v;                                   // kept for the second output
+                    *e = from_f32<T>(gelu_grad_t<T>(v));                // out0 = gelu'(pre): all the backward needs
                 } else if (EPI == EPI_GELU_BWD) {
-                    const float pre = to_f32(((const T*)p.aux)[(long)m * p.ldaux + n]);
-                    v *= gelu_erf_grad(pre);
-                    o0[(long)m * p.ldo0 + n] = from_f32<T>(v);
-                    csum += v;
+                    v *= to_f32(*e);
+                    *e = from_f32<T>(v);
+                    const bool ok = m0 + (wm * Loop::TM + i) * 32 + acc_row(r, lane) < p.M;
+                    csum += ok ? v : 0.f;
                 } else {
-                    o0[(long)m * p.ldo0 + n] = from_f32<T>(v);
+                    *e = from_f32<T>(v);
                 }
             }
-        }
         if (EPI == EPI_GELU_BWD && p.cs0) {
             csum += __shfl_xor(csum, 32, 64);
-            if (lane < 32) atomicAdd(p.cs0 + n, csum);
+            if (lane < 32) atomicAdd(p.cs0 + n0 + (wn * Loop::TN + j) * 32 + lane, csum);
         }
+    }
+    store_tile(p.out0, p.ldo0);
+    if (EPI == EPI_BIAS_GELU) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < Loop::TN; ++j)
+#pragma unroll
+            for (int i = 0; i < Loop::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *elem(i, j, r) = from_f32<T>(gelu_t<T>(acc[i][j][r]));
+        store_tile(p.out1, p.ldo1);
     }
 }
 
@@ -78,13 +116,13 @@ constexpr int ROW_BM = 64, ROW_BN = 384, ROW_BKB = 64, ROW_RS = 132;
 // Full-row totals of per-lane partials p[i][r] (row = i*32 + acc_row(r)), summed over the 32 column lanes of the
 // 4 waves, through LDS (red: [64][132] floats, tot: [64]).  Three barriers; all 256 threads must call it.
 template <int TM>
-__device__ __forceinline__ void row_reduce(float (&p)[TM][16], float* red, float* tot, int lane, int wave, int tid) {
+__device__ __forceinline__ void row_reduce(float (&p)[TM][16], float* red, float* tot, int lane, int wm, int wn, int tid) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(i * 32 + acc_row(r, lane)) * ROW_RS + wave * 32 + (lane & 31)] = p[i][r];
+        for (int r = 0; r < 16; ++r) red[((wm * TM + i) * 32 + acc_row(r, lane)) * ROW_RS + wn * 32 + (lane & 31)] = p[i][r];
     __syncthreads();
-    {
+    if (tid < 256) {
         const int row = tid >> 2, q = tid & 3;
         float s = 0.f;
 #pragma unroll
@@ -100,27 +138,28 @@ __device__ __forceinline__ void row_reduce(float (&p)[TM][16], float* red, float
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[i][r] = tot[i * 32 + acc_row(r, lane)];
+        for (int r = 0; r < 16; ++r) p[i][r] = tot[(wm * TM + i) * 32 + acc_row(r, lane)];
     __syncthreads();
 }
 
-template <typename T, int REPI>
-__global__ __launch_bounds__(256) void gemm_nt_row_kernel(GemmP p) {
-    constexpr int BM = ROW_BM, BN = ROW_BN, WM = 1, WN = 4;
-    typedef NtLoop<T, BM, BN, ROW_BKB, WM, WN> Loop;
-    constexpr int TM = Loop::TM, TN = Loop::TN;  // 2 x 3
+template <typename T, int REPI, int WM, int BKB>
+__global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
+    constexpr int BM = ROW_BM, BN = ROW_BN, WN = 4;
+    typedef NtLoop<T, BM, BN, BKB, WM, WN> Loop;
+    constexpr int TM = Loop::TM, TN = Loop::TN;  // (2 | 1) x 3
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int m0 = blockIdx.x * BM;
     f32x16 acc[TM][TN];
     Loop::run(p, m0, 0, lds, acc);  // ends with a barrier: the staging LDS is free from here on
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
     float* red = (float*)lds;
     float* tot = red + BM * ROW_RS;
     const float invN = 1.0f / (float)BN;
     int ncol[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) ncol[j] = (wave * TN + j) * 32 + (lane & 31);
+    for (int j = 0; j < TN; ++j) ncol[j] = (wn * TN + j) * 32 + (lane & 31);
 
     if (REPI == REPI_RES_LN) {
         float bj[TN], gj[TN], btj[TN];
@@ -135,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_nt_row_kernel(GemmP p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + i * 32 + acc_row(r, lane);
+                const int m = m0 + (wm * TM + i) * 32 + acc_row(r, lane);
                 const bool ok = m < p.M;
                 const int mm = ok ? m : p.M - 1;
                 const int orow = out_row(p, mm);
@@ -146,12 +185,12 @@ __global__ __launch_bounds__(256) void gemm_nt_row_kernel(GemmP p) {
                     float v = acc[i][j][r] + bj[j];
                     if (p.res) v += p.res[rrow * p.ldres + ncol[j]];
                     acc[i][j][r] = v;
-                    if (ok && p.out0) ((float*)p.out0)[(long)orow * p.ldo0 + ncol[j]] = v;
+                    if (p.out0) ((float*)p.out0)[(long)orow * p.ldo0 + ncol[j]] = v;
                     s += v;
                 }
                 part[i][r] = s;
             }
-        row_reduce<TM>(part, red, tot, lane, wave, tid);
+        row_reduce<TM>(part, red, tot, lane, wm, wn, tid);
         float mu[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -166,16 +205,16 @@ __global__ __launch_bounds__(256) void gemm_nt_row_kernel(GemmP p) {
                 }
                 part[i][r] = s;
             }
-        row_reduce<TM>(part, red, tot, lane, wave, tid);
+        row_reduce<TM>(part, red, tot, lane, wm, wn, tid);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + i * 32 + acc_row(r, lane);
-                if (m >= p.M) continue;
+                const int mraw = m0 + (wm * TM + i) * 32 + acc_row(r, lane);
+                const int m = mraw < p.M ? mraw : p.M - 1;   // duplicates of row M-1 store identical values
                 const int orow = out_row(p, m);
                 const float rs = rsqrtf(part[i][r] * invN + p.eps);
-                if (wave == 0 && (lane & 31) == 0 && p.mean) {
+                if (wn == 0 && (lane & 31) == 0 && p.mean) {
                     p.mean[orow] = mu[i][r];
                     p.rstd[orow] = rs;
                 }
@@ -201,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_nt_row_kernel(GemmP p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + i * 32 + acc_row(r, lane);
+                const int m = m0 + (wm * TM + i) * 32 + acc_row(r, lane);
                 const bool ok = m < p.M;
                 const int mm = ok ? m : p.M - 1;
                 const float mu = p.mean[mm], rs = p.rstd[mm];
@@ -211,26 +250,26 @@ __global__ __launch_bounds__(256) void gemm_nt_row_kernel(GemmP p) {
                 for (int j = 0; j < TN; ++j) {
                     const float x = ((const float*)p.aux)[(long)mm * p.ldaux + ncol[j]];
                     const float h = (x - mu) * rs;
-                    const float dy = ok ? acc[i][j][r] : 0.f;
-                    acc[i][j][r] = dy;
+                    const float dy = acc[i][j][r];      // padded rows replicate row M-1; only the column sums mask them
                     xh[i][j][r] = h;
                     const float g = dy * gj[j];
                     s1 += g;
                     s2 += g * h;
-                    cs_g[j] += dy * h;
-                    cs_b[j] += dy;
+                    cs_g[j] += ok ? dy * h : 0.f;
+                    cs_b[j] += ok ? dy : 0.f;
                 }
                 p1[i][r] = s1;
                 p2[i][r] = s2;
             }
-        row_reduce<TM>(p1, red, tot, lane, wave, tid);
-        row_reduce<TM>(p2, red, tot, lane, wave, tid);
+        row_reduce<TM>(p1, red, tot, lane, wm, wn, tid);
+        row_reduce<TM>(p2, red, tot, lane, wm, wn, tid);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + i * 32 + acc_row(r, lane);
-                if (m >= p.M) continue;
+                const int mraw = m0 + (wm * TM + i) * 32 + acc_row(r, lane);
+                const bool ok = mraw < p.M;
+                const int m = ok ? mraw : p.M - 1;
                 const float c1 = p1[i][r] * invN, c2 = p2[i][r] * invN, rs = rsv[i][r];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -238,7 +277,7 @@ __global__ __launch_bounds__(256) void gemm_nt_row_kernel(GemmP p) {
                     if (p.res) dx += p.res[(long)m * p.ldres + ncol[j]];
                     ((float*)p.out0)[(long)m * p.ldo0 + ncol[j]] = dx;
                     if (p.out1) ((T*)p.out1)[(long)m * p.ldo1 + ncol[j]] = from_f32<T>(dx);
-                    cs_x[j] += dx;
+                    cs_x[j] += ok ? dx : 0.f;
                 }
             }
 #pragma unroll
@@ -261,7 +300,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     // out0[n][k] (f32, atomicAdd) += sum_{m in split} A[m][n] * W[m][k];  p.N = n extent, p.K = k extent, p.M = reduction
     constexpr int BN = 128, BK2 = 128, NT = 256;
-    constexpr int KR = 64 / (int)sizeof(T);  // 32 bf16 / 16 f32 reduction rows per stage
+    constexpr int KR = 128 / (int)sizeof(T);  // 64 bf16 / 32 f32 reduction rows per stage (16 MFMAs per wave per barrier)
     typedef STile<T, BN, KR> TA;
     typedef STile<T, BK2, KR> TB;
     constexpr int STAGE = TA::BYTES + TB::BYTES;
@@ -287,6 +326,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // optional column sums of A (= bias gradient): one extra MFMA per A fragment against an all-ones B fragment,
+    // done by the k-tile-0 / wn-0 waves only (every output column of that product equals sum_m A[m][n])
+    const bool do_cs = p.cs0 != nullptr && k0 == 0 && wn == 0;
+    f32x16 bacc[2];
+    typename MmaTraits<T>::frag_t ones;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    } else {
+        ones = 1.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
     const int nst = (mend - mbeg + KR - 1) / KR;
     sa.load(A, p.lda, mbeg, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
     sb.load(X, p.ldw, mbeg, mend, k0, tid);
@@ -312,6 +366,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<T>::mma(a[i], b[j], acc[i][j]);
+            if (do_cs) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) bacc[i] = MmaTraits<T>::mma(a[i], ones, bacc[i]);
+            }
         }
         if (st + 1 < nst) {
             char* na = lds + (cur ^ 1) * STAGE;
@@ -332,6 +390,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
                 const int k = k0 + (wn * 2 + j) * 32 + (lane & 31);
                 atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
             }
+    if (do_cs && (lane & 31) == 0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + n0 + (wm * 2 + i) * 32 + acc_row(r, lane), bacc[i][r]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------- launchers
@@ -339,37 +403,50 @@ template <typename T, int EPI> static int launch_tile(const GemmP& p, hipStream_
     typedef NtLoop<T, 128, 128, 128, 2, 2> Loop;
     if (p.N % 128 || p.K % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
     const int nwg = (p.N / 128) * ((p.M + 127) / 128);
+    constexpr int epi_bytes = 128 * (128 * (int)sizeof(T) + 16);
+    constexpr int lds_bytes = Loop::LDS_BYTES > epi_bytes ? Loop::LDS_BYTES : epi_bytes;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, Loop::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
     ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
-    hipLaunchKernelGGL((gemm_nt_tile_kernel<T, EPI>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), Loop::LDS_BYTES, st, p);
+    hipLaunchKernelGGL((gemm_nt_tile_kernel<T, EPI>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), lds_bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
-template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_t st) {
-    typedef NtLoop<T, ROW_BM, ROW_BN, ROW_BKB, 1, 4> Loop;
+static int row_variant() {   // MFVIT_ROW_VARIANT: 0 = 4 waves (1x4), BK 64 B rows | 1 = 4 waves, 128 B rows | 2 = 8 waves (2x4), 128 B rows
+    static const int v = [] { const char* e = getenv("MFVIT_ROW_VARIANT"); return e ? atoi(e) : 2; }();
+    return v;
+}
+template <typename T, int REPI, int WM, int BKB> static int launch_row_v(const GemmP& p, hipStream_t st) {
+    typedef NtLoop<T, ROW_BM, ROW_BN, BKB, WM, 4> Loop;
     if (p.N != ROW_BN || p.K % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
     constexpr int need = ROW_BM * ROW_RS * 4 + ROW_BM * 4;
     constexpr int bytes = Loop::LDS_BYTES > need ? Loop::LDS_BYTES : need;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_row_kernel<T, REPI>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_row_kernel<T, REPI, WM, BKB>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
     ProfScope ps(REPI == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
-    hipLaunchKernelGGL((gemm_nt_row_kernel<T, REPI>), dim3((p.M + ROW_BM - 1) / ROW_BM), dim3(256), bytes, st, p);
+    hipLaunchKernelGGL((gemm_nt_row_kernel<T, REPI, WM, BKB>), dim3((p.M + ROW_BM - 1) / ROW_BM), dim3(WM * 256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
+template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_t st) {
+    const int v = row_variant();
+    if (v == 0 || p.K % (128 / (int)sizeof(T))) return launch_row_v<T, REPI, 1, 64>(p, st);
+    if (v == 1) return launch_row_v<T, REPI, 1, 128>(p, st);
+    return launch_row_v<T, REPI, 2, 128>(p, st);
+}
 template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
     if (p.N % 128 || p.K % 128 || p.M <= 0) return MFVIT_EINVAL;
-    constexpr int KR = 64 / (int)sizeof(T);
+    constexpr int KR = 128 / (int)sizeof(T);
     const int tiles = (p.N / 128) * (p.K / 128);
     if (p.splits <= 0) {
-        int s = (1024 + tiles - 1) / tiles;              // aim at ~4 blocks per CU
+        static const int target = [] { const char* e = getenv("MFVIT_TN_TARGET"); return e ? atoi(e) : 384; }();
+        int s = (target + tiles - 1) / tiles;            // aim at `target` blocks on the chip
         const int maxs = (p.M + 4 * KR - 1) / (4 * KR);  // at least 4 stages per split
         p.splits = s < 1 ? 1 : (s > maxs ? maxs : s);
         if (p.splits < 1) p.splits = 1;

@@ -403,12 +403,13 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.out0 = ws + W.dattn; p.ldo0 = D;
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, p, st));
             }
-            MFVIT_TRY(attn_bwd(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), ws + W.dqkv, gb + L.qkv_b,
+            MFVIT_TRY(attn_bwd(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), ws + W.dqkv, nullptr,
                                      d.B, d.T, d.H, d.HD, st));
-            {   // dWqkv += dqkv^T y1
+            {   // dWqkv += dqkv^T y1 ; d qkv_b += column sums of dqkv (ones-fragment MFMA inside the wgrad kernel)
                 GemmP p = zero_gemm();
                 p.A = ws + W.dqkv; p.lda = 3 * D; p.W = b + W.y1; p.ldw = D;
                 p.M = d.M; p.N = 3 * d.D; p.K = d.D;
+                p.cs0 = gb + L.qkv_b;
                 p.out0 = gb + L.qkv_w; p.ldo0 = D;
                 MFVIT_TRY(gemm_tn(d.dtype, p, st));
             }

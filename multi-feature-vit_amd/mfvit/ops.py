@@ -22,7 +22,7 @@ def _code_of(t):
 
 
 def linear_fwd(x, w, bias=None, gelu=False):
-    """y = x @ w.T + bias (x [M,K], w [N,K] of the same dtype).  gelu=True returns (pre, act)."""
+    """y = x @ w.T + bias (x [M,K], w [N,K] of the same dtype).  gelu=True returns (gelu'(y), gelu(y))."""
     require_cuda(x, w, bias)
     code = _code_of(x)
     M, K = x.shape
