@@ -9,6 +9,8 @@ methods are stored, the modules arrive as forward arguments), so ``parameters()`
 22 fusion tensors; each backbone's two per-step evaluations on the same image are computed once (Q2); only the cls
 row of the post-exchange LayerNorm / residual is consumed (Q3).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -62,6 +64,8 @@ class Fus_CrossViT(nn.Module):
         self.mlp_head_enh = nn.Sequential(nn.Linear(large_dim, num_classes))
         self.apply(self._init_weights)
         self._arena = ParamArena(list(self.named_parameters()))
+        self._two_streams = os.environ.get("MFVIT_TWO_STREAMS", "1") == "1"
+        self._side = None
 
     @staticmethod
     def _init_weights(m):  # FUS:117-124
@@ -90,8 +94,22 @@ class Fus_CrossViT(nn.Module):
         return None
 
     def forward(self, vit_cxr, vit_enh, img_cxr, img_enh):
-        cxr_ftrs = self.vit_features_cxr(img_cxr)      # (B, 197, 384)   FUS:128
-        enh_ftrs = self.vit_features_enh(img_enh)      #                 FUS:133
+        if self._two_streams and img_enh is not None and img_enh.is_cuda:
+            # the two encoders are independent: run the ENH stream's ~100 kernels on a second HIP stream so that its
+            # MFMA phases overlap the CXR stream's HBM-bound epilogues (and vice versa); autograd replays each
+            # encoder's backward on the stream its forward ran on, so the overlap holds for the backward too
+            main = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                enh_ftrs = self.vit_features_enh(img_enh)  #             FUS:133
+            cxr_ftrs = self.vit_features_cxr(img_cxr)      # (B, 197, 384) FUS:128
+            main.wait_stream(self._side)
+            enh_ftrs.record_stream(main)
+        else:
+            cxr_ftrs = self.vit_features_cxr(img_cxr)      # (B, 197, 384)   FUS:128
+            enh_ftrs = self.vit_features_enh(img_enh)      #                 FUS:133
         hc, he = self._plain_head(vit_cxr), self._plain_head(vit_enh)
         fused_heads = hc is not None and he is not None and hc.out_features == self.num_classes == he.out_features \
             and getattr(vit_cxr, "features3D", None) == self.vit_features_cxr \
