@@ -166,6 +166,53 @@ int mfvit_prof_enable(int class_mask); /* bit c set = time class c; 0 = off */
 int mfvit_prof_collect(double* out, int ncls);
 const char* mfvit_prof_class_name(int cls);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * MoCo step pieces (BLD = moco/builder_vit_mocov3structure_mocov2loss.py).  The Linear layers of the projector /
+ * predictor run on mfvit_linear_fwd / mfvit_linear_wgrad.
+ * ------------------------------------------------------------------------------------------------------------ */
+/* BatchNorm1d over the batch axis of x[n][C] (BLD:62-78; SyncBatchNorm semantics, MAIN_MOCO:297):
+ *   mfvit_bn_stats   : rank-local per-column mean and M2 = sum (x - mean)^2
+ *   mfvit_bn_combine : merge W (mean, M2, count) triples (all_gathered by the host) -> global mean, invstd; updates the
+ *                      running statistics (momentum, unbiased variance) when given
+ *   mfvit_bn_apply   : y = (x - mean) * invstd [* gamma + beta] [-> ReLU]   (gamma == NULL: affine=False) */
+int mfvit_bn_stats(int dtype, const void* x, int n, int C, float* mean, float* m2, mfvit_stream_t stream);
+int mfvit_bn_combine(const float* means, const float* m2s, const float* counts, int W, int C, float eps, float momentum, float* mean,
+                     float* invstd, float* running_mean, float* running_var, mfvit_stream_t stream);
+int mfvit_bn_apply(int dtype, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                   void* y, int n, int C, mfvit_stream_t stream);
+/* backward: s1 = sum dy', s2 = sum dy' * xhat per column (dy' = dy masked by the fused ReLU via y); after the host has
+ * summed s1, s2 over ranks: dx = gamma * invstd * (dy' - S1 * inv_count - xhat * S2 * inv_count).  dgamma = local s2, dbeta = local s1. */
+int mfvit_bn_bwd_sums(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd, int relu, int n,
+                      int C, float* s1, float* s2, mfvit_stream_t stream);
+int mfvit_bn_bwd_apply(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd, const float* gamma,
+                       int relu, const float* S1, const float* S2, float inv_count, void* dx, int n, int C, mfvit_stream_t stream);
+/* F.normalize(x, dim=1) (BLD:165,175) and its backward (f32). */
+int mfvit_l2norm_fwd(const float* x, float* y, float* inv_norm, int n, int C, float eps, mfvit_stream_t stream);
+int mfvit_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int n, int C, mfvit_stream_t stream);
+/* out[r * ldo] = scale * (a[r] . b[r])   (l_pos, BLD:183). */
+int mfvit_rowdot(const float* a, const float* b, float* out, int64_t ldo, float scale, int n, int C, mfvit_stream_t stream);
+/* nn.CrossEntropyLoss (mean) over wide rows, e.g. the (n, 1 + 65536) InfoNCE logits (MAIN_MOCO:330,535):
+ * loss_mean[1]; optional per-row lse; optional dlogits = (softmax - onehot) / n. */
+int mfvit_cross_entropy_rows(const float* logits, int64_t ld, const int64_t* target, float* loss_mean, float* lse, float* dlogits,
+                             int64_t ldd, int n, int C, mfvit_stream_t stream);
+/* momentum update over a flat arena: dst = dst * m + src * (1 - m)   (BLD:83-89, one launch instead of ~157 x 3). */
+int mfvit_ema_update(float* dst, const float* src, float m, int64_t n, mfvit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-tensor optimizer steps.  `table` is a DEVICE array of int64[nchunks][7]:
+ *   [tensor_id, param_ptr, grad_ptr, state0_ptr, state1_ptr, count, flag]   (pointers to the chunk's first float)
+ * LARS (OPT:10-43): flag = 1 for tensors with ndim > 1 (weight decay + trust ratio), 0 otherwise; state0 = mu;
+ *   `norms` = device scratch float[2 * ntensors].
+ * Adam / AdamW (torch.optim semantics; MAIN_CA:455-459, MAIN_MOCO:338-345): state0 = exp_avg, state1 = exp_avg_sq,
+ *   flag bit 0 = decoupled weight decay (AdamW); `step` counts from 1.
+ * SGD (MAIN_CA:445-448): state0 = momentum buffer; first_step = 1 initialises the buffer with the gradient. */
+int mfvit_lars_step(const int64_t* table, int nchunks, int ntensors, float* norms, float lr, float weight_decay, float momentum,
+                    float trust_coefficient, mfvit_stream_t stream);
+int mfvit_adam_step(const int64_t* table, int nchunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    mfvit_stream_t stream);
+int mfvit_sgd_step(const int64_t* table, int nchunks, float lr, float momentum, float weight_decay, int first_step,
+                   mfvit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

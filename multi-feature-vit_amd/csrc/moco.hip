@@ -1,0 +1,272 @@
+// MoCo (v3 structure, v2 queue loss) step kernels for gfx950: BatchNorm1d of the projector / predictor MLPs (local
+// statistics -> cross-rank combine -> apply, and the backward), L2 row normalisation, positive logits, row-wise
+// cross entropy over the (1 + K)-wide InfoNCE logits, momentum (EMA) update over flat arenas.
+//
+// Reference (relative to /root/reference/moco_pretraining/moco/moco/builder_vit_mocov3structure_mocov2loss.py):
+//   :62-78   _build_mlp: Linear(no bias) -> BatchNorm1d -> ReLU ... last BatchNorm1d(affine=False)   (SyncBN: MAIN_MOCO:297)
+//   :83-89   momentum update  p_k = p_k * m + p_q * (1 - m)
+//   :165,175 F.normalize(dim=1)     :183 l_pos = einsum('nc,nc->n')     MAIN_MOCO:330,535  CrossEntropyLoss over (n, 1+K)
+// All of these are HBM / latency bound (n x 4096 activations, 64 MiB queue, 43 M parameter floats); the Linear layers
+// themselves run on the MFMA GEMM kernels (gemm.hip).
+#include "kernels.h"
+
+namespace mfvit {
+
+// ----------------------------------------------------------------------------------------------- BatchNorm1d
+// local per-column mean and M2 = sum (x - mean_local)^2 over the n local rows; thread = column (coalesced rows)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int n, int C, float* __restrict__ mean,
+                                                       float* __restrict__ m2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < n; ++r) s += to_f32(x[(long)r * C + c]);
+    const float mu = s / (float)n;
+    float q = 0.f;
+    for (int r = 0; r < n; ++r) { const float d = to_f32(x[(long)r * C + c]) - mu; q = fmaf(d, d, q); }
+    mean[c] = mu;
+    m2[c] = q;
+}
+// Chan's parallel combine of W rank-local (mean, M2, count) triples -> global mean, invstd; running-stat update.
+__global__ __launch_bounds__(256) void bn_combine_kernel(const float* __restrict__ means, const float* __restrict__ m2s,
+                                                         const float* __restrict__ counts, int W, int C, float eps, float momentum,
+                                                         float* __restrict__ mean, float* __restrict__ invstd,
+                                                         float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float N = 0.f, mu = 0.f, M2 = 0.f;
+    for (int w = 0; w < W; ++w) {
+        const float nb = counts[w], mb = means[(long)w * C + c], qb = m2s[(long)w * C + c];
+        const float Nn = N + nb, d = mb - mu;
+        mu += d * nb / Nn;
+        M2 += qb + d * d * N * nb / Nn;
+        N = Nn;
+    }
+    const float var = M2 / N;
+    mean[c] = mu;
+    invstd[c] = rsqrtf(var + eps);
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (N > 1.f ? M2 / (N - 1.f) : var);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int relu, T* __restrict__ y, long total, int C) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    float v = (to_f32(x[i]) - mean[c]) * invstd[c];
+    if (gamma) v = fmaf(v, gamma[c], beta[c]);
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = from_f32<T>(v);
+}
+// backward pass 1: per-column sums of dy' and dy' * xhat (dy' = dy masked by the fused ReLU)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_sums_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                          int n, int C, float* __restrict__ s1, float* __restrict__ s2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mu = mean[c], is = invstd[c];
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < n; ++r) {
+        const long i = (long)r * C + c;
+        float g = to_f32(dy[i]);
+        if (relu && !(to_f32(y[i]) > 0.f)) g = 0.f;
+        a += g;
+        b = fmaf(g, (to_f32(x[i]) - mu) * is, b);
+    }
+    s1[c] = a;
+    s2[c] = b;
+}
+// backward pass 2: dx = gamma * invstd * (dy' - S1/N - xhat * S2/N) with the GLOBAL sums S1, S2 and count N
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, int relu, const float* __restrict__ S1,
+                                                           const float* __restrict__ S2, float invN, T* __restrict__ dx, long total,
+                                                           int C) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    float g = to_f32(dy[i]);
+    if (relu && !(to_f32(y[i]) > 0.f)) g = 0.f;
+    const float is = invstd[c], xh = (to_f32(x[i]) - mean[c]) * is;
+    const float w = gamma ? gamma[c] : 1.f;
+    dx[i] = from_f32<T>(w * is * (g - S1[c] * invN - xh * S2[c] * invN));
+}
+
+// ----------------------------------------------------------------------------------------------- row ops (wave per row)
+// y = x / max(||x||, eps)   (F.normalize, dim=1);  also returns 1/norm for the backward
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv,
+                                                         int n, int C, float eps) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = x[(long)r * C + c]; s = fmaf(v, v, s); }
+    const float iv = 1.f / fmaxf(sqrtf(wave_sum(s)), eps);
+    for (int c = lane; c < C; c += 64) y[(long)r * C + c] = x[(long)r * C + c] * iv;
+    if (lane == 0) inv[r] = iv;
+}
+// dx = (dy - y (y . dy)) / norm
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ inv, float* __restrict__ dx, int n, int C) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(dy[(long)r * C + c], y[(long)r * C + c], s);
+    s = wave_sum(s);
+    const float iv = inv[r];
+    for (int c = lane; c < C; c += 64) dx[(long)r * C + c] = (dy[(long)r * C + c] - y[(long)r * C + c] * s) * iv;
+}
+// out[r * ldo] = scale * (a[r] . b[r])      (l_pos, written straight into column 0 of the logits)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                     long ldo, float scale, int n, int C) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(a[(long)r * C + c], b[(long)r * C + c], s);
+    s = wave_sum(s);
+    if (lane == 0) out[(long)r * ldo] = s * scale;
+}
+
+// ----------------------------------------------------------------------------------------------- cross entropy over wide rows
+// One block per row: online (max, sum-exp) in one pass, then dlogits = (softmax - onehot) * gscale in a second.
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ target,
+                                                      float* __restrict__ loss_sum, float* __restrict__ lse_out,
+                                                      float* __restrict__ dlogits, long ldd, float gscale, int C) {
+    __shared__ float sm[4], ss[4];
+    const int r = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* z = logits + (long)r * ld;
+    float m = -INFINITY, s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float v = z[c];
+        if (v > m) { s *= __expf(m - v); m = v; }
+        s += __expf(v - m);
+    }
+    const float wm = wave_max(m);
+    s = wave_sum(s * __expf(m - wm));
+    if (lane == 0) { sm[w] = wm; ss[w] = s; }
+    __syncthreads();
+    const float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    const float S = ss[0] * __expf(sm[0] - M) + ss[1] * __expf(sm[1] - M) + ss[2] * __expf(sm[2] - M) + ss[3] * __expf(sm[3] - M);
+    const float lse = M + __logf(S);
+    const int t = (int)target[r];
+    if (threadIdx.x == 0) {
+        atomicAdd(loss_sum, (lse - z[t]) * gscale);
+        if (lse_out) lse_out[r] = lse;
+    }
+    if (dlogits) {
+        float* d = dlogits + (long)r * ldd;
+        for (int c = threadIdx.x; c < C; c += 256) d[c] = (__expf(z[c] - lse) - (c == t ? 1.f : 0.f)) * gscale;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- EMA over a flat arena
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ dst, const float* __restrict__ src, float m, long n4, long n) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i < n4) {
+        float4 d = ((float4*)dst)[i];
+        const float4 s = ((const float4*)src)[i];
+        const float om = 1.f - m;
+        d.x = d.x * m + s.x * om; d.y = d.y * m + s.y * om; d.z = d.z * m + s.z * om; d.w = d.w * m + s.w * om;
+        ((float4*)dst)[i] = d;
+    } else {
+        const long j = n4 * 4 + (i - n4);
+        if (j < n) dst[j] = dst[j] * m + src[j] * (1.f - m);
+    }
+}
+
+}  // namespace mfvit
+
+using namespace mfvit;
+
+extern "C" {
+
+int mfvit_bn_stats(int dtype, const void* x, int n, int C, float* mean, float* m2, mfvit_stream_t stream) {
+    if (!x || !mean || !m2 || n <= 0 || C <= 0) return MFVIT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFVIT_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16>, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16*)x, n, C, mean, m2);
+    else hipLaunchKernelGGL(bn_stats_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)x, n, C, mean, m2);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int mfvit_bn_combine(const float* means, const float* m2s, const float* counts, int W, int C, float eps, float momentum, float* mean,
+                     float* invstd, float* running_mean, float* running_var, mfvit_stream_t stream) {
+    if (!means || !m2s || !counts || !mean || !invstd || W <= 0) return MFVIT_EINVAL;
+    hipLaunchKernelGGL(bn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, means, m2s, counts, W, C, eps, momentum,
+                       mean, invstd, running_mean, running_var);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int mfvit_bn_apply(int dtype, const void* x, const float* mean, const float* invstd, const float* gamma, const float* beta, int relu,
+                   void* y, int n, int C, mfvit_stream_t stream) {
+    if (!x || !mean || !invstd || !y) return MFVIT_EINVAL;
+    const long total = (long)n * C;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFVIT_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, mean, invstd, gamma, beta, relu, (bf16*)y, total, C);
+    else hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, mean, invstd, gamma, beta, relu, (float*)y, total, C);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int mfvit_bn_bwd_sums(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd, int relu, int n,
+                      int C, float* s1, float* s2, mfvit_stream_t stream) {
+    if (!dy || !x || !mean || !invstd || !s1 || !s2 || (relu && !y)) return MFVIT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFVIT_BF16) hipLaunchKernelGGL(bn_bwd_sums_kernel<bf16>, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, relu, n, C, s1, s2);
+    else hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, relu, n, C, s1, s2);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int mfvit_bn_bwd_apply(int dtype, const void* dy, const void* x, const void* y, const float* mean, const float* invstd, const float* gamma,
+                       int relu, const float* S1, const float* S2, float inv_count, void* dx, int n, int C, mfvit_stream_t stream) {
+    if (!dy || !x || !mean || !invstd || !S1 || !S2 || !dx || (relu && !y)) return MFVIT_EINVAL;
+    const long total = (long)n * C;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MFVIT_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, gamma, relu, S1, S2, inv_count, (bf16*)dx, total, C);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, gamma, relu, S1, S2, inv_count, (float*)dx, total, C);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int mfvit_l2norm_fwd(const float* x, float* y, float* inv_norm, int n, int C, float eps, mfvit_stream_t stream) {
+    if (!x || !y || !inv_norm) return MFVIT_EINVAL;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, inv_norm, n, C, eps);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int mfvit_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int n, int C, mfvit_stream_t stream) {
+    if (!dy || !y || !inv_norm || !dx) return MFVIT_EINVAL;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, inv_norm, dx, n, C);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int mfvit_rowdot(const float* a, const float* b, float* out, int64_t ldo, float scale, int n, int C, mfvit_stream_t stream) {
+    if (!a || !b || !out) return MFVIT_EINVAL;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)ldo, scale, n, C);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int mfvit_cross_entropy_rows(const float* logits, int64_t ld, const int64_t* target, float* loss_mean, float* lse, float* dlogits,
+                             int64_t ldd, int n, int C, mfvit_stream_t stream) {
+    if (!logits || !target || !loss_mean || n <= 0 || C <= 0) return MFVIT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(loss_mean, 0, sizeof(float), st) != hipSuccess) return MFVIT_ELAUNCH;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(n), dim3(256), 0, st, logits, (long)ld, (const long*)target, loss_mean, lse, dlogits, (long)ldd,
+                       1.0f / (float)n, C);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int mfvit_ema_update(float* dst, const float* src, float m, int64_t n, mfvit_stream_t stream) {
+    if (!dst || !src || n <= 0) return MFVIT_EINVAL;
+    const long n4 = ((uintptr_t)dst % 16 == 0 && (uintptr_t)src % 16 == 0) ? n / 4 : 0;
+    const long threads = n4 + (n - n4 * 4);
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, m, n4, (long)n);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
+}  // extern "C"

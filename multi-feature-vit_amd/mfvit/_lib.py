@@ -56,6 +56,19 @@ SIGNATURES = {
     "mfvit_fusion_param_count": (c_size_t, [POINTER(FusionCfg)]),
     "mfvit_fusion_workspace_bytes": (c_size_t, [POINTER(FusionCfg)]),
     "mfvit_fusion_forward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P, P, P, P]),
+    "mfvit_bn_stats": (I, [I, P, I, I, P, P, P]),
+    "mfvit_bn_combine": (I, [P, P, P, I, I, F, F, P, P, P, P, P]),
+    "mfvit_bn_apply": (I, [I, P, P, P, P, P, I, P, I, I, P]),
+    "mfvit_bn_bwd_sums": (I, [I, P, P, P, P, P, I, I, I, P, P, P]),
+    "mfvit_bn_bwd_apply": (I, [I, P, P, P, P, P, P, I, P, P, F, P, I, I, P]),
+    "mfvit_l2norm_fwd": (I, [P, P, P, I, I, F, P]),
+    "mfvit_l2norm_bwd": (I, [P, P, P, P, I, I, P]),
+    "mfvit_rowdot": (I, [P, P, P, L, F, I, I, P]),
+    "mfvit_cross_entropy_rows": (I, [P, L, P, P, P, P, L, I, I, P]),
+    "mfvit_ema_update": (I, [P, P, F, L, P]),
+    "mfvit_lars_step": (I, [P, I, I, P, F, F, F, F, P]),
+    "mfvit_adam_step": (I, [P, I, F, F, F, F, F, I, P]),
+    "mfvit_sgd_step": (I, [P, I, F, F, F, I, P]),
     "mfvit_prof_enable": (I, [I]),
     "mfvit_prof_collect": (I, [POINTER(ctypes.c_double), I]),
     "mfvit_prof_class_name": (c_char_p, [I]),

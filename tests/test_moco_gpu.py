@@ -1,0 +1,205 @@
+"""GPU parity of the MoCo step pieces (drop-in builder + HIP kernels) against
+  (a) reference-generated golden vectors (tests/golden/moco_pieces.npz, lars.npz): projector / predictor MLPs with
+      train-mode BatchNorm (forward, gradients, running statistics), EMA, enqueue with pointer wrap, LARS trajectory;
+  (b) the CPU oracle (oracle/ref_moco.py) for the whole forward -> InfoNCE logits -> CE -> backward.
+All in precision='fp32' (exact-f32 MFMA); tolerances 1e-3 relative (north_star), measured values logged."""
+import os
+import types
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, check_sampled, rng_tensor
+from oracle import ref_moco, ref_vit
+
+pytestmark = pytest.mark.gpu
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_moco.txt")
+DEV = "cuda:0"
+
+
+def log(msg):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(msg + "\n")
+
+
+def scale_err(got, ref, floor=1e-30):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(floor))
+
+
+def make_moco(depth=1, mlp_dim=512, dim=256, T=0.2, precision="fp32", **kw):
+    import vits
+    import moco.builder_vit_mocov3structure_mocov2loss as bld
+    args = types.SimpleNamespace(arch="vit_small")
+    torch.manual_seed(0)
+    return bld.MoCo_ViT(partial(vits.vit_small, stop_grad_conv1=True, depth=depth, precision=precision), args, dim, mlp_dim, T, **kw)
+
+
+def test_mlps_against_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "moco_pieces.npz"), allow_pickle=False)
+    n, hid, mlp_dim, dim = (int(g[k]) for k in ("n", "hid", "mlp_dim", "dim"))
+    m = make_moco(mlp_dim=mlp_dim, dim=dim)
+    proj = m._build_mlp(3, hid, mlp_dim, dim)
+    pred = m._build_mlp(2, dim, mlp_dim, dim)
+    assert proj.load_state_dict(ref_moco.seeded_mlp_params(int(g["seed_proj"]), "", 3, hid, mlp_dim, dim), strict=False).unexpected_keys == []
+    assert pred.load_state_dict(ref_moco.seeded_mlp_params(int(g["seed_pred"]), "", 2, dim, mlp_dim, dim), strict=False).unexpected_keys == []
+    proj, pred = proj.to(DEV).train(), pred.to(DEV).train()
+    x = rng_tensor(int(g["seed_x"]), (n, hid)).to(DEV).requires_grad_(True)
+    r = rng_tensor(int(g["seed_r"]), (n, dim)).to(DEV)
+    from mfvit.moco_ops import l2_normalize
+    z = proj(x)
+    q = pred(z)
+    qn = l2_normalize(q)
+    (qn * r).sum().backward()
+    errs = dict(proj=scale_err(z, torch.from_numpy(g["proj_out"])), pred=scale_err(q, torch.from_numpy(g["pred_out"])),
+                qn=scale_err(qn, torch.from_numpy(g["q_norm"])), dx=scale_err(x.grad, torch.from_numpy(g["dx"])))
+    for name, p in proj.named_parameters():
+        check_sampled(g, "dproj." + name, p.grad, rtol=2e-3, atol=2e-3 * float(g[f"dproj.{name}.abssum"]) / p.numel())
+    for name, p in pred.named_parameters():
+        check_sampled(g, "dpred." + name, p.grad, rtol=2e-3, atol=2e-3 * float(g[f"dpred.{name}.abssum"]) / p.numel())
+    for name, b in proj.named_buffers():
+        errs["buf." + name] = scale_err(b, torch.from_numpy(g["buf." + name]), 1e-2) if b.numel() > 1 else abs(int(b) - int(g["buf." + name]))
+    for name, b in pred.named_buffers():
+        errs["buf.pred." + name] = scale_err(b, torch.from_numpy(g["buf.pred." + name]), 1e-2) if b.numel() > 1 else abs(int(b) - int(g["buf.pred." + name]))
+    log(f"mlps vs reference golden: {errs}")
+    assert max(errs.values()) < 1e-3, errs
+
+
+def test_ema_and_enqueue_against_reference_golden():
+    from mfvit.moco_ops import ema_update_
+    g = np.load(os.path.join(GOLDEN, "moco_pieces.npz"), allow_pickle=False)
+    names = list(g["ema_names"])
+    base = [rng_tensor(int(g["ema_seed_base0"]) + i, g["ema." + n].shape) for i, n in enumerate(names)]
+    mom = [rng_tensor(int(g["ema_seed_mom0"]) + i, g["ema." + n].shape) for i, n in enumerate(names)]
+    fb = torch.cat([t.reshape(-1) for t in base]).to(DEV)
+    fm = torch.cat([t.reshape(-1) for t in mom]).to(DEV)
+    ema_update_(fm, fb, float(g["ema_m"]))
+    off = 0
+    for n in names:
+        k = g["ema." + n].size
+        torch.testing.assert_close(fm[off:off + k].cpu().double(), torch.from_numpy(g["ema." + n]).reshape(-1), rtol=1e-6, atol=1e-7)
+        off += k
+    ema_update_(fm[1:], fb[1:], 0.5)          # unaligned views take the scalar path
+    # enqueue with pointer wrap (BLD:91-105) on the drop-in's key-major queue
+    m = make_moco().to(DEV)
+    K = int(g["K"])
+    assert m.K == K and tuple(m.queue.shape) == (256, K)
+    keys = set(m.state_dict().keys())
+    assert {k for k in g["state_keys"] if k.startswith(("predictor", "queue")) or ".head." in k} <= keys
+    queue = torch.nn.functional.normalize(rng_tensor(int(g["seed_queue"]), (256, K)), dim=0)
+    m.queue.copy_(queue.to(DEV))
+    m.queue_ptr[0] = int(g["enq_ptr_before"])
+    kt = torch.nn.functional.normalize(rng_tensor(int(g["seed_keys"]), (32, 256)), dim=1).to(DEV)
+    m._dequeue_and_enqueue(kt)
+    assert int(m.queue_ptr) == int(g["enq_ptr_after"]) == 0
+    assert torch.equal(m.queue[:, K - 32:].cpu().double(), torch.from_numpy(g["enq_cols"]))
+    assert torch.equal(m.queue[:, :64].cpu().double(), torch.from_numpy(g["enq_untouched"]))
+    # InfoNCE logits on the reference's own queue values (builder:183-191)
+    from mfvit.moco_ops import cross_entropy_rows, neg_logits, pos_logits
+    m.queue.copy_(queue.to(DEV))
+    qv = torch.nn.functional.normalize(rng_tensor(int(g["seed_q"]), (4, 256)), dim=1).to(DEV)
+    kv = torch.nn.functional.normalize(rng_tensor(int(g["seed_k"]), (4, 256)), dim=1).to(DEV)
+    logits = torch.cat([pos_logits(qv, kv), neg_logits(qv, m._queue_t())], dim=1) / float(g["T"])
+    check_sampled(g, "nce_logits", logits, rtol=1e-4, atol=1e-5)
+    loss = cross_entropy_rows(logits, torch.zeros(4, dtype=torch.long, device=DEV))
+    assert abs(float(loss) - float(g["nce_loss"])) < 1e-4 * abs(float(g["nce_loss"]))
+
+
+@pytest.mark.parametrize("predict_keys", [True, False])
+def test_moco_forward_backward_vs_oracle(predict_keys):
+    from mfvit.moco_ops import cross_entropy_rows
+    depth, mlp_dim, dim, T, n, mval = 2, 512, 256, 0.2, 8, 0.99
+    m = make_moco(depth=depth, mlp_dim=mlp_dim, dim=dim, T=T, predict_keys=predict_keys)
+    with torch.no_grad():                                   # make everything non-trivial
+        sd = ref_vit.seeded_params(701, num_classes=0, depth=depth)
+        m.base_encoder.load_state_dict(sd, strict=False)
+        m.momentum_encoder.load_state_dict(ref_vit.seeded_params(702, num_classes=0, depth=depth), strict=False)
+        for i, (_, p) in enumerate(list(m.base_encoder.head.named_parameters()) + list(m.predictor.named_parameters())
+                                   + list(m.momentum_encoder.head.named_parameters())):
+            if p.ndim == 1:
+                p.copy_(1.0 + 0.1 * rng_tensor(710 + i, p.shape) if "weight" in _ else 0.05 * rng_tensor(710 + i, p.shape))
+            else:
+                p.copy_(rng_tensor(710 + i, p.shape) / p.shape[1] ** 0.5)
+    m = m.to(DEV).train()
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    split = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    base_vit = {k: v for k, v in split("base_encoder.").items() if not k.startswith("head.")}
+    mom_vit = {k: v for k, v in split("momentum_encoder.").items() if not k.startswith("head.")}
+    base_proj = {k: v for k, v in split("base_encoder.").items() if k.startswith("head.") and "running" not in k and "num_b" not in k}
+    mom_proj = {k: v for k, v in split("momentum_encoder.").items() if k.startswith("head.") and "running" not in k and "num_b" not in k}
+    pred = {k: v for k, v in sd.items() if k.startswith("predictor.") and "running" not in k and "num_b" not in k}
+    for d_ in (base_vit, base_proj, pred):
+        for k, v in d_.items():
+            v.requires_grad_(k != "pos_embed" and not k.startswith("patch_embed"))
+    im_q, im_k = rng_tensor(720, (n, 3, 224, 224)), rng_tensor(721, (n, 3, 224, 224))
+    ref = ref_moco.moco_forward(base_vit, base_proj, mom_vit, mom_proj, pred, sd["queue"], int(sd["queue_ptr"]), im_q.double(),
+                                im_k.double(), mval, T, use_predictor_on_k=predict_keys)
+    ref["loss"].backward()
+    logits, labels = m(im_q.to(DEV), im_k.to(DEV), mval)
+    assert tuple(logits.shape) == (n, 1 + m.K) and labels.dtype == torch.long and int(labels.abs().sum()) == 0
+    loss = cross_entropy_rows(logits, labels)
+    loss.backward()
+    errs = dict(logits=scale_err(logits, ref["logits"]), loss=abs(float(loss) - float(ref["loss"])) / abs(float(ref["loss"])))
+    worst = ("", 0.0)
+    # gradients that are mathematically zero (a batch-constant shift in front of a BatchNorm, e.g. norm.bias) are pure
+    # rounding noise in both implementations: compare against a floor tied to the largest gradient
+    gfloor = 1e-4 * max(float(v.grad.abs().max()) for d_ in (base_vit, base_proj, pred) for v in d_.values() if v.grad is not None)
+    for name, p in m.named_parameters():
+        if name.startswith("base_encoder.head."):
+            rg = base_proj[name[len("base_encoder."):]].grad
+        elif name.startswith("base_encoder."):
+            rg = base_vit[name[len("base_encoder."):]].grad
+        elif name.startswith("predictor."):
+            rg = pred[name].grad
+        else:
+            assert p.grad is None, name                   # momentum encoder: no gradient (BLD:52-54)
+            continue
+        if rg is None:
+            assert p.grad is None, name
+            continue
+        e = scale_err(p.grad, rg, gfloor)
+        worst = max(worst, (name, e), key=lambda t: t[1])
+        assert e < 2e-3, (name, e)
+    # momentum encoder after the EMA, queue after the enqueue
+    for k, v in ref["mom_vit"].items():
+        assert scale_err(m.momentum_encoder.state_dict()[k], v) < 1e-5, k
+    for k, v in ref["mom_proj"].items():
+        assert scale_err(m.momentum_encoder.state_dict()[k], v) < 1e-5, k
+    assert int(m.queue_ptr) == ref["ptr"] == n
+    errs["queue"] = scale_err(m.queue[:, :n], ref["queue"][:, :n])
+    log(f"moco fwd/bwd vs oracle [predict_keys={predict_keys}]: {errs} worst grad {worst}")
+    assert errs["logits"] < 1e-3 and errs["loss"] < 1e-3 and errs["queue"] < 1e-3
+
+
+def test_lars_against_reference_golden_and_adam_sgd_vs_torch():
+    from moco.optimizer import LARS
+    from mfvit.optim import SGD, Adam, AdamW
+    g = np.load(os.path.join(GOLDEN, "lars.npz"), allow_pickle=False)
+    shapes = [(6, 5), (5,), (4, 3), (3, 2)]
+    ps = [torch.nn.Parameter(rng_tensor(400 + i, s).to(DEV)) for i, s in enumerate(shapes)]
+    with torch.no_grad():
+        ps[3].zero_()
+    opt = LARS(ps, lr=float(g["lr"]), weight_decay=float(g["weight_decay"]), momentum=float(g["momentum"]))
+    for step in range(3):
+        for i, p in enumerate(ps):
+            p.grad = rng_tensor(410 + 10 * step + i, p.shape).to(DEV)
+            if step == 1 and i == 2:
+                p.grad = (-float(g["weight_decay"]) * p.detach()).clone()
+        opt.step()
+        for i, p in enumerate(ps):
+            torch.testing.assert_close(p.detach().cpu().double(), torch.from_numpy(g[f"p{i}.step{step}"]), rtol=5e-6, atol=1e-7)
+    for mine, theirs, kw in ((Adam, torch.optim.Adam, dict(lr=1e-2, weight_decay=0.1)), (AdamW, torch.optim.AdamW, dict(lr=1e-2, weight_decay=0.1)),
+                             (SGD, torch.optim.SGD, dict(lr=0.1, momentum=0.9, weight_decay=0.01))):
+        a = [torch.nn.Parameter(rng_tensor(500 + i, s).to(DEV)) for i, s in enumerate([(70000,), (33, 7), (5,)])]
+        b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+        oa, ob = mine(a, **kw), theirs(b, **kw)
+        for step in range(4):
+            for i, (pa, pb) in enumerate(zip(a, b)):
+                gr = rng_tensor(520 + 10 * step + i, pa.shape).to(DEV)
+                pa.grad, pb.grad = gr.clone(), gr.clone()
+            oa.step(); ob.step()
+        for pa, pb in zip(a, b):
+            torch.testing.assert_close(pa.detach(), pb.detach(), rtol=2e-5, atol=2e-6)
