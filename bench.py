@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--mode", choices=["T", "F"], default="T")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--img", type=int, default=224)
+    ap.add_argument("--workload", choices=["ca", "single", "moco"], default="ca",
+                    help="ca = BASELINE configs[2] (the metric's configuration); single = configs[1]; moco = configs[3] per-GPU slice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     return ap.parse_args()
@@ -112,6 +114,90 @@ def cpu_baseline(args, model, backs, x, xe, target):
                        f"{' after 1 warm-up' if n else ' (the warm-up itself, host too slow for more)'}, {ncpu} threads"), out
 
 
+def other_workloads(args, world, rank, dev, lib):
+    """configs[1] (single-stream fwd/bwd, B=64) and configs[3] (MoCo pretrain step, 128 samples / GPU): same timing contract,
+    reported with their own metric names (they are NOT the headline metric)."""
+    import types
+    from functools import partial
+    import vits
+    from mfvit.ddp import GradSync
+    from mfvit.losses import cross_entropy
+    from mfvit.optim import SGD, AdamW
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1234 + rank)
+    sync = GradSync()
+    if args.workload == "single":
+        B = 64 if args.batch == 128 else args.batch
+        model = vits.vit_small(num_classes=3, precision=args.precision, img_size=args.img).to(dev)     # MAIN_SS:276,290
+        sync.attach(model)
+        x = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
+        y = torch.randint(0, 3, (B,), generator=g).to(dev)
+        opt = SGD(model.parameters(), lr=1e-3, momentum=0.9)                                           # MAIN_SS:386-398
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss, _ = cross_entropy(model(x), y)                                                       # MAIN_SS:711-714
+            loss.backward()
+            sync.reduce_grads(list(model.head.parameters()))
+            sync.finish()
+            opt.step()
+            return loss
+        gflop, name = 27.59, "images/sec (single-stream vit_small fwd+bwd step, BASELINE configs[1])"
+    else:
+        import moco.builder_vit_mocov3structure_mocov2loss as bld
+        from mfvit.moco_ops import cross_entropy_rows
+        from mfvit.schedules import adjust_moco_momentum
+        B = args.batch
+        model = bld.MoCo_ViT(partial(vits.vit_small, stop_grad_conv1=True, precision=args.precision, img_size=args.img),
+                             types.SimpleNamespace(arch="vit_small"), 256, 4096, 0.2).to(dev)          # MAIN_MOCO:273-275, README.md:33
+        sync.attach(model.base_encoder)
+        x1 = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
+        x2 = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
+        train = [p for p in model.parameters() if p.requires_grad]
+        small = [p for n, p in model.named_parameters() if p.requires_grad and (".head." in n or n.startswith("predictor"))]
+        opt = AdamW(train, lr=1.5e-4, weight_decay=0.1)                                                # MAIN_MOCO:338-340
+        it = [0]
+
+        def step():
+            m = adjust_moco_momentum(it[0] / 1000.0, 300, 0.99)                                        # MAIN_MOCO:525-526
+            it[0] += 1
+            logits, labels = model(x1, x2, m)                                                          # MAIN_MOCO:534
+            loss = cross_entropy_rows(logits, labels)                                                  # MAIN_MOCO:535
+            opt.zero_grad(set_to_none=True)
+            loss.backward()                                                                            # MAIN_MOCO:546
+            sync.reduce_grads(small)
+            sync.finish()
+            opt.step()
+            return loss
+        gflop, name = 36.80, "samples/sec (MoCo vit_small pretrain step, BASELINE configs[3] per-GPU slice of 128)"
+    for _ in range(max(args.warmup, 1)):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+    if rank == 0:
+        print(json.dumps(dict(metric=name, value=B * world * args.steps / dt, unit="images/sec", n_gpus=world, steps=args.steps,
+                              warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
+                              vs_baseline=None, dtype=args.precision, data="synthetic",
+                              config=dict(workload=args.workload, per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
+                              model_tflops=gflop * B * world * args.steps / dt / 1e3 if args.img == 224 else None,
+                              loss=float(loss.detach()))), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,6 +215,8 @@ def main():
     from mfvit.losses import cross_entropy
     lib = _lib.lib()
 
+    if args.workload != "ca":
+        return other_workloads(args, world, rank, dev, lib)
     model, backs = build_models(args, dev)
     g = torch.Generator().manual_seed(1234 + rank)                                       # SURVEY.md 8(d) synthetic inputs
     B = args.batch
@@ -139,7 +227,8 @@ def main():
     params = list(model.parameters())
     for m in backs:
         params += [p for p in m.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.999))                          # MAIN_CA:455-459
+    from mfvit.optim import Adam
+    opt = Adam(params, lr=1e-4, betas=(0.9, 0.999))                                      # MAIN_CA:455-459 (multi-tensor HIP kernel)
     sync = GradSync()
     for m in backs:
         sync.attach(m)

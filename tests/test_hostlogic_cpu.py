@@ -1,0 +1,114 @@
+"""CPU: host-side logic of the product - schedules vs the oracle, MoCo drop-in surface / state-dict layout vs the
+reference-generated golden key list, optimizers' constructor surface, and the N > 1 paths on 2 gloo ranks
+(GradSync flat exchange, concat_all_gather ordering, enqueue of gathered keys)."""
+import os
+import types
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN
+from oracle import ref_moco
+
+
+def test_schedules_match_oracle():
+    from mfvit import schedules
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    lr0, E, W = 1.5e-4 * 1024 / 4, 300, 40                       # MAIN_MOCO:286-288 lr scaling
+    for e in (0.0, 0.5, 20.0, 39.99, 40.0, 41.3, 170.0, 299.9, 300.0):
+        a = schedules.adjust_learning_rate(opt, e, lr0, E, W)
+        assert a == ref_moco.adjust_learning_rate(e, lr0, E, W) == opt.param_groups[0]["lr"]
+        assert schedules.adjust_moco_momentum(e, E, 0.99) == ref_moco.adjust_moco_momentum(e, E, 0.99)
+    assert schedules.adjust_learning_rate(None, 65, 0.1, 90, 0, cos=False, schedule=(30, 60)) == \
+        ref_moco.adjust_learning_rate(65, 0.1, 90, 0, cos=False, schedule=(30, 60))
+
+
+def _moco(depth=1, mlp_dim=128, **kw):
+    import vits
+    import moco.builder_vit_mocov3structure_mocov2loss as bld
+    return bld, bld.MoCo_ViT(partial(vits.vit_small, stop_grad_conv1=True, depth=depth), types.SimpleNamespace(arch="vit_small"),
+                             256, mlp_dim, 0.2, **kw)
+
+
+def test_moco_drop_in_surface_and_state_dict_layout():
+    g = np.load(os.path.join(GOLDEN, "moco_pieces.npz"), allow_pickle=False)
+    bld, m = _moco()
+    for n in ("MoCo", "MoCo_ViT", "MoCo_ResNet", "concat_all_gather"):                    # MAIN_MOCO:35,273-282
+        assert hasattr(bld, n)
+    keys = set(m.state_dict().keys())
+    ref_keys = {k for k in g["state_keys"] if k.startswith(("predictor", "queue")) or ".head." in k}
+    assert ref_keys <= keys                                                                # BLD:215-225 layout, reference-generated
+    assert "predictor.4.weight" not in keys and "base_encoder.head.7.weight" not in keys  # last BN affine=False
+    assert m.K == 65536 and tuple(m.queue.shape) == (256, 65536) and m.queue_ptr.dtype == torch.long
+    torch.testing.assert_close(m.queue.norm(dim=0), torch.ones(65536), rtol=1e-5, atol=1e-5)   # BLD:57-58
+    for pb, pm in zip(m.base_encoder.parameters(), m.momentum_encoder.parameters()):       # BLD:52-54
+        assert torch.equal(pb, pm) and not pm.requires_grad
+    assert not m.base_encoder.patch_embed.proj.weight.requires_grad                        # stop_grad_conv1 (MAIN_MOCO:274)
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert n_train == sum(p.numel() for n_, p in m.named_parameters()
+                          if not n_.startswith("momentum_encoder") and p.requires_grad)
+    with pytest.raises(NotImplementedError):
+        bld.MoCo_ViT(lambda **k: None, types.SimpleNamespace(arch="resnet50"))
+    import moco.builder_vit_mocov3structure_mocov2loss_noprediction_q as np_bld
+    assert np_bld.MoCo_ViT is not bld.MoCo_ViT
+    from moco.optimizer import LARS
+    opt = LARS(m.parameters(), 0.3, weight_decay=1e-6, momentum=0.9)                       # MAIN_MOCO:335-337
+    assert opt.defaults["trust_coefficient"] == 0.001
+    from mfvit import MfvitError
+    with pytest.raises(MfvitError):
+        m(torch.zeros(2, 3, 224, 224), torch.zeros(2, 3, 224, 224), 0.99)                  # CPU tensors: loud failure
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mfvit.ddp import GradSync
+        bld, m = _moco()
+        # (1) GradSync: flat exchange of small gradients = mean over ranks
+        ps = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))]
+        for i, p in enumerate(ps):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        sync = GradSync()
+        assert sync.enabled and sync.world == world and not sync.avg
+        sync.reduce_grads(ps)
+        sync.finish()
+        ok1 = all(torch.allclose(p.grad, torch.full_like(p, 1.5 * (i + 1))) for i, p in enumerate(ps))
+        # (2) encoder stage hook: per-block slices of a flat gradient arena are averaged, everything is covered exactly once
+        vit = m.base_encoder
+        sync.attach(vit)
+        gflat = torch.full_like(vit.flat_parameters(), float(rank + 1))
+        for s in range(vit.depth, -2, -1):
+            vit._grad_stage_hook(vit, s, gflat)
+        sync.finish()
+        ok2 = bool(torch.allclose(gflat, torch.full_like(gflat, 1.5)))
+        # (3) concat_all_gather order + enqueue of the gathered keys (BLD:91-105, 229-240)
+        keys = torch.nn.functional.normalize(torch.full((4, 256), float(rank + 1)) + torch.arange(4).float()[:, None], dim=1)
+        allk = bld.concat_all_gather(keys)
+        ok3 = allk.shape == (8, 256) and torch.equal(allk[rank * 4:(rank + 1) * 4], keys)
+        m.queue_ptr[0] = m.K - 8
+        m._dequeue_and_enqueue(keys)
+        ok4 = int(m.queue_ptr) == 0 and torch.equal(m.queue[:, m.K - 8:], allk.t())
+        q.put((rank, ok1, ok2, bool(ok3), bool(ok4)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_paths():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 200
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok1, ok2, ok3, ok4 in res:
+        assert ok1 and ok2 and ok3 and ok4, (rank, ok1, ok2, ok3, ok4)
