@@ -186,10 +186,14 @@ int ln_bwd_rows(int dtype, int N, const float* dy, long lddy, const float* x, lo
 
 // --------------------------------------------------------------------------------------- cast + transpose
 // src f32 [R][C] -> dst T [R][C] (optional) and dstT T [C][R] (optional); 64x64 tiles through LDS.
+// blockIdx.z = batch index (same-shaped matrices at fixed strides: the 12 blocks of an encoder in one launch)
 template <typename T>
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, T* __restrict__ dstT, int R,
-                                                             int C) {
+                                                             int C, long s_src, long s_dst, long s_dstT) {
     __shared__ float tile[64][65];
+    src += blockIdx.z * s_src;
+    if (dst) dst = (T*)((char*)dst + blockIdx.z * s_dst);
+    if (dstT) dstT = (T*)((char*)dstT + blockIdx.z * s_dstT);
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     for (int q = threadIdx.x; q < 64 * 64; q += 256) {
         const int r = q >> 6, c = q & 63;
@@ -208,14 +212,19 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         }
     }
 }
-int cast_transpose(int dtype, const float* src, void* dst, void* dstT, int R, int C, hipStream_t st) {
-    const dim3 grid((C + 63) / 64, (R + 63) / 64);
+// strides: s_src in floats, s_dst / s_dstT in BYTES (shadow layouts are byte-addressed)
+int cast_transpose_batched(int dtype, const float* src, void* dst, void* dstT, int R, int C, int nb, long s_src, long s_dst, long s_dstT,
+                           hipStream_t st) {
+    const dim3 grid((C + 63) / 64, (R + 63) / 64, nb);
     if (dtype == MFVIT_BF16)
-        hipLaunchKernelGGL(cast_transpose_kernel<bf16>, grid, dim3(256), 0, st, src, (bf16*)dst, (bf16*)dstT, R, C);
+        hipLaunchKernelGGL(cast_transpose_kernel<bf16>, grid, dim3(256), 0, st, src, (bf16*)dst, (bf16*)dstT, R, C, s_src, s_dst, s_dstT);
     else
-        hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, (float*)dstT, R, C);
+        hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, (float*)dstT, R, C, s_src, s_dst, s_dstT);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
+}
+int cast_transpose(int dtype, const float* src, void* dst, void* dstT, int R, int C, hipStream_t st) {
+    return cast_transpose_batched(dtype, src, dst, dstT, R, C, 1, 0, 0, 0, st);
 }
 
 // --------------------------------------------------------------------------------------- small linear heads

@@ -27,6 +27,8 @@ int ln_bwd_rows(int dtype, int N, const float* dy, long lddy, const float* x, lo
                 const float* gamma, const float* dres, long ldres, float* dx, long lddx, void* dxT, long lddxT, float* dgamma, float* dbeta,
                 float* dcol, int rows, int row_stride, int row_off, hipStream_t st);
 int cast_transpose(int dtype, const float* src, void* dst, void* dstT, int R, int C, hipStream_t st);
+int cast_transpose_batched(int dtype, const float* src, void* dst, void* dstT, int R, int C, int nb, long s_src, long s_dst, long s_dstT,
+                           hipStream_t st);
 int linear_small_fwd(const float* x, long ldx, const float* W, const float* b, float* y, long ldy, int M, int N, int K, int accumulate,
                      hipStream_t st);
 int linear_small_bwd(const float* dy, long lddy, const float* x, long ldx, const float* W, float* dx, long lddx, int dx_accumulate, float* dW,

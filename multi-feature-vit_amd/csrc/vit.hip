@@ -205,14 +205,14 @@ int mfvit_vit_prepare_shadow(const mfvit_vit_cfg* cfg, const float* params, void
     char* sh = (char*)shadow;
     const bool hw = d.dtype == MFVIT_BF16;
     if (hw) MFVIT_TRY(cast_transpose(d.dtype, params + L.pe_w, sh + S.pe_w, nullptr, d.D, 768, st));
-    for (int l = 0; l < d.depth; ++l) {
-        const float* pb = params + L.blk0 + (long)l * L.blk_stride;
-        char* sb = sh + S.blk0 + (size_t)l * S.blk_stride;
-        MFVIT_TRY(cast_transpose(d.dtype, pb + L.qkv_w, hw ? sb + S.qkv_w : nullptr, sb + S.qkv_t, 3 * d.D, d.D, st));
-        MFVIT_TRY(cast_transpose(d.dtype, pb + L.proj_w, hw ? sb + S.proj_w : nullptr, sb + S.proj_t, d.D, d.D, st));
-        MFVIT_TRY(cast_transpose(d.dtype, pb + L.fc1_w, hw ? sb + S.fc1_w : nullptr, sb + S.fc1_t, d.F, d.D, st));
-        MFVIT_TRY(cast_transpose(d.dtype, pb + L.fc2_w, hw ? sb + S.fc2_w : nullptr, sb + S.fc2_t, d.D, d.F, st));
-    }
+    // one launch per weight type covers all `depth` blocks (identical shapes at fixed arena / shadow strides)
+    const float* pb = params + L.blk0;
+    char* sb = sh + S.blk0;
+    const long ss = L.blk_stride, sd = (long)S.blk_stride;
+    MFVIT_TRY(cast_transpose_batched(d.dtype, pb + L.qkv_w, hw ? sb + S.qkv_w : nullptr, sb + S.qkv_t, 3 * d.D, d.D, d.depth, ss, sd, sd, st));
+    MFVIT_TRY(cast_transpose_batched(d.dtype, pb + L.proj_w, hw ? sb + S.proj_w : nullptr, sb + S.proj_t, d.D, d.D, d.depth, ss, sd, sd, st));
+    MFVIT_TRY(cast_transpose_batched(d.dtype, pb + L.fc1_w, hw ? sb + S.fc1_w : nullptr, sb + S.fc1_t, d.F, d.D, d.depth, ss, sd, sd, st));
+    MFVIT_TRY(cast_transpose_batched(d.dtype, pb + L.fc2_w, hw ? sb + S.fc2_w : nullptr, sb + S.fc2_t, d.D, d.F, d.depth, ss, sd, sd, st));
     return MFVIT_OK;
 }
 
