@@ -205,9 +205,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # RCCL ('nccl' on ROCm) in production; MFVIT_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
+        dist.init_process_group(os.environ.get("MFVIT_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from mfvit import _lib

@@ -230,7 +230,7 @@ static int launch_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int
         attr_set = true;
     }
     ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
-    hipLaunchKernelGGL((attn_fwd_exact_kernel<T, HD>), dim3(B * H), dim3(256), bytes, st, (const T*)qkv, (T*)out, lse, Tn, H,
+    MFVIT_LAUNCH((attn_fwd_exact_kernel<T, HD>), dim3(B * H), dim3(256), bytes, st, (const T*)qkv, (T*)out, lse, Tn, H,
                        1.0f / sqrtf((float)HD));
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -246,7 +246,7 @@ static int launch_bwd(const void* qkv, const void* out, const void* dout, const 
         attr_set = true;
     }
     ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
-    hipLaunchKernelGGL((attn_bwd_exact_kernel<T, HD>), dim3(B * H), dim3(256), bytes, st, (const T*)qkv, (const T*)out, (const T*)dout, lse,
+    MFVIT_LAUNCH((attn_bwd_exact_kernel<T, HD>), dim3(B * H), dim3(256), bytes, st, (const T*)qkv, (const T*)out, (const T*)dout, lse,
                        (T*)dqkv, dbias, Tn, H, 1.0f / sqrtf((float)HD));
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;

@@ -298,7 +298,7 @@ int attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int Tn, int H, 
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (bf16*)out, lse, Tn, H,
+    MFVIT_LAUNCH(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (bf16*)out, lse, Tn, H,
                        1.0f / sqrtf((float)HD));
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -311,13 +311,13 @@ int attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const floa
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     {
         ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
-        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
+        MFVIT_LAUNCH(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
                            lse, (bf16*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
         MFVIT_CHECK_LAUNCH();
     }
     if (dbias) {
         const int M = B * Tn, N = 3 * H * HD;
-        hipLaunchKernelGGL(colsum_bf16_kernel, dim3((M + 63) / 64), dim3(256), 0, st, (const bf16*)dqkv, (long)N, dbias, M, N);
+        MFVIT_LAUNCH(colsum_bf16_kernel, dim3((M + 63) / 64), dim3(256), 0, st, (const bf16*)dqkv, (long)N, dbias, M, N);
         MFVIT_CHECK_LAUNCH();
     }
     return MFVIT_OK;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/mfvit.h"
 
@@ -103,10 +104,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + loc;
 }
 
-#define MFVIT_CHECK_LAUNCH()                                  \
-    do {                                                      \
-        hipError_t e__ = hipGetLastError();                   \
-        if (e__ != hipSuccess) return MFVIT_ELAUNCH;         \
+// Launch wrapper: clears whatever sticky error code earlier, unrelated runtime calls of this thread left behind (the host
+// framework's event queries, device probing at load time), so that MFVIT_CHECK_LAUNCH reports THIS launch only.
+#define MFVIT_LAUNCH(kernel, grid, block, lds_bytes, stream, ...)                       \
+    do {                                                                               \
+        (void)hipGetLastError();                                                       \
+        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, __VA_ARGS__);       \
+    } while (0)
+
+// hipGetLastError() also reports benign sticky codes left behind by the host framework's own calls on this thread
+// (hipErrorNotReady from event / stream queries of the caching allocator): those are not launch failures.
+#define MFVIT_CHECK_LAUNCH()                                                       \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess && e__ != hipErrorNotReady) {                        \
+            fprintf(stderr, "[mfvit] HIP error %d (%s) at %s:%d\n", (int)e__, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return MFVIT_ELAUNCH;                                                  \
+        }                                                                          \
     } while (0)
 
 }  // namespace mfvit

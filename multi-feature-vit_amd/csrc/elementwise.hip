@@ -39,9 +39,9 @@ int im2col16(int dtype, const float* img, void* P, int B, int H, int W, hipStrea
     const long total = (long)B * (H / 16) * (W / 16) * 96;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (dtype == MFVIT_BF16)
-        hipLaunchKernelGGL(im2col16_kernel<bf16>, dim3(blocks), dim3(256), 0, st, img, (bf16*)P, B, H, W);
+        MFVIT_LAUNCH(im2col16_kernel<bf16>, dim3(blocks), dim3(256), 0, st, img, (bf16*)P, B, H, W);
     else
-        hipLaunchKernelGGL(im2col16_kernel<float>, dim3(blocks), dim3(256), 0, st, img, (float*)P, B, H, W);
+        MFVIT_LAUNCH(im2col16_kernel<float>, dim3(blocks), dim3(256), 0, st, img, (float*)P, B, H, W);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -98,7 +98,7 @@ int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long
     if (rows <= 0) return MFVIT_OK;
     const dim3 grid((rows + 3) / 4), blk(256);
 #define MFVIT_LN(TT, NPL)                                                                                                        \
-    hipLaunchKernelGGL((ln_rows_kernel<TT, NPL>), grid, blk, 0, st, in0, ld0, in1, ld1, mod1, xout, ldx, y, ldy, y_f32, gamma, beta, eps, \
+    MFVIT_LAUNCH((ln_rows_kernel<TT, NPL>), grid, blk, 0, st, in0, ld0, in1, ld1, mod1, xout, ldx, y, ldy, y_f32, gamma, beta, eps, \
                        mean, rstd, rows, row_stride, row_off, in0_bcast)
     if (N == 384) { if (dtype == MFVIT_BF16) MFVIT_LN(bf16, 6); else MFVIT_LN(float, 6); }
     else if (N == 768) { if (dtype == MFVIT_BF16) MFVIT_LN(bf16, 12); else MFVIT_LN(float, 12); }
@@ -174,7 +174,7 @@ int ln_bwd_rows(int dtype, int N, const float* dy, long lddy, const float* x, lo
     int blocks = (rows + 3) / 4;
     if (blocks > 1024) blocks = 1024;
 #define MFVIT_LNB(TT, NPL)                                                                                                         \
-    hipLaunchKernelGGL((ln_bwd_rows_kernel<TT, NPL>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres, ldres, dx, \
+    MFVIT_LAUNCH((ln_bwd_rows_kernel<TT, NPL>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres, ldres, dx, \
                        lddx, (TT*)dxT, lddxT, dgamma, dbeta, dcol, rows, row_stride, row_off)
     if (N == 384) { if (dtype == MFVIT_BF16) MFVIT_LNB(bf16, 6); else MFVIT_LNB(float, 6); }
     else if (N == 768) { if (dtype == MFVIT_BF16) MFVIT_LNB(bf16, 12); else MFVIT_LNB(float, 12); }
@@ -217,9 +217,9 @@ int cast_transpose_batched(int dtype, const float* src, void* dst, void* dstT, i
                            hipStream_t st) {
     const dim3 grid((C + 63) / 64, (R + 63) / 64, nb);
     if (dtype == MFVIT_BF16)
-        hipLaunchKernelGGL(cast_transpose_kernel<bf16>, grid, dim3(256), 0, st, src, (bf16*)dst, (bf16*)dstT, R, C, s_src, s_dst, s_dstT);
+        MFVIT_LAUNCH(cast_transpose_kernel<bf16>, grid, dim3(256), 0, st, src, (bf16*)dst, (bf16*)dstT, R, C, s_src, s_dst, s_dstT);
     else
-        hipLaunchKernelGGL(cast_transpose_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, (float*)dstT, R, C, s_src, s_dst, s_dstT);
+        MFVIT_LAUNCH(cast_transpose_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, (float*)dstT, R, C, s_src, s_dst, s_dstT);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void linear_small_bwd_kernel(const float* __re
 }
 int linear_small_fwd(const float* x, long ldx, const float* W, const float* b, float* y, long ldy, int M, int N, int K, int accumulate,
                      hipStream_t st) {
-    hipLaunchKernelGGL(linear_small_fwd_kernel, dim3((M * N + 3) / 4), dim3(256), 0, st, x, ldx, W, b, y, ldy, M, N, K, accumulate);
+    MFVIT_LAUNCH(linear_small_fwd_kernel, dim3((M * N + 3) / 4), dim3(256), 0, st, x, ldx, W, b, y, ldy, M, N, K, accumulate);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -277,7 +277,7 @@ int linear_small_bwd(const float* dy, long lddy, const float* x, long ldx, const
                      float* db, int M, int N, int K, hipStream_t st) {
     long work = (long)M * K;
     if ((long)N * K > work) work = (long)N * K;
-    hipLaunchKernelGGL(linear_small_bwd_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dy, lddy, x, ldx, W, dx, lddx,
+    MFVIT_LAUNCH(linear_small_bwd_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, dy, lddy, x, ldx, W, dx, lddx,
                        dx_accumulate, dW, db, M, N, K);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -310,7 +310,7 @@ __global__ void ce_small_kernel(const float* __restrict__ logits, const long* __
 int ce_small(const float* logits, const long* target, float* loss_mean, float* dlogits, long* preds, int B, int C, hipStream_t st) {
     if (C > 64 || C < 1) return MFVIT_EINVAL;
     if (hipMemsetAsync(loss_mean, 0, sizeof(float), st) != hipSuccess) return MFVIT_ELAUNCH;
-    hipLaunchKernelGGL(ce_small_kernel, dim3((B + 255) / 256), dim3(256), 0, st, logits, target, loss_mean, dlogits, preds, B, C);
+    MFVIT_LAUNCH(ce_small_kernel, dim3((B + 255) / 256), dim3(256), 0, st, logits, target, loss_mean, dlogits, preds, B, C);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -321,7 +321,7 @@ __global__ void add_rows_kernel(float* __restrict__ dst, long ldd, const float* 
     if (id < (long)rows * N) dst[(id / N) * ldd + id % N] += src[(id / N) * lds_ + id % N];
 }
 int add_rows(float* dst, long ldd, const float* src, long lds_, int rows, int N, hipStream_t st) {
-    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)(((long)rows * N + 255) / 256)), dim3(256), 0, st, dst, ldd, src, lds_, rows, N);
+    MFVIT_LAUNCH(add_rows_kernel, dim3((unsigned)(((long)rows * N + 255) / 256)), dim3(256), 0, st, dst, ldd, src, lds_, rows, N);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -330,7 +330,7 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
     if (i < n) y[i] = fmaf(a, x[i], y[i]);
 }
 int axpy(float* y, const float* x, float a, long n, hipStream_t st) {
-    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, a, n);
+    MFVIT_LAUNCH(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, a, n);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void colsum_rows_kernel(const float* __restric
 }
 int colsum_rows(const float* x, long ld, float* out, int rows, int row_stride, int row_off, int N, hipStream_t st) {
     int gy = rows < 64 ? rows : 64;
-    hipLaunchKernelGGL(colsum_rows_kernel, dim3((N + 255) / 256, gy), dim3(256), 0, st, x, ld, out, rows, row_stride, row_off, N);
+    MFVIT_LAUNCH(colsum_rows_kernel, dim3((N + 255) / 256, gy), dim3(256), 0, st, x, ld, out, rows, row_stride, row_off, N);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

@@ -467,7 +467,7 @@ int mfvit_fusion_forward(const mfvit_fusion_cfg* cfg, const float* params, const
         for (int k = 0; k < 4; ++k)
             FUS_TRY(cast_transpose(MFVIT_F32, params + L.ca[dir] + offs[k], nullptr, ws + W.wT + ((long)dir * 4 + k) * D * D, D, D, st));
     }
-    hipLaunchKernelGGL(x_cls_ln_kernel, dim3(B, 2), dim3(64), 0, st, f_cxr, f_enh, params, L, cfg->eps_pre, B, T, ws + W.z0, ws + W.st0);
+    MFVIT_LAUNCH(x_cls_ln_kernel, dim3(B, 2), dim3(64), 0, st, f_cxr, f_enh, params, L, cfg->eps_pre, B, T, ws + W.z0, ws + W.st0);
     MFVIT_CHECK_LAUNCH();
     {   // qv = z0 Wq^T
         GemmP p = zg();
@@ -488,7 +488,7 @@ int mfvit_fusion_forward(const mfvit_fusion_cfg* cfg, const float* params, const
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)x_stream_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
         ProfScope ps(PROF_XATTN_FWD, 0, 2.0 * B * T * D * 4 * 2, st);
-        hipLaunchKernelGGL(x_stream_fwd_kernel, dim3(B, 2), dim3(256), lds, st, f_cxr, f_enh, params, L, cfg->eps_pre, scale, B, T,
+        MFVIT_LAUNCH(x_stream_fwd_kernel, dim3(B, 2), dim3(256), lds, st, f_cxr, f_enh, params, L, cfg->eps_pre, scale, B, T,
                            ws + W.kq, ws + W.u, ws + W.a, ws + W.st);
         MFVIT_CHECK_LAUNCH();
     }
@@ -507,7 +507,7 @@ int mfvit_fusion_forward(const mfvit_fusion_cfg* cfg, const float* params, const
         p.nb = 2; p.nbi = 1; p.sAo = (long)B * D; p.sWo = L.ca_stride; p.sOo = (long)B * D; p.sBo = L.ca_stride;
         FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_BIAS, p, st));
     }
-    hipLaunchKernelGGL(x_finish_fwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, cfg->eps_post, B, T, C, ws + W.outp,
+    MFVIT_LAUNCH(x_finish_fwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, cfg->eps_post, B, T, C, ws + W.outp,
                        ws + W.fus, ws + W.stc, hw_cxr, hb_cxr, hw_enh, hb_enh, fused, x_cxr, x_enh);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -526,7 +526,7 @@ int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, cons
     float* ws = (float*)workspace;
     const float scale = 1.0f / sqrtf((float)DH);
     const float* wT = ws + W.wT;
-    hipLaunchKernelGGL(x_finish_bwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, B, T, C, ws + W.outp, ws + W.fus,
+    MFVIT_LAUNCH(x_finish_bwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, B, T, C, ws + W.outp, ws + W.fus,
                        ws + W.stc, hw_cxr, hw_enh, dfused, dx_cxr, dx_enh, dparams, dhw_cxr, dhb_cxr, dhw_enh, dhb_enh, ws + W.dout,
                        ws + W.dqp);
     MFVIT_CHECK_LAUNCH();
@@ -563,7 +563,7 @@ int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, cons
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)x_stream_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
         ProfScope ps(PROF_XATTN_BWD, 0, 2.0 * B * T * D * 4 * 3, st);
-        hipLaunchKernelGGL(x_stream_bwd_kernel, dim3(B, 2), dim3(256), lds, st, f_cxr, f_enh, params, L, scale, B, T, ws + W.kq, ws + W.a,
+        MFVIT_LAUNCH(x_stream_bwd_kernel, dim3(B, 2), dim3(256), lds, st, f_cxr, f_enh, params, L, scale, B, T, ws + W.kq, ws + W.a,
                            ws + W.st, ws + W.du, ws + W.dkq, ws + W.dz0p, dparams, df_cxr, df_enh);
         MFVIT_CHECK_LAUNCH();
     }
@@ -595,7 +595,7 @@ int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, cons
         p.nb = 2; p.nbi = 1; p.sAo = (long)B * D; p.sWo = 4L * D * D; p.sOo = (long)B * D;
         FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
     }
-    hipLaunchKernelGGL(x_row0_bwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, B, T, ws + W.st0, ws + W.dz0p, ws + W.dz0q,
+    MFVIT_LAUNCH(x_row0_bwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, B, T, ws + W.st0, ws + W.dz0p, ws + W.dz0q,
                        ws + W.dqp, dparams, df_cxr, df_enh);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;

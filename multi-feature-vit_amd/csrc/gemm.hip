@@ -411,7 +411,7 @@ template <typename T, int EPI> static int launch_tile(const GemmP& p, hipStream_
         attr_set = true;
     }
     ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
-    hipLaunchKernelGGL((gemm_nt_tile_kernel<T, EPI>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), lds_bytes, st, p);
+    MFVIT_LAUNCH((gemm_nt_tile_kernel<T, EPI>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), lds_bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -430,7 +430,7 @@ template <typename T, int REPI, int WM, int BKB> static int launch_row_v(const G
         attr_set = true;
     }
     ProfScope ps(REPI == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
-    hipLaunchKernelGGL((gemm_nt_row_kernel<T, REPI, WM, BKB>), dim3((p.M + ROW_BM - 1) / ROW_BM), dim3(WM * 256), bytes, st, p);
+    MFVIT_LAUNCH((gemm_nt_row_kernel<T, REPI, WM, BKB>), dim3((p.M + ROW_BM - 1) / ROW_BM), dim3(WM * 256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -458,7 +458,7 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
         attr_set = true;
     }
     ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
-    hipLaunchKernelGGL((gemm_tn_kernel<T>), dim3(tiles, p.splits, p.nb > 1 ? p.nb : 1), dim3(256), bytes, st, p);
+    MFVIT_LAUNCH((gemm_tn_kernel<T>), dim3(tiles, p.splits, p.nb > 1 ? p.nb : 1), dim3(256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

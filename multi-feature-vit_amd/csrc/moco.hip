@@ -188,15 +188,15 @@ extern "C" {
 int mfvit_bn_stats(int dtype, const void* x, int n, int C, float* mean, float* m2, mfvit_stream_t stream) {
     if (!x || !mean || !m2 || n <= 0 || C <= 0) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFVIT_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16>, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16*)x, n, C, mean, m2);
-    else hipLaunchKernelGGL(bn_stats_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)x, n, C, mean, m2);
+    if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_stats_kernel<bf16>, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16*)x, n, C, mean, m2);
+    else MFVIT_LAUNCH(bn_stats_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)x, n, C, mean, m2);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
 int mfvit_bn_combine(const float* means, const float* m2s, const float* counts, int W, int C, float eps, float momentum, float* mean,
                      float* invstd, float* running_mean, float* running_var, mfvit_stream_t stream) {
     if (!means || !m2s || !counts || !mean || !invstd || W <= 0) return MFVIT_EINVAL;
-    hipLaunchKernelGGL(bn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, means, m2s, counts, W, C, eps, momentum,
+    MFVIT_LAUNCH(bn_combine_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, means, m2s, counts, W, C, eps, momentum,
                        mean, invstd, running_mean, running_var);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -207,8 +207,8 @@ int mfvit_bn_apply(int dtype, const void* x, const float* mean, const float* inv
     const long total = (long)n * C;
     const dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFVIT_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, mean, invstd, gamma, beta, relu, (bf16*)y, total, C);
-    else hipLaunchKernelGGL(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, mean, invstd, gamma, beta, relu, (float*)y, total, C);
+    if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, mean, invstd, gamma, beta, relu, (bf16*)y, total, C);
+    else MFVIT_LAUNCH(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, mean, invstd, gamma, beta, relu, (float*)y, total, C);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -216,8 +216,8 @@ int mfvit_bn_bwd_sums(int dtype, const void* dy, const void* x, const void* y, c
                       int C, float* s1, float* s2, mfvit_stream_t stream) {
     if (!dy || !x || !mean || !invstd || !s1 || !s2 || (relu && !y)) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFVIT_BF16) hipLaunchKernelGGL(bn_bwd_sums_kernel<bf16>, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, relu, n, C, s1, s2);
-    else hipLaunchKernelGGL(bn_bwd_sums_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, relu, n, C, s1, s2);
+    if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_bwd_sums_kernel<bf16>, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, relu, n, C, s1, s2);
+    else MFVIT_LAUNCH(bn_bwd_sums_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, relu, n, C, s1, s2);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -227,26 +227,26 @@ int mfvit_bn_bwd_apply(int dtype, const void* dy, const void* x, const void* y, 
     const long total = (long)n * C;
     const dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MFVIT_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, gamma, relu, S1, S2, inv_count, (bf16*)dx, total, C);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, gamma, relu, S1, S2, inv_count, (float*)dx, total, C);
+    if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, gamma, relu, S1, S2, inv_count, (bf16*)dx, total, C);
+    else MFVIT_LAUNCH(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, gamma, relu, S1, S2, inv_count, (float*)dx, total, C);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
 int mfvit_l2norm_fwd(const float* x, float* y, float* inv_norm, int n, int C, float eps, mfvit_stream_t stream) {
     if (!x || !y || !inv_norm) return MFVIT_EINVAL;
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, inv_norm, n, C, eps);
+    MFVIT_LAUNCH(l2norm_fwd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, inv_norm, n, C, eps);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
 int mfvit_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, float* dx, int n, int C, mfvit_stream_t stream) {
     if (!dy || !y || !inv_norm || !dx) return MFVIT_EINVAL;
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, inv_norm, dx, n, C);
+    MFVIT_LAUNCH(l2norm_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, inv_norm, dx, n, C);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
 int mfvit_rowdot(const float* a, const float* b, float* out, int64_t ldo, float scale, int n, int C, mfvit_stream_t stream) {
     if (!a || !b || !out) return MFVIT_EINVAL;
-    hipLaunchKernelGGL(rowdot_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)ldo, scale, n, C);
+    MFVIT_LAUNCH(rowdot_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)ldo, scale, n, C);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -255,7 +255,7 @@ int mfvit_cross_entropy_rows(const float* logits, int64_t ld, const int64_t* tar
     if (!logits || !target || !loss_mean || n <= 0 || C <= 0) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(loss_mean, 0, sizeof(float), st) != hipSuccess) return MFVIT_ELAUNCH;
-    hipLaunchKernelGGL(ce_rows_kernel, dim3(n), dim3(256), 0, st, logits, (long)ld, (const long*)target, loss_mean, lse, dlogits, (long)ldd,
+    MFVIT_LAUNCH(ce_rows_kernel, dim3(n), dim3(256), 0, st, logits, (long)ld, (const long*)target, loss_mean, lse, dlogits, (long)ldd,
                        1.0f / (float)n, C);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -264,7 +264,7 @@ int mfvit_ema_update(float* dst, const float* src, float m, int64_t n, mfvit_str
     if (!dst || !src || n <= 0) return MFVIT_EINVAL;
     const long n4 = ((uintptr_t)dst % 16 == 0 && (uintptr_t)src % 16 == 0) ? n / 4 : 0;
     const long threads = n4 + (n - n4 * 4);
-    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, m, n4, (long)n);
+    MFVIT_LAUNCH(ema_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst, src, m, n4, (long)n);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

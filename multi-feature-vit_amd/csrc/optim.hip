@@ -99,9 +99,9 @@ int mfvit_lars_step(const int64_t* table, int nchunks, int ntensors, float* norm
     if (!table || !norms || nchunks <= 0 || ntensors <= 0) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(norms, 0, sizeof(float) * 2 * ntensors, st) != hipSuccess) return MFVIT_ELAUNCH;
-    hipLaunchKernelGGL(lars_norms_kernel, dim3(nchunks), dim3(256), 0, st, (const long*)table, weight_decay, norms);
+    MFVIT_LAUNCH(lars_norms_kernel, dim3(nchunks), dim3(256), 0, st, (const long*)table, weight_decay, norms);
     MFVIT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(lars_update_kernel, dim3(nchunks), dim3(256), 0, st, (const long*)table, norms, lr, weight_decay, momentum,
+    MFVIT_LAUNCH(lars_update_kernel, dim3(nchunks), dim3(256), 0, st, (const long*)table, norms, lr, weight_decay, momentum,
                        trust_coefficient);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -111,7 +111,7 @@ int mfvit_adam_step(const int64_t* table, int nchunks, float lr, float beta1, fl
     if (!table || nchunks <= 0 || step <= 0) return MFVIT_EINVAL;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, lr, beta1, beta2, eps, weight_decay,
+    MFVIT_LAUNCH(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, lr, beta1, beta2, eps, weight_decay,
                        bc1, bc2s);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -119,7 +119,7 @@ int mfvit_adam_step(const int64_t* table, int nchunks, float lr, float beta1, fl
 int mfvit_sgd_step(const int64_t* table, int nchunks, float lr, float momentum, float weight_decay, int first_step,
                    mfvit_stream_t stream) {
     if (!table || nchunks <= 0) return MFVIT_EINVAL;
-    hipLaunchKernelGGL(sgd_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, lr, momentum, weight_decay, first_step);
+    MFVIT_LAUNCH(sgd_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, lr, momentum, weight_decay, first_step);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

@@ -5,6 +5,10 @@ to run on a non-GPU tensor, a RuntimeError is raised.
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  MUST precede loading libmfvit_hip.so: torch bundles its own libamdhip64.so.7 / libhsa-runtime64;
+#                      whichever copy of that SONAME is mapped first serves the whole process, and mixing the system
+#                      runtime with torch's bundled HSA layer leaves the extension with "no ROCm-capable device"
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

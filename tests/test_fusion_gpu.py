@@ -133,3 +133,22 @@ def test_fus_crossvit_end_to_end_against_reference_golden():
     assert output.argmax(1).cpu().tolist() == g["preds"].tolist()
     for k, p in model.named_parameters():
         check_sampled(g, "d." + k, p.grad, rtol=2e-3, atol=2e-3 * float(g[f"d.{k}.abssum"]) / p.numel())
+
+
+def test_two_rank_data_parallel_step_rehearsal():
+    """N = 2 rehearsal of bench.py's data-parallel path on ONE GPU (gloo backend, both ranks on cuda:0): rendezvous, per-block
+    asynchronous gradient all-reduce from the encoder backward hooks, flat exchange of the fusion gradients, max-over-ranks
+    timing, one JSON line from rank 0.  (RCCL itself needs one GPU per rank; the driver runs that at round end.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MFVIT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "4", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["value"] > 0 and np.isfinite(j["loss"])
