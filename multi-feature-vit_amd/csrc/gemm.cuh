@@ -74,15 +74,17 @@ template <int R, int BKB> struct KTile<float, R, BKB> {
 template <typename T, int R, int BKB, int NT> struct KStage {
     typedef KTile<T, R, BKB> Tile;
     static constexpr int CPR = BKB / 16;
-    static constexpr int NCH = R * CPR / NT;
+    static constexpr int TOTAL = R * CPR;
+    static constexpr int NCH = (TOTAL + NT - 1) / NT;
     static constexpr int EPC = 16 / sizeof(T);  // elements per chunk
-    static_assert(R * CPR % NT == 0, "tile chunks must divide over the block");
+    static_assert(TOTAL % NT == 0 || TOTAL < NT, "tile chunks must divide over the block (or fit in one pass)");
     uint4 reg[NCH];
     // rows >= rmax are clamped (their products are never stored)
     __device__ __forceinline__ void load(const T* base, long ld, int row0, int rmax, int k0, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int q = tid + i * NT, row = q / CPR, c = q % CPR;
+            if (TOTAL < NT && q >= TOTAL) continue;
             int gr = row0 + row;
             gr = gr < rmax ? gr : rmax - 1;
             reg[i] = *(const uint4*)(base + (long)gr * ld + k0 + c * EPC);
@@ -92,6 +94,7 @@ template <typename T, int R, int BKB, int NT> struct KStage {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int q = tid + i * NT, row = q / CPR, c = q % CPR;
+            if (TOTAL < NT && q >= TOTAL) continue;
             Tile::put(t, row, c, reg[i]);
         }
     }

@@ -169,25 +169,32 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
             gj[j] = p.gamma[ncol[j]];
             btj[j] = p.beta[ncol[j]];
         }
+        // pass A: v = acc + bias + residual.  LOADS ONLY (restrict-qualified, no store in this loop) so that the 48 residual
+        // loads of a lane are all in flight together; the stores come in pass C.
+        const float* __restrict__ resp = p.res;
         float part[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + acc_row(r, lane);
-                const bool ok = m < p.M;
-                const int mm = ok ? m : p.M - 1;
-                const int orow = out_row(p, mm);
-                const long rrow = p.res_mod ? (mm % p.res_mod) + p.res_off : orow;
+                const int mm = m < p.M ? m : p.M - 1;
+                const long rrow = p.res_mod ? (mm % p.res_mod) + p.res_off : out_row(p, mm);
+                if (resp) {       // branch hoisted out of the j loop: hipcc serialises loads that sit in their own basic block
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j][r] += bj[j] + resp[rrow * p.ldres + ncol[j]];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j][r] += bj[j];
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float v = acc[i][j][r] + bj[j];
-                    if (p.res) v += p.res[rrow * p.ldres + ncol[j]];
-                    acc[i][j][r] = v;
-                    if (p.out0) ((float*)p.out0)[(long)orow * p.ldo0 + ncol[j]] = v;
-                    s += v;
-                }
+                for (int j = 0; j < TN; ++j) s += acc[i][j][r];
                 part[i][r] = s;
             }
         row_reduce<TM>(part, red, tot, lane, wm, wn, tid);
@@ -206,31 +213,40 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
                 part[i][r] = s;
             }
         row_reduce<TM>(part, red, tot, lane, wm, wn, tid);
+        // pass C: stores only (x_out f32, y, statistics); padded rows replicate row M-1 -> identical duplicate stores
+        float* __restrict__ xo = (float*)p.out0;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int mraw = m0 + (wm * TM + i) * 32 + acc_row(r, lane);
-                const int m = mraw < p.M ? mraw : p.M - 1;   // duplicates of row M-1 store identical values
+                const int m = mraw < p.M ? mraw : p.M - 1;
                 const int orow = out_row(p, m);
                 const float rs = rsqrtf(part[i][r] * invN + p.eps);
                 if (wn == 0 && (lane & 31) == 0 && p.mean) {
                     p.mean[orow] = mu[i][r];
                     p.rstd[orow] = rs;
                 }
+                if (xo) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const float y = (acc[i][j][r] - mu[i][r]) * rs * gj[j] + btj[j];
-                    if (p.y_f32)
-                        ((float*)p.out1)[(long)orow * p.ldo1 + ncol[j]] = y;
-                    else
-                        ((T*)p.out1)[(long)orow * p.ldo1 + ncol[j]] = from_f32<T>(y);
+                    for (int j = 0; j < TN; ++j) xo[(long)orow * p.ldo0 + ncol[j]] = acc[i][j][r];
+                }
+                if (p.y_f32) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        ((float*)p.out1)[(long)orow * p.ldo1 + ncol[j]] = (acc[i][j][r] - mu[i][r]) * rs * gj[j] + btj[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        ((T*)p.out1)[(long)orow * p.ldo1 + ncol[j]] = from_f32<T>((acc[i][j][r] - mu[i][r]) * rs * gj[j] + btj[j]);
                 }
             }
     } else {  // REPI_LNBWD_RES: acc = dL/dy (y = LN output); aux = saved LN input x (f32)
         float gj[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) gj[j] = p.gamma[ncol[j]];
+        const float* __restrict__ auxp = (const float*)p.aux;
+        const float* __restrict__ resp = p.res;
         f32x16 xh[TM][TN];
         float p1[TM][16], p2[TM][16], rsv[TM][16];
         float cs_g[TN], cs_b[TN], cs_x[TN];
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const float x = ((const float*)p.aux)[(long)mm * p.ldaux + ncol[j]];
+                    const float x = auxp[(long)mm * p.ldaux + ncol[j]];
                     const float h = (x - mu) * rs;
                     const float dy = acc[i][j][r];      // padded rows replicate row M-1; only the column sums mask them
                     xh[i][j][r] = h;
@@ -271,13 +287,30 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
                 const bool ok = mraw < p.M;
                 const int m = ok ? mraw : p.M - 1;
                 const float c1 = p1[i][r] * invN, c2 = p2[i][r] * invN, rs = rsv[i][r];
+                if (resp) {                      // loads only: dx (+ residual gradient) back into acc
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float dx = rs * (acc[i][j][r] * gj[j] - c1 - xh[i][j][r] * c2);
-                    if (p.res) dx += p.res[(long)m * p.ldres + ncol[j]];
-                    ((float*)p.out0)[(long)m * p.ldo0 + ncol[j]] = dx;
-                    if (p.out1) ((T*)p.out1)[(long)m * p.ldo1 + ncol[j]] = from_f32<T>(dx);
-                    cs_x[j] += ok ? dx : 0.f;
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j][r] = rs * (acc[i][j][r] * gj[j] - c1 - xh[i][j][r] * c2) + resp[(long)m * p.ldres + ncol[j]];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j][r] = rs * (acc[i][j][r] * gj[j] - c1 - xh[i][j][r] * c2);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) cs_x[j] += ok ? acc[i][j][r] : 0.f;
+            }
+        float* __restrict__ dxo = (float*)p.out0;
+        T* __restrict__ dxt = (T*)p.out1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {       // stores only
+                const int mraw = m0 + (wm * TM + i) * 32 + acc_row(r, lane);
+                const int m = mraw < p.M ? mraw : p.M - 1;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) dxo[(long)m * p.ldo0 + ncol[j]] = acc[i][j][r];
+                if (dxt) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) dxt[(long)m * p.ldo1 + ncol[j]] = from_f32<T>(acc[i][j][r]);
                 }
             }
 #pragma unroll
@@ -438,6 +471,7 @@ template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_
     const int v = row_variant();
     if (v == 0 || p.K % (128 / (int)sizeof(T))) return launch_row_v<T, REPI, 1, 64>(p, st);
     if (v == 1) return launch_row_v<T, REPI, 1, 128>(p, st);
+    if (v == 3) return launch_row_v<T, REPI, 2, 64>(p, st);
     return launch_row_v<T, REPI, 2, 128>(p, st);
 }
 template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
