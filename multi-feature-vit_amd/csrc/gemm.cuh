@@ -141,18 +141,21 @@ template <typename T, int R, int KR, int NT> struct SStage {
     static_assert(KR * CPRW % NT == 0, "tile chunks must divide over the block");
     uint4 reg[NCH];
     // m rows >= mmax are zero-filled (they would otherwise add into the reduction)
-    // (rin, rout, roff): optional row remap  m -> (m / rin) * rout + m % rin + roff  (patch rows -> token rows)
+    // BRANCH-FREE (a load in its own basic block gets a vmcnt(0) behind it): out-of-range rows are clamped for the load and
+    // zeroed by a select.  REMAP: row m -> (m / rin) * rout + m % rin + roff  (patch rows -> token rows), compile-time switch.
+    template <bool REMAP>
     __device__ __forceinline__ void load(const T* base, long ld, int m0, int mmax, int c0, int tid, int rin = 0, int rout = 0,
                                          int roff = 0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int q = tid + i * NT, m = q / CPRW, c = q % CPRW;
             const int mm = m0 + m;
-            const long gr = rin ? (long)(mm / rin) * rout + (mm % rin) + roff : mm;
-            if (mm < mmax)
-                reg[i] = *(const uint4*)(base + gr * ld + c0 + c * EPC);
-            else
-                reg[i] = make_uint4(0, 0, 0, 0);
+            const bool ok = mm < mmax;
+            const int mc = ok ? mm : mmax - 1;
+            long gr = mc;
+            if (REMAP) gr = (long)(mc / rin) * rout + (mc % rin) + roff;
+            const uint4 v = *(const uint4*)(base + gr * ld + c0 + c * EPC);
+            reg[i] = ok ? v : make_uint4(0, 0, 0, 0);
         }
     }
     __device__ __forceinline__ void store(char* t, int tid) const {

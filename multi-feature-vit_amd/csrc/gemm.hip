@@ -329,7 +329,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------- wgrad (TN)
-template <typename T>
+template <typename T, bool REMAP>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     // out0[n][k] (f32, atomicAdd) += sum_{m in split} A[m][n] * W[m][k];  p.N = n extent, p.K = k extent, p.M = reduction
     constexpr int BN = 128, BK2 = 128, NT = 256;
@@ -342,10 +342,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntk = p.K / BK2;
-    const int n0 = (blockIdx.x / ntk) * BN, k0 = (blockIdx.x % ntk) * BK2;
+    // XCD-aware placement (speed only): blocks are dealt round-robin over the 8 XCDs, each with a private L2.  All tiles of
+    // one m-split read the same dY / X rows, so a split's tiles are kept on ONE XCD (split = xcd + 8 * ...): the operands are
+    // then fetched into that L2 once and re-read from it by the other tiles instead of 3-12 times from HBM / Infinity Cache.
+    int tile = blockIdx.x, split = blockIdx.y;
+    if (gridDim.y == 1 && p.splits > 1) {          // 1-D launch: splits is a multiple of 8
+        const int tiles = ntk * (p.N / BN);
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        split = xcd + 8 * (loc / tiles);
+        tile = loc % tiles;
+    }
+    const int n0 = (tile / ntk) * BN, k0 = (tile % ntk) * BK2;
     int chunk = (p.M + p.splits - 1) / p.splits;
     chunk = (chunk + KR - 1) / KR * KR;
-    const int mbeg = blockIdx.y * chunk;
+    const int mbeg = split * chunk;
     const int mend = min(p.M, mbeg + chunk);
     if (mbeg >= mend) return;
     const T* A = (const T*)p.A;
@@ -375,8 +385,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
     const int nst = (mend - mbeg + KR - 1) / KR;
-    sa.load(A, p.lda, mbeg, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
-    sb.load(X, p.ldw, mbeg, mend, k0, tid);
+    sa.template load<REMAP>(A, p.lda, mbeg, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
+    sb.template load<false>(X, p.ldw, mbeg, mend, k0, tid);
     sa.store(lds, tid);
     sb.store(lds + TA::BYTES, tid);
     __syncthreads();
@@ -385,8 +395,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
         const char* ta = lds + cur * STAGE;
         const char* tb = ta + TA::BYTES;
         if (st + 1 < nst) {
-            sa.load(A, p.lda, mbeg + (st + 1) * KR, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
-            sb.load(X, p.ldw, mbeg + (st + 1) * KR, mend, k0, tid);
+            sa.template load<REMAP>(A, p.lda, mbeg + (st + 1) * KR, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
+            sb.template load<false>(X, p.ldw, mbeg + (st + 1) * KR, mend, k0, tid);
         }
 #pragma unroll
         for (int s = 0; s < TA::KSTEPS; ++s) {
@@ -484,15 +494,22 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
         const int maxs = (p.M + 4 * KR - 1) / (4 * KR);  // at least 4 stages per split
         p.splits = s < 1 ? 1 : (s > maxs ? maxs : s);
         if (p.splits < 1) p.splits = 1;
+        if (p.splits >= 8) p.splits = (p.splits + 4) / 8 * 8;   // multiple of 8 -> XCD-aware 1-D launch
     }
+    const bool xcd1d = p.splits >= 8 && p.splits % 8 == 0 && p.nb <= 1;
     constexpr int bytes = 2 * (STile<T, 128, KR>::BYTES * 2);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
     ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
-    MFVIT_LAUNCH((gemm_tn_kernel<T>), dim3(tiles, p.splits, p.nb > 1 ? p.nb : 1), dim3(256), bytes, st, p);
+    const dim3 grid = xcd1d ? dim3(tiles * p.splits, 1, 1) : dim3(tiles, p.splits, p.nb > 1 ? p.nb : 1);
+    if (p.orow_in)
+        MFVIT_LAUNCH((gemm_tn_kernel<T, true>), grid, dim3(256), bytes, st, p);
+    else
+        MFVIT_LAUNCH((gemm_tn_kernel<T, false>), grid, dim3(256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
