@@ -1,7 +1,7 @@
 // HBM-bound helper kernels of the encoder path (gfx950): patch gather, cls row, LayerNorm rows (fwd / bwd),
 // weight cast + transpose, small linear heads, small-C cross entropy.  All wave64, 16-B vector access where the
 // layout allows it.  Roofline for every kernel here: HBM bytes (each tensor touched once).
-#include "common.cuh"
+#include "kernels.h"
 
 namespace mfvit {
 
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ dres, long ldres,
                                                           float* __restrict__ dx, long lddx, T* __restrict__ dxT, long lddxT,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dcol,
-                                                          int rows, int row_stride, int row_off) {
+                                                          float* __restrict__ cpart, int rows, int row_stride, int row_off) {
     constexpr int N = NPL * 64;
     __shared__ float red[3][4][N];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -162,25 +162,33 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
         const float a = red[0][0][n] + red[0][1][n] + red[0][2][n] + red[0][3][n];
         const float b = red[1][0][n] + red[1][1][n] + red[1][2][n] + red[1][3][n];
         const float c = red[2][0][n] + red[2][1][n] + red[2][2][n] + red[2][3][n];
-        if (dgamma) atomicAdd(dgamma + n, a);
-        if (dbeta) atomicAdd(dbeta + n, b);
-        if (dcol) atomicAdd(dcol + n, c);
+        if (cpart) {   // per-block partials [block][3][N] (reduced by colpart_reduce): no contended atomics
+            cpart[((long)blockIdx.x * 3 + 0) * N + n] = a;
+            cpart[((long)blockIdx.x * 3 + 1) * N + n] = b;
+            cpart[((long)blockIdx.x * 3 + 2) * N + n] = c;
+        } else {
+            if (dgamma) atomicAdd(dgamma + n, a);
+            if (dbeta) atomicAdd(dbeta + n, b);
+            if (dcol) atomicAdd(dcol + n, c);
+        }
     }
 }
 int ln_bwd_rows(int dtype, int N, const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                 const float* gamma, const float* dres, long ldres, float* dx, long lddx, void* dxT, long lddxT, float* dgamma, float* dbeta,
-                float* dcol, int rows, int row_stride, int row_off, hipStream_t st) {
+                float* dcol, float* cpart, int rows, int row_stride, int row_off, hipStream_t st) {
     if (rows <= 0) return MFVIT_OK;
     int blocks = (rows + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    const int cap = cpart ? 256 : 1024;
+    if (blocks > cap) blocks = cap;
 #define MFVIT_LNB(TT, NPL)                                                                                                         \
     MFVIT_LAUNCH((ln_bwd_rows_kernel<TT, NPL>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres, ldres, dx, \
-                       lddx, (TT*)dxT, lddxT, dgamma, dbeta, dcol, rows, row_stride, row_off)
+                       lddx, (TT*)dxT, lddxT, dgamma, dbeta, dcol, cpart, rows, row_stride, row_off)
     if (N == 384) { if (dtype == MFVIT_BF16) MFVIT_LNB(bf16, 6); else MFVIT_LNB(float, 6); }
     else if (N == 768) { if (dtype == MFVIT_BF16) MFVIT_LNB(bf16, 12); else MFVIT_LNB(float, 12); }
     else return MFVIT_EINVAL;
 #undef MFVIT_LNB
     MFVIT_CHECK_LAUNCH();
+    if (cpart) return colpart_reduce(cpart, blocks, N, 3, dgamma, dbeta, dcol, st);
     return MFVIT_OK;
 }
 

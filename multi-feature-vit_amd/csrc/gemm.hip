@@ -32,7 +32,12 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
     const int bid = xcd_remap(blockIdx.x, ntn * ntm);
     const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
     f32x16 acc[Loop::TM][Loop::TN];
-    Loop::run(p, m0, n0, lds, acc);
+    if constexpr (sizeof(T) == 2) {
+        if (p.y_f32 == 99) NtLoopGlds<BM, BN, WM, WN, 4>::run(p, m0, n0, lds, acc);   // LDS-DMA main loop (bf16)
+        else Loop::run(p, m0, n0, lds, acc);
+    } else {
+        Loop::run(p, m0, n0, lds, acc);
+    }
 
     // ---- epilogue through LDS: per-element math in registers -> [128][128 + pad] tile in LDS -> 16-byte coalesced stores.
     // Rows >= M replicate row M-1 exactly (the A loads are clamped), so they are stored as identical duplicates: no branches.
@@ -65,9 +70,10 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
         }
         __syncthreads();
     }
-    float bj[Loop::TN];
+    float bj[Loop::TN], csums[Loop::TN];
 #pragma unroll
     for (int j = 0; j < Loop::TN; ++j) {
+        csums[j] = 0.f;
         const int n = n0 + (wn * Loop::TN + j) * 32 + (lane & 31);
         bj[j] = ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.bias) ? p.bias[n] : 0.f;
     }
@@ -94,10 +100,21 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
             }
         if (EPI == EPI_GELU_BWD && p.cs0) {
             csum += __shfl_xor(csum, 32, 64);
-            if (lane < 32) atomicAdd(p.cs0 + n0 + (wn * Loop::TN + j) * 32 + lane, csum);
+            if (p.cpart) csums[j] = csum;
+            else if (lane < 32) atomicAdd(p.cs0 + n0 + (wn * Loop::TN + j) * 32 + lane, csum);
         }
     }
     store_tile(p.out0, p.ldo0);
+    if (EPI == EPI_GELU_BWD && p.cs0 && p.cpart) {   // per-workgroup partial column sums: [m-tile][N], plain stores
+        __syncthreads();
+        float* sc = (float*)tile;                       // [WM][BN]
+        if (lane < 32) {
+#pragma unroll
+            for (int j = 0; j < Loop::TN; ++j) sc[wm * BN + (wn * Loop::TN + j) * 32 + lane] = csums[j];
+        }
+        __syncthreads();
+        if (tid < BN) p.cpart[(long)(m0 / BM) * p.N + n0 + tid] = sc[tid] + sc[BN + tid];
+    }
     if (EPI == EPI_BIAS_GELU) {
         __syncthreads();
 #pragma unroll
@@ -313,6 +330,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
                     for (int j = 0; j < TN; ++j) dxt[(long)m * p.ldo1 + ncol[j]] = from_f32<T>(acc[i][j][r]);
                 }
             }
+        if (p.cpart) __syncthreads();                  // red / tot are free again; reuse as [WM][3][BN] scratch
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float a = cs_g[j], b = cs_b[j], c = cs_x[j];
@@ -320,9 +338,24 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
             b += __shfl_xor(b, 32, 64);
             c += __shfl_xor(c, 32, 64);
             if (lane < 32) {
-                if (p.cs0) atomicAdd(p.cs0 + ncol[j], a);
-                if (p.cs1) atomicAdd(p.cs1 + ncol[j], b);
-                if (p.cs2) atomicAdd(p.cs2 + ncol[j], c);
+                if (p.cpart) {
+                    red[(wm * 3 + 0) * BN + ncol[j]] = a;
+                    red[(wm * 3 + 1) * BN + ncol[j]] = b;
+                    red[(wm * 3 + 2) * BN + ncol[j]] = c;
+                } else {
+                    if (p.cs0) atomicAdd(p.cs0 + ncol[j], a);
+                    if (p.cs1) atomicAdd(p.cs1 + ncol[j], b);
+                    if (p.cs2) atomicAdd(p.cs2 + ncol[j], c);
+                }
+            }
+        }
+        if (p.cpart) {                                 // per-workgroup partials [block][3][384], plain coalesced stores
+            __syncthreads();
+            for (int q = tid; q < 3 * BN; q += WM * 256) {
+                float s = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WM; ++w2) s += red[w2 * 3 * BN + q];
+                p.cpart[(long)blockIdx.x * 3 * BN + q] = s;
             }
         }
     }
@@ -442,9 +475,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------- launchers
-template <typename T, int EPI> static int launch_tile(const GemmP& p, hipStream_t st) {
+template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStream_t st) {
     typedef NtLoop<T, 128, 128, 128, 2, 2> Loop;
+    GemmP p = pin;
     if (p.N % 128 || p.K % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
+    static const int use_glds = [] { const char* e = getenv("MFVIT_GLDS"); return e ? atoi(e) : 0; }();
+    if (sizeof(T) == 2 && use_glds) p.y_f32 = 99;
     const int nwg = (p.N / 128) * ((p.M + 127) / 128);
     constexpr int epi_bytes = 128 * (128 * (int)sizeof(T) + 16);
     constexpr int lds_bytes = Loop::LDS_BYTES > epi_bytes ? Loop::LDS_BYTES : epi_bytes;
@@ -514,10 +550,41 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
     return MFVIT_OK;
 }
 
+// dst_q[c] += sum_g part[g][q * ncols + c]  for q < nq.  Grid: (column groups of 64) x (chunks of 32 partial rows); every block
+// adds its chunk sum with one atomic per column, so an address sees G / 32 adds instead of G.
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int G, int ncols, int nq, float* d0, float* d1,
+                                                             float* d2) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int g0 = blockIdx.y * 32;
+    __shared__ float sm[4][64];
+    float s = 0.f;
+    if (c < nq * ncols) {
+        const int g1 = g0 + 32 < G ? g0 + 32 : G;
+        for (int g2 = g0 + sub; g2 < g1; g2 += 4) s += part[(long)g2 * nq * ncols + c];
+    }
+    sm[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < nq * ncols) {
+        s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+        float* d = c / ncols == 0 ? d0 : (c / ncols == 1 ? d1 : d2);
+        if (d) atomicAdd(d + c % ncols, s);
+    }
+}
+int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float* d1, float* d2, hipStream_t st) {
+    MFVIT_LAUNCH(colpart_reduce_kernel, dim3((nq * ncols + 63) / 64, (G + 31) / 32), dim3(256), 0, st, part, G, ncols, nq, d0, d1, d2);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
 #define MFVIT_TILE_CASE(E)                                              \
     case E:                                                             \
         return dtype == MFVIT_BF16 ? launch_tile<bf16, E>(p, st) : launch_tile<float, E>(p, st);
+    if (epi == EPI_GELU_BWD && p.cpart && p.cs0) {
+        const int rc = dtype == MFVIT_BF16 ? launch_tile<bf16, EPI_GELU_BWD>(p, st) : launch_tile<float, EPI_GELU_BWD>(p, st);
+        if (rc != MFVIT_OK) return rc;
+        return colpart_reduce(p.cpart, (p.M + 127) / 128, p.N, 1, p.cs0, nullptr, nullptr, st);
+    }
     switch (epi) {
         MFVIT_TILE_CASE(EPI_BIAS)
         MFVIT_TILE_CASE(EPI_BIAS_GELU)
@@ -529,7 +596,11 @@ int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
 }
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
     if (repi == REPI_RES_LN) return dtype == MFVIT_BF16 ? launch_row<bf16, REPI_RES_LN>(p, st) : launch_row<float, REPI_RES_LN>(p, st);
-    if (repi == REPI_LNBWD_RES) return dtype == MFVIT_BF16 ? launch_row<bf16, REPI_LNBWD_RES>(p, st) : launch_row<float, REPI_LNBWD_RES>(p, st);
+    if (repi == REPI_LNBWD_RES) {
+        const int rc = dtype == MFVIT_BF16 ? launch_row<bf16, REPI_LNBWD_RES>(p, st) : launch_row<float, REPI_LNBWD_RES>(p, st);
+        if (rc != MFVIT_OK || !p.cpart) return rc;
+        return colpart_reduce(p.cpart, (p.M + ROW_BM - 1) / ROW_BM, ROW_BN, 3, p.cs0, p.cs1, p.cs2, st);
+    }
     return MFVIT_EINVAL;
 }
 int gemm_tn(int dtype, const GemmP& p, hipStream_t st) {

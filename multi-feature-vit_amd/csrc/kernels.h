@@ -10,6 +10,7 @@ enum { REPI_RES_LN = 0, REPI_LNBWD_RES = 1 };
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st);
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st);
 int gemm_tn(int dtype, const GemmP& p, hipStream_t st);
+int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float* d1, float* d2, hipStream_t st);
 
 int attn_fwd_exact(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HD, hipStream_t st);
 int attn_bwd_exact(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
@@ -25,7 +26,7 @@ int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long
             int in0_bcast, hipStream_t st);
 int ln_bwd_rows(int dtype, int N, const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                 const float* gamma, const float* dres, long ldres, float* dx, long lddx, void* dxT, long lddxT, float* dgamma, float* dbeta,
-                float* dcol, int rows, int row_stride, int row_off, hipStream_t st);
+                float* dcol, float* cpart, int rows, int row_stride, int row_off, hipStream_t st);
 int cast_transpose(int dtype, const float* src, void* dst, void* dstT, int R, int C, hipStream_t st);
 int cast_transpose_batched(int dtype, const float* src, void* dst, void* dstT, int R, int C, int nb, long s_src, long s_dst, long s_dstT,
                            hipStream_t st);

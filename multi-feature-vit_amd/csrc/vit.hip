@@ -113,7 +113,7 @@ struct WsLayout {
     size_t blk0, blk_stride;    // per block (depth or 1 copies):
     size_t y1, qkv, attn, lse, xmid, st2, y2, hpre, hact;
     // backward scratch
-    size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch;
+    size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart;
     size_t total;
 };
 WsLayout ws_layout(const Dims& d) {
@@ -146,8 +146,14 @@ WsLayout ws_layout(const Dims& d) {
         W.dattn = o; o += align256(M * D * es);
         W.dqkv = o; o += align256(M * 3 * D * es);
         W.colscratch = o; o += align256(2 * D * 4);
+        {   // per-workgroup column-sum partials: max over the kernels that use them
+            size_t a = ((M + 63) / 64) * 3 * D, b2 = ((M + 127) / 128) * F, c2 = 256 * 3 * D;
+            size_t n = a > b2 ? a : b2;
+            n = n > c2 ? n : c2;
+            W.colpart = o; o += align256(n * 4);
+        }
     } else {
-        W.gx = W.gmid = W.gxT = W.gmidT = W.dhpre = W.dattn = W.dqkv = W.colscratch = o;
+        W.gx = W.gmid = W.gxT = W.gmidT = W.dhpre = W.dattn = W.dqkv = W.colscratch = W.colpart = o;
     }
     W.total = o;
     return W;
@@ -340,14 +346,15 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
     void* gxT = ws + W.gxT;
     void* gmidT = ws + W.gmidT;
     float* colscr = (float*)(ws + W.colscratch);
+    float* colpart = (float*)(ws + W.colpart);
 
     for (int s = stage_hi; s >= stage_lo; --s) {
         if (s == d.depth) {
             // final LayerNorm backward: dfeatures -> gx (grad of x_depth); dcol = d fc2_b of the last block
             if (!dfeatures) return MFVIT_EINVAL;
             MFVIT_TRY(ln_bwd_rows(d.dtype, d.D, dfeatures, D, xbuf(d.depth), D, stat(d.depth), stat(d.depth) + d.M, params + L.norm_w,
-                                  nullptr, 0, gx, D, gxT, D, dparams + L.norm_w, dparams + L.norm_b, gblk(d.depth - 1) + L.fc2_b, d.M, 1,
-                                  0, st));
+                                  nullptr, 0, gx, D, gxT, D, dparams + L.norm_w, dparams + L.norm_b, gblk(d.depth - 1) + L.fc2_b, colpart,
+                                  d.M, 1, 0, st));
         } else if (s >= 0) {
             const int l = s;
             char* b = blk(l);
@@ -367,7 +374,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.M = d.M; p.N = d.F; p.K = d.D;
                 p.aux = b + W.hpre; p.ldaux = F;
                 p.out0 = ws + W.dhpre; p.ldo0 = F;
-                p.cs0 = gb + L.fc1_b;
+                p.cs0 = gb + L.fc1_b; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_GELU_BWD, p, st));
             }
             {   // dW1 += dhpre^T y2
@@ -386,7 +393,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.gamma = pb + L.ln2_w;
                 p.res = gx; p.ldres = D;
                 p.out0 = gmid; p.ldo0 = D; p.out1 = gmidT; p.ldo1 = D;
-                p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = gb + L.proj_b;
+                p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = gb + L.proj_b; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
             {   // dWproj += gmid^T attn
@@ -423,7 +430,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.gamma = pb + L.ln1_w;
                 p.res = gmid; p.ldres = D;
                 p.out0 = gx; p.ldo0 = D; p.out1 = gxT; p.ldo1 = D;
-                p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = l > 0 ? gblk(l - 1) + L.fc2_b : colscr;
+                p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = l > 0 ? gblk(l - 1) + L.fc2_b : colscr; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
         } else {
@@ -507,7 +514,7 @@ int mfvit_layernorm_bwd(int dtype, const float* dy, const float* x, const float*
                         const float* dres, float* dx, void* dx_t, float* dgamma, float* dbeta, float* dcol, int rows, int N,
                         mfvit_stream_t stream) {
     if (!dy || !x || !mean || !rstd || !gamma) return MFVIT_EINVAL;
-    return ln_bwd_rows(dtype, N, dy, N, x, N, mean, rstd, gamma, dres, N, dx, N, dx_t, N, dgamma, dbeta, dcol, rows, 1, 0,
+    return ln_bwd_rows(dtype, N, dy, N, x, N, mean, rstd, gamma, dres, N, dx, N, dx_t, N, dgamma, dbeta, dcol, nullptr, rows, 1, 0,
                        (hipStream_t)stream);
 }
 int mfvit_cast_transpose(int dtype, const float* src, void* dst, void* dst_t, int R, int C, mfvit_stream_t stream) {

@@ -22,3 +22,8 @@ for K in (64, 128, 384, 768, 1536):
 y = torch.empty(M, D, device=dev)
 timeit(lambda: ops.layernorm_fwd(res, g, be, 1e-6, out_dtype=torch.bfloat16), "plain LN rows f32->bf16 (58 MB)")
 timeit(lambda: torch.add(res, res, out=y), "torch add f32 (116 MB)")
+mean, rstd = torch.zeros(M, device=dev), torch.ones(M, device=dev)
+for K in (64, 384, 1152, 1536):
+    dy, wt = r(M, K), r(D, K, sc=.05)
+    timeit(lambda: ops.linear_dgrad_ln_bwd(dy, wt, res, mean, rstd, g, res), f"row_bwd K={K}")
+    timeit(lambda: ops.linear_dgrad_ln_bwd(dy, wt, res, mean, rstd, g, None, want_copy=False), f"row_bwd K={K} no-res no-copy")
