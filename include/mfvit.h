@@ -156,6 +156,17 @@ int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, cons
                           float* dparams, float* df_cxr, float* df_enh, float* dhw_cxr, float* dhb_cxr, float* dhw_enh, float* dhb_enh,
                           mfvit_stream_t stream);
 
+/* Stand-alone PreNorm(CrossAttention) (MOD:15-21,108-137): out[b] = proj(attn(LN_1e-5([x_own[b,0] ; x_oth[b,1:]]))) -> (B, dim).
+ * params = one block [norm.weight, norm.bias, fn.wq.weight, fn.wk.weight, fn.wv.weight, fn.proj.weight, fn.proj.bias]
+ * (4 D^2 + 3 D floats).  x_own == x_oth reproduces PreNorm(dim, CrossAttention(...))(x) exactly.  cfg: batch, tokens, dim 384,
+ * heads 3, eps_pre; workspace of mfvit_fusion_workspace_bytes(cfg).  Backward: dparams accumulated; dx_own receives row 0 only,
+ * dx_oth rows 1.. only (the caller zero-fills both), or both NULL. */
+int mfvit_prenorm_xattn_forward(const mfvit_fusion_cfg* cfg, const float* params, const float* x_own, const float* x_oth,
+                                void* workspace, float* out, mfvit_stream_t stream);
+int mfvit_prenorm_xattn_backward(const mfvit_fusion_cfg* cfg, const float* params, const float* x_own, const float* x_oth,
+                                 void* workspace, const float* dout, float* dparams, float* dx_own, float* dx_oth,
+                                 mfvit_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Opt-in kernel timing (HIP events on the launch stream), used by bench.py for the roofline of the dominant kernel.
  * Classes: 0 gemm_nt_tile 1 gemm_nt_row_res_ln 2 gemm_nt_row_lnbwd 3 gemm_tn_wgrad 4 attention_fwd 5 attention_bwd

@@ -446,10 +446,66 @@ bool fus_ok(const mfvit_fusion_cfg* c) {
 
 }  // namespace
 
+static int xattn_core_backward(int ndir, const FusLayout& L, const FusWs& W, const float* params, const float* f_cxr, const float* f_enh,
+                               float* ws, int B, int T, float* dparams, float* df_cxr, float* df_enh, hipStream_t st);
+
 extern "C" {
 
 size_t mfvit_fusion_param_count(const mfvit_fusion_cfg* cfg) { return fus_ok(cfg) ? (size_t)fus_layout(cfg->num_classes).total : 0; }
 size_t mfvit_fusion_workspace_bytes(const mfvit_fusion_cfg* cfg) { return fus_ok(cfg) ? (size_t)fus_ws(cfg->batch, cfg->tokens).total * 4 : 0; }
+
+// PreNorm -> CrossAttention of `ndir` directions up to the projection output outp[dir][b][D] (MOD:20,123-137)
+static int xattn_core_forward(int ndir, const FusLayout& L, const FusWs& W, const float* params, const float* f_cxr, const float* f_enh,
+                              float* ws, int B, int T, float eps_pre, hipStream_t st) {
+    const float scale = 1.0f / sqrtf((float)DH);
+    // transposed copies of wq, wk, wv, wp (used by kq here and by the backward)
+    for (int dir = 0; dir < ndir; ++dir) {
+        const long offs[4] = {L.wq, L.wk, L.wv, L.wp};
+        for (int k = 0; k < 4; ++k)
+            FUS_TRY(cast_transpose(MFVIT_F32, params + L.ca[dir] + offs[k], nullptr, ws + W.wT + ((long)dir * 4 + k) * D * D, D, D, st));
+    }
+    MFVIT_LAUNCH(x_cls_ln_kernel, dim3(B, ndir), dim3(64), 0, st, f_cxr, f_enh, params, L, eps_pre, B, T, ws + W.z0, ws + W.st0);
+    MFVIT_CHECK_LAUNCH();
+    {   // qv = z0 Wq^T
+        GemmP p = zg();
+        p.A = ws + W.z0; p.lda = D; p.W = params + L.ca[0] + L.wq; p.ldw = D; p.M = B; p.N = D; p.K = D;
+        p.out0 = ws + W.qv; p.ldo0 = D;
+        p.nb = ndir; p.nbi = 1; p.sAo = (long)B * D; p.sWo = L.ca_stride; p.sOo = (long)B * D;
+        FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
+    }
+    {   // kq_h = qv_h Wk_h  (W operand = WkT[:, h*128 ..])
+        GemmP p = zg();
+        p.A = ws + W.qv; p.lda = D; p.W = ws + W.wT + 1L * D * D; p.ldw = D; p.M = B; p.N = D; p.K = DH;
+        p.out0 = ws + W.kq; p.ldo0 = NH * D;
+        p.nb = ndir * NH; p.nbi = NH; p.sAo = (long)B * D; p.sAi = DH; p.sWo = 4L * D * D; p.sWi = DH; p.sOo = (long)B * NH * D; p.sOi = D;
+        FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
+    }
+    {
+        const size_t lds = (size_t)(5 * T + 4 * NH * D) * 4;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)x_stream_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        ProfScope ps(PROF_XATTN_FWD, 0, 2.0 * B * T * D * 4 * 2, st);
+        MFVIT_LAUNCH(x_stream_fwd_kernel, dim3(B, ndir), dim3(256), lds, st, f_cxr, f_enh, params, L, eps_pre, scale, B, T,
+                           ws + W.kq, ws + W.u, ws + W.a, ws + W.st);
+        MFVIT_CHECK_LAUNCH();
+    }
+    {   // o_h = u_h Wv_h^T
+        GemmP p = zg();
+        p.A = ws + W.u; p.lda = NH * D; p.W = params + L.ca[0] + L.wv; p.ldw = D; p.M = B; p.N = DH; p.K = D;
+        p.out0 = ws + W.o; p.ldo0 = D;
+        p.nb = ndir * NH; p.nbi = NH; p.sAo = (long)B * NH * D; p.sAi = D; p.sWo = L.ca_stride; p.sWi = (long)DH * D; p.sOo = (long)B * D; p.sOi = DH;
+        FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
+    }
+    {   // outp = o Wp^T + bp
+        GemmP p = zg();
+        p.A = ws + W.o; p.lda = D; p.W = params + L.ca[0] + L.wp; p.ldw = D; p.M = B; p.N = D; p.K = D;
+        p.bias = params + L.ca[0] + L.bp;
+        p.out0 = ws + W.outp; p.ldo0 = D;
+        p.nb = ndir; p.nbi = 1; p.sAo = (long)B * D; p.sWo = L.ca_stride; p.sOo = (long)B * D; p.sBo = L.ca_stride;
+        FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_BIAS, p, st));
+    }
+    return MFVIT_OK;
+}
 
 int mfvit_fusion_forward(const mfvit_fusion_cfg* cfg, const float* params, const float* f_cxr, const float* f_enh, const float* hw_cxr,
                          const float* hb_cxr, const float* hw_enh, const float* hb_enh, void* workspace, float* fused, float* x_cxr,
@@ -460,53 +516,7 @@ int mfvit_fusion_forward(const mfvit_fusion_cfg* cfg, const float* params, const
     const FusLayout L = fus_layout(C);
     const FusWs W = fus_ws(B, T);
     float* ws = (float*)workspace;
-    const float scale = 1.0f / sqrtf((float)DH);
-    // transposed copies of wq, wk, wv, wp (used by kq here and by the backward)
-    for (int dir = 0; dir < 2; ++dir) {
-        const long offs[4] = {L.wq, L.wk, L.wv, L.wp};
-        for (int k = 0; k < 4; ++k)
-            FUS_TRY(cast_transpose(MFVIT_F32, params + L.ca[dir] + offs[k], nullptr, ws + W.wT + ((long)dir * 4 + k) * D * D, D, D, st));
-    }
-    MFVIT_LAUNCH(x_cls_ln_kernel, dim3(B, 2), dim3(64), 0, st, f_cxr, f_enh, params, L, cfg->eps_pre, B, T, ws + W.z0, ws + W.st0);
-    MFVIT_CHECK_LAUNCH();
-    {   // qv = z0 Wq^T
-        GemmP p = zg();
-        p.A = ws + W.z0; p.lda = D; p.W = params + L.ca[0] + L.wq; p.ldw = D; p.M = B; p.N = D; p.K = D;
-        p.out0 = ws + W.qv; p.ldo0 = D;
-        p.nb = 2; p.nbi = 1; p.sAo = (long)B * D; p.sWo = L.ca_stride; p.sOo = (long)B * D;
-        FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
-    }
-    {   // kq_h = qv_h Wk_h  (W operand = WkT[:, h*128 ..])
-        GemmP p = zg();
-        p.A = ws + W.qv; p.lda = D; p.W = ws + W.wT + 1L * D * D; p.ldw = D; p.M = B; p.N = D; p.K = DH;
-        p.out0 = ws + W.kq; p.ldo0 = NH * D;
-        p.nb = 6; p.nbi = NH; p.sAo = (long)B * D; p.sAi = DH; p.sWo = 4L * D * D; p.sWi = DH; p.sOo = (long)B * NH * D; p.sOi = D;
-        FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
-    }
-    {
-        const size_t lds = (size_t)(5 * T + 4 * NH * D) * 4;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)x_stream_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        ProfScope ps(PROF_XATTN_FWD, 0, 2.0 * B * T * D * 4 * 2, st);
-        MFVIT_LAUNCH(x_stream_fwd_kernel, dim3(B, 2), dim3(256), lds, st, f_cxr, f_enh, params, L, cfg->eps_pre, scale, B, T,
-                           ws + W.kq, ws + W.u, ws + W.a, ws + W.st);
-        MFVIT_CHECK_LAUNCH();
-    }
-    {   // o_h = u_h Wv_h^T
-        GemmP p = zg();
-        p.A = ws + W.u; p.lda = NH * D; p.W = params + L.ca[0] + L.wv; p.ldw = D; p.M = B; p.N = DH; p.K = D;
-        p.out0 = ws + W.o; p.ldo0 = D;
-        p.nb = 6; p.nbi = NH; p.sAo = (long)B * NH * D; p.sAi = D; p.sWo = L.ca_stride; p.sWi = (long)DH * D; p.sOo = (long)B * D; p.sOi = DH;
-        FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
-    }
-    {   // outp = o Wp^T + bp
-        GemmP p = zg();
-        p.A = ws + W.o; p.lda = D; p.W = params + L.ca[0] + L.wp; p.ldw = D; p.M = B; p.N = D; p.K = D;
-        p.bias = params + L.ca[0] + L.bp;
-        p.out0 = ws + W.outp; p.ldo0 = D;
-        p.nb = 2; p.nbi = 1; p.sAo = (long)B * D; p.sWo = L.ca_stride; p.sOo = (long)B * D; p.sBo = L.ca_stride;
-        FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_BIAS, p, st));
-    }
+    FUS_TRY(xattn_core_forward(2, L, W, params, f_cxr, f_enh, ws, B, T, cfg->eps_pre, st));
     MFVIT_LAUNCH(x_finish_fwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, cfg->eps_post, B, T, C, ws + W.outp,
                        ws + W.fus, ws + W.stc, hw_cxr, hb_cxr, hw_enh, hb_enh, fused, x_cxr, x_enh);
     MFVIT_CHECK_LAUNCH();
@@ -524,38 +534,46 @@ int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, cons
     const FusLayout L = fus_layout(C);
     const FusWs W = fus_ws(B, T);
     float* ws = (float*)workspace;
-    const float scale = 1.0f / sqrtf((float)DH);
-    const float* wT = ws + W.wT;
     MFVIT_LAUNCH(x_finish_bwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, B, T, C, ws + W.outp, ws + W.fus,
                        ws + W.stc, hw_cxr, hw_enh, dfused, dx_cxr, dx_enh, dparams, dhw_cxr, dhb_cxr, dhw_enh, dhb_enh, ws + W.dout,
                        ws + W.dqp);
     MFVIT_CHECK_LAUNCH();
+    return xattn_core_backward(2, L, W, params, f_cxr, f_enh, ws, B, T, dparams, df_cxr, df_enh, st);
+}
+
+}  // extern "C"
+
+// backward of xattn_core_forward: consumes ws.dout (= d outp) and ws.dqp (cls gradient that bypasses the attention)
+static int xattn_core_backward(int ndir, const FusLayout& L, const FusWs& W, const float* params, const float* f_cxr, const float* f_enh,
+                               float* ws, int B, int T, float* dparams, float* df_cxr, float* df_enh, hipStream_t st) {
+    const float scale = 1.0f / sqrtf((float)DH);
+    const float* wT = ws + W.wT;
     {   // dWp += dout^T o
         GemmP p = zg();
         p.A = ws + W.dout; p.lda = D; p.W = ws + W.o; p.ldw = D; p.M = B; p.N = D; p.K = D;
         p.out0 = dparams + L.ca[0] + L.wp; p.ldo0 = D;
-        p.nb = 2; p.nbi = 1; p.sAo = (long)B * D; p.sWo = (long)B * D; p.sOo = L.ca_stride;
+        p.nb = ndir; p.nbi = 1; p.sAo = (long)B * D; p.sWo = (long)B * D; p.sOo = L.ca_stride;
         FUS_TRY(gemm_tn(MFVIT_F32, p, st));
     }
     {   // do = dout Wp   (W operand = WpT)
         GemmP p = zg();
         p.A = ws + W.dout; p.lda = D; p.W = wT + 3L * D * D; p.ldw = D; p.M = B; p.N = D; p.K = D;
         p.out0 = ws + W.dob; p.ldo0 = D;
-        p.nb = 2; p.nbi = 1; p.sAo = (long)B * D; p.sWo = 4L * D * D; p.sOo = (long)B * D;
+        p.nb = ndir; p.nbi = 1; p.sAo = (long)B * D; p.sWo = 4L * D * D; p.sOo = (long)B * D;
         FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
     }
     {   // dWv_h += do_h^T u_h
         GemmP p = zg();
         p.A = ws + W.dob; p.lda = D; p.W = ws + W.u; p.ldw = NH * D; p.M = B; p.N = DH; p.K = D;
         p.out0 = dparams + L.ca[0] + L.wv; p.ldo0 = D;
-        p.nb = 6; p.nbi = NH; p.sAo = (long)B * D; p.sAi = DH; p.sWo = (long)B * NH * D; p.sWi = D; p.sOo = L.ca_stride; p.sOi = (long)DH * D;
+        p.nb = ndir * NH; p.nbi = NH; p.sAo = (long)B * D; p.sAi = DH; p.sWo = (long)B * NH * D; p.sWi = D; p.sOo = L.ca_stride; p.sOi = (long)DH * D;
         FUS_TRY(gemm_tn(MFVIT_F32, p, st));
     }
     {   // du_h = do_h Wv_h   (W operand = WvT[:, h*128 ..])
         GemmP p = zg();
         p.A = ws + W.dob; p.lda = D; p.W = wT + 2L * D * D; p.ldw = D; p.M = B; p.N = D; p.K = DH;
         p.out0 = ws + W.du; p.ldo0 = NH * D;
-        p.nb = 6; p.nbi = NH; p.sAo = (long)B * D; p.sAi = DH; p.sWo = 4L * D * D; p.sWi = DH; p.sOo = (long)B * NH * D; p.sOi = D;
+        p.nb = ndir * NH; p.nbi = NH; p.sAo = (long)B * D; p.sAi = DH; p.sWo = 4L * D * D; p.sWi = DH; p.sOo = (long)B * NH * D; p.sOi = D;
         FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
     }
     {
@@ -563,7 +581,7 @@ int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, cons
         static bool attr = false;
         if (!attr) { (void)hipFuncSetAttribute((const void*)x_stream_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
         ProfScope ps(PROF_XATTN_BWD, 0, 2.0 * B * T * D * 4 * 3, st);
-        MFVIT_LAUNCH(x_stream_bwd_kernel, dim3(B, 2), dim3(256), lds, st, f_cxr, f_enh, params, L, scale, B, T, ws + W.kq, ws + W.a,
+        MFVIT_LAUNCH(x_stream_bwd_kernel, dim3(B, ndir), dim3(256), lds, st, f_cxr, f_enh, params, L, scale, B, T, ws + W.kq, ws + W.a,
                            ws + W.st, ws + W.du, ws + W.dkq, ws + W.dz0p, dparams, df_cxr, df_enh);
         MFVIT_CHECK_LAUNCH();
     }
@@ -571,34 +589,76 @@ int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, cons
         GemmP p = zg();
         p.A = ws + W.qv; p.lda = D; p.W = ws + W.dkq; p.ldw = NH * D; p.M = B; p.N = DH; p.K = D;
         p.out0 = dparams + L.ca[0] + L.wk; p.ldo0 = D;
-        p.nb = 6; p.nbi = NH; p.sAo = (long)B * D; p.sAi = DH; p.sWo = (long)B * NH * D; p.sWi = D; p.sOo = L.ca_stride; p.sOi = (long)DH * D;
+        p.nb = ndir * NH; p.nbi = NH; p.sAo = (long)B * D; p.sAi = DH; p.sWo = (long)B * NH * D; p.sWi = D; p.sOo = L.ca_stride; p.sOi = (long)DH * D;
         FUS_TRY(gemm_tn(MFVIT_F32, p, st));
     }
     {   // dqv_h = dkq_h Wk_h^T
         GemmP p = zg();
         p.A = ws + W.dkq; p.lda = NH * D; p.W = params + L.ca[0] + L.wk; p.ldw = D; p.M = B; p.N = DH; p.K = D;
         p.out0 = ws + W.dqv; p.ldo0 = D;
-        p.nb = 6; p.nbi = NH; p.sAo = (long)B * NH * D; p.sAi = D; p.sWo = L.ca_stride; p.sWi = (long)DH * D; p.sOo = (long)B * D; p.sOi = DH;
+        p.nb = ndir * NH; p.nbi = NH; p.sAo = (long)B * NH * D; p.sAi = D; p.sWo = L.ca_stride; p.sWi = (long)DH * D; p.sOo = (long)B * D; p.sOi = DH;
         FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
     }
     {   // dWq += dqv^T z0
         GemmP p = zg();
         p.A = ws + W.dqv; p.lda = D; p.W = ws + W.z0; p.ldw = D; p.M = B; p.N = D; p.K = D;
         p.out0 = dparams + L.ca[0] + L.wq; p.ldo0 = D;
-        p.nb = 2; p.nbi = 1; p.sAo = (long)B * D; p.sWo = (long)B * D; p.sOo = L.ca_stride;
+        p.nb = ndir; p.nbi = 1; p.sAo = (long)B * D; p.sWo = (long)B * D; p.sOo = L.ca_stride;
         FUS_TRY(gemm_tn(MFVIT_F32, p, st));
     }
     {   // dz0q = dqv Wq   (W operand = WqT)
         GemmP p = zg();
         p.A = ws + W.dqv; p.lda = D; p.W = wT; p.ldw = D; p.M = B; p.N = D; p.K = D;
         p.out0 = ws + W.dz0q; p.ldo0 = D;
-        p.nb = 2; p.nbi = 1; p.sAo = (long)B * D; p.sWo = 4L * D * D; p.sOo = (long)B * D;
+        p.nb = ndir; p.nbi = 1; p.sAo = (long)B * D; p.sWo = 4L * D * D; p.sOo = (long)B * D;
         FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
     }
-    MFVIT_LAUNCH(x_row0_bwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, B, T, ws + W.st0, ws + W.dz0p, ws + W.dz0q,
+    MFVIT_LAUNCH(x_row0_bwd_kernel, dim3(B), dim3(64 * ndir), 0, st, f_cxr, f_enh, params, L, B, T, ws + W.st0, ws + W.dz0p, ws + W.dz0q,
                        ws + W.dqp, dparams, df_cxr, df_enh);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ stand-alone PreNorm(CrossAttention)
+__global__ void x_copy_out_kernel(const float* __restrict__ src, float* __restrict__ dst, long n) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+extern "C" {
+
+int mfvit_prenorm_xattn_forward(const mfvit_fusion_cfg* cfg, const float* params, const float* x_own, const float* x_oth,
+                                void* workspace, float* out, mfvit_stream_t stream) {
+    if (!fus_ok(cfg) || !params || !x_own || !x_oth || !workspace || !out) return MFVIT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = cfg->batch, T = cfg->tokens;
+    FusLayout L = fus_layout(cfg->num_classes);
+    L.ca[0] = 0;                                   // params = one CA block: norm.{w,b}, wq, wk, wv, proj.{w,b}
+    const FusWs W = fus_ws(B, T);
+    float* ws = (float*)workspace;
+    FUS_TRY(xattn_core_forward(1, L, W, params, x_own, x_oth, ws, B, T, cfg->eps_pre, st));
+    MFVIT_LAUNCH(x_copy_out_kernel, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, st, ws + W.outp, out, (long)B * D);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
+int mfvit_prenorm_xattn_backward(const mfvit_fusion_cfg* cfg, const float* params, const float* x_own, const float* x_oth,
+                                 void* workspace, const float* dout, float* dparams, float* dx_own, float* dx_oth,
+                                 mfvit_stream_t stream) {
+    if (!fus_ok(cfg) || !params || !x_own || !x_oth || !workspace || !dout || !dparams) return MFVIT_EINVAL;
+    if ((dx_own == nullptr) != (dx_oth == nullptr)) return MFVIT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = cfg->batch, T = cfg->tokens;
+    FusLayout L = fus_layout(cfg->num_classes);
+    L.ca[0] = 0;
+    const FusWs W = fus_ws(B, T);
+    float* ws = (float*)workspace;
+    MFVIT_LAUNCH(x_copy_out_kernel, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, st, dout, ws + W.dout, (long)B * D);
+    MFVIT_CHECK_LAUNCH();
+    if (hipMemsetAsync(ws + W.dqp, 0, sizeof(float) * B * D, st) != hipSuccess) return MFVIT_ELAUNCH;
+    // d proj.bias = column sums of dout (x_finish_bwd does this in the fused model)
+    FUS_TRY(colsum_rows(dout, D, dparams + L.bp, B, 1, 0, D, st));
+    return xattn_core_backward(1, L, W, params, x_own, x_oth, ws, B, T, dparams, dx_own, dx_oth, st);
 }
 
 }  // extern "C"

@@ -73,6 +73,8 @@ SIGNATURES = {
     "mfvit_lars_step": (I, [P, I, I, P, F, F, F, F, P]),
     "mfvit_adam_step": (I, [P, I, F, F, F, F, F, I, P]),
     "mfvit_sgd_step": (I, [P, I, F, F, F, I, P]),
+    "mfvit_prenorm_xattn_forward": (I, [POINTER(FusionCfg), P, P, P, P, P, P]),
+    "mfvit_prenorm_xattn_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P]),
     "mfvit_prof_enable": (I, [I]),
     "mfvit_prof_collect": (I, [POINTER(ctypes.c_double), I]),
     "mfvit_prof_class_name": (c_char_p, [I]),

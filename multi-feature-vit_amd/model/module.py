@@ -4,7 +4,7 @@ constructor signatures, parameters under the same attribute names (-> same state
 On the accelerated path these classes are PARAMETER CONTAINERS: ``Fus_CrossViT`` (the only live user, FUS:22-33) runs
 PreNorm -> CrossAttention -> residual -> LayerNorm of both directions as one fused f32 HIP pipeline
 (csrc/fusion.hip) and never calls the per-module ``forward``.  A stand-alone ``PreNorm(dim, CrossAttention(..))(x)``
-call runs the same kernels on a single direction.  ``Residual`` / ``FeedForward`` / ``Attention`` are dead code in
+call runs the same kernels on a single direction (mfvit/xattn.py -> mfvit_prenorm_xattn_forward / _backward).  ``Residual`` / ``FeedForward`` / ``Attention`` are dead code in
 the reference (defined MOD:8-64, instantiated by no live path); the names exist because FUS:6 imports them.
 """
 import torch
@@ -70,4 +70,4 @@ class CrossAttention(nn.Module):
 
     def forward(self, x):
         raise NotImplementedError("CrossAttention runs fused with its PreNorm (the reference never calls it bare, FUS:25,30); "
-                                  "call PreNorm(dim, CrossAttention(...))(x) or Fus_CrossViT")
+                                  "call PreNorm(dim, CrossAttention(...))(x), MultiScaleTransformerEncoder or Fus_CrossViT")

@@ -152,3 +152,59 @@ def test_two_rank_data_parallel_step_rehearsal():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["value"] > 0 and np.isfinite(j["loss"])
+
+
+def test_standalone_prenorm_cross_attention_against_reference_golden():
+    """PreNorm(384, CrossAttention(384, num_heads=3))(x), forward and every gradient, vs the reference's own module
+    (tests/golden/fusion_cross_attention.npz, generated by oracle/make_golden.py from MOD:15-21,108-137)."""
+    mod = importlib.import_module("model.module")
+    g = np.load(os.path.join(GOLDEN, "fusion_cross_attention.npz"), allow_pickle=False)
+    dev = torch.device("cuda:0")
+    fp = ref_fusion.seeded_fusion_params(int(g["seed_params"]))
+    L = ref_fusion._L
+    m = mod.PreNorm(384, mod.CrossAttention(384, num_heads=3))
+    m.load_state_dict({"norm.weight": fp[L + "0.norm.weight"], "norm.bias": fp[L + "0.norm.bias"], "fn.wq.weight": fp[L + "0.fn.wq.weight"],
+                       "fn.wk.weight": fp[L + "0.fn.wk.weight"], "fn.wv.weight": fp[L + "0.fn.wv.weight"],
+                       "fn.proj.weight": fp[L + "0.fn.proj.weight"], "fn.proj.bias": fp[L + "0.fn.proj.bias"]}, strict=True)
+    m = m.to(dev)
+    x = rng_tensor(int(g["seed_x"]), (2, 197, 384)).to(dev).requires_grad_(True)
+    r = rng_tensor(int(g["seed_r"]), (2, 1, 384)).to(dev)
+    y = m(x)
+    (y * r).sum().backward()
+    e_y = scale_err(y, torch.from_numpy(g["y"]))
+    check_sampled(g, "dx", x.grad, rtol=2e-3, atol=2e-3 * float(g["dx.abssum"]) / x.numel())
+    for name, p in m.named_parameters():
+        check_sampled(g, "d." + name, p.grad, rtol=2e-3, atol=2e-3 * float(g[f"d.{name}.abssum"]) / p.numel())
+    log(f"standalone PreNorm(CrossAttention) vs reference golden: fwd {e_y:.3e}")
+    assert e_y < 1e-3
+
+
+def test_standalone_exchange_against_reference_golden():
+    """MultiScaleTransformerEncoder()(xs, xl) full (B,197,384) outputs vs the reference's own module (fusion_exchange.npz), and
+    its gradients vs the oracle."""
+    fus = importlib.import_module(FUS_MOD)
+    g = np.load(os.path.join(GOLDEN, "fusion_exchange.npz"), allow_pickle=False)
+    dev = torch.device("cuda:0")
+    fp = ref_fusion.seeded_fusion_params(int(g["seed_params"]))
+    enc = fus.MultiScaleTransformerEncoder()
+    pre = "multi_scale_transformers.0."
+    enc.load_state_dict({k[len(pre):]: v for k, v in fp.items() if k.startswith(pre)}, strict=True)
+    enc = enc.to(dev)
+    xs = rng_tensor(int(g["seed_xs"]), (2, 197, 384))
+    xl = rng_tensor(int(g["seed_xl"]), (2, 197, 384))
+    xsg, xlg = xs.to(dev).requires_grad_(True), xl.to(dev).requires_grad_(True)
+    xs_o, xl_o = enc(xsg, xlg)
+    check_sampled(g, "xs_out", xs_o, rtol=1e-3, atol=1e-4)
+    check_sampled(g, "xl_out", xl_o, rtol=1e-3, atol=1e-4)
+    assert scale_err(xs_o[:, 0], torch.from_numpy(g["xs_out_cls"])) < 1e-3 and scale_err(xl_o[:, 0], torch.from_numpy(g["xl_out_cls"])) < 1e-3
+    r1, r2 = rng_tensor(651, (2, 197, 384)), rng_tensor(652, (2, 197, 384))
+    ((xs_o * r1.to(dev)).sum() + (xl_o * r2.to(dev)).sum()).backward()
+    fpd = {k: v.double().requires_grad_(True) for k, v in fp.items()}
+    xsd, xld = xs.double().requires_grad_(True), xl.double().requires_grad_(True)
+    a, b = ref_fusion.exchange(fpd, xsd, xld)
+    ((a * r1.double()).sum() + (b * r2.double()).sum()).backward()
+    worst = max(scale_err(xsg.grad, xsd.grad), scale_err(xlg.grad, xld.grad))
+    for k, p in enc.named_parameters():
+        worst = max(worst, scale_err(p.grad, fpd[pre + k].grad))
+    log(f"standalone exchange: worst gradient err {worst:.3e}")
+    assert worst < 1e-3
