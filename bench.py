@@ -287,6 +287,13 @@ def main():
         else:
             ach = bts / (ms * 1e-3) / 1e9
             roof.update(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, traffic=None)
+        try:   # HBM bytes per launch of this kernel class from the committed PMC passes (profiles/README.md); null if absent
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_class.json")))
+            if args.batch == 128 and args.img == 224 and args.precision == "bf16" and name in tj["per_class"]:
+                roof["traffic"] = tj["per_class"][name]["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/r01_hbm_traffic_by_class.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except (OSError, ValueError, KeyError):
+            pass
         total = sum(cls_ms) or 1.0
         roof["warmup_time_share_by_class"] = {lib.mfvit_prof_class_name(c).decode(): round(cls_ms[c] / total, 4)
                                               for c in range(NCLS) if cls_ms[c] > 0}
