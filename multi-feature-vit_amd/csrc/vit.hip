@@ -4,6 +4,7 @@
 #include "../../include/mfvit.h"
 #include "kernels.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 using namespace mfvit;
@@ -114,6 +115,7 @@ struct WsLayout {
     size_t y1, qkv, attn, lse, xmid, st2, y2, hpre, hact;
     // backward scratch
     size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart;
+    size_t pp_stride;           // distance between the two ping-pong copies of gxT / gmidT / dhpre / dqkv (0 = none)
     size_t total;
 };
 WsLayout ws_layout(const Dims& d) {
@@ -140,11 +142,14 @@ WsLayout ws_layout(const Dims& d) {
     if (d.save) {
         W.gx = o; o += align256(M * D * 4);
         W.gmid = o; o += align256(M * D * 4);
+        // dY buffers read by the weight-gradient kernels on the side stream: two copies, used by layer parity
         W.gxT = o; o += align256(M * D * es);
         W.gmidT = o; o += align256(M * D * es);
         W.dhpre = o; o += align256(M * F * es);
-        W.dattn = o; o += align256(M * D * es);
         W.dqkv = o; o += align256(M * 3 * D * es);
+        W.pp_stride = o - W.gxT;
+        o += W.pp_stride;
+        W.dattn = o; o += align256(M * D * es);
         W.colscratch = o; o += align256(2 * D * 4);
         {   // per-workgroup column-sum partials: max over the kernels that use them
             size_t a = ((M + 63) / 64) * 3 * D, b2 = ((M + 127) / 128) * F, c2 = 256 * 3 * D;
@@ -154,6 +159,7 @@ WsLayout ws_layout(const Dims& d) {
         }
     } else {
         W.gx = W.gmid = W.gxT = W.gmidT = W.dhpre = W.dattn = W.dqkv = W.colscratch = W.colpart = o;
+        W.pp_stride = 0;
     }
     W.total = o;
     return W;
@@ -163,6 +169,41 @@ GemmP zero_gemm() {
     GemmP p;
     memset(&p, 0, sizeof(p));
     return p;
+}
+
+// Weight-gradient GEMMs are leaves of the backward graph: they run on a second (library-owned, lazily created) HIP stream
+// beside the dgrad chain, ordered by events.  MFVIT_WGRAD_STREAM=0 keeps everything on the caller's stream.
+struct SideStream {
+    hipStream_t owner = nullptr;    // caller stream this side stream is paired with
+    hipStream_t s = nullptr;
+    hipEvent_t in = nullptr, end = nullptr;
+    hipEvent_t done[64] = {};
+    bool ok = false;
+};
+SideStream& side_stream(hipStream_t caller) {
+    // one side stream per (thread, caller stream): two encoders running on two caller streams do not share a side queue
+    static thread_local SideStream ss[8];
+    static thread_local int used = 0;
+    SideStream* px = nullptr;
+    for (int i = 0; i < used; ++i)
+        if (ss[i].owner == caller) px = &ss[i];
+    if (!px) {
+        px = &ss[used < 8 ? used++ : 7];
+        if (px->owner != caller && px->s) return *px;   // table full: share the last one
+        px->owner = caller;
+    }
+    SideStream& x = *px;
+    if (!x.s) {
+        static const bool enabled = [] { const char* e = getenv("MFVIT_WGRAD_STREAM"); return !(e && e[0] == '0'); }();
+        if (enabled && hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&x.in, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&x.end, hipEventDisableTiming) == hipSuccess) {
+            x.ok = true;
+            for (auto& e : x.done) x.ok = x.ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        }
+        if (!x.ok && !x.s) x.s = (hipStream_t)-1;   // do not retry
+    }
+    return x;
 }
 
 #define MFVIT_TRY(expr)            \
@@ -343,50 +384,70 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
     auto sblk = [&](int l) { return sh + S.blk0 + (size_t)l * S.blk_stride; };
     float* gx = (float*)(ws + W.gx);
     float* gmid = (float*)(ws + W.gmid);
-    void* gxT = ws + W.gxT;
-    void* gmidT = ws + W.gmidT;
     float* colscr = (float*)(ws + W.colscratch);
     float* colpart = (float*)(ws + W.colpart);
+    // dY buffers by layer parity (the embed stage counts as layer -1 -> parity 1)
+    auto pp = [&](size_t off, int l) { return (void*)(ws + off + (size_t)(l & 1) * W.pp_stride); };
+    SideStream& ss = side_stream(st);
+    const bool use_side = ss.ok && W.pp_stride != 0;
+    hipStream_t wst = use_side ? ss.s : st;                       // stream of the weight-gradient GEMMs
+    // the side stream may only start after everything already queued on the caller's stream (activations, zeroed gradients)
+    auto fork = [&]() -> int {                                    // main -> side dependency at this point of the main stream
+        if (!use_side) return MFVIT_OK;
+        if (hipEventRecord(ss.in, st) != hipSuccess || hipStreamWaitEvent(ss.s, ss.in, 0) != hipSuccess) return MFVIT_ELAUNCH;
+        return MFVIT_OK;
+    };
+    auto wait_layer = [&](int l) -> int {                         // main waits until the wgrads of layer l have finished
+        if (!use_side || l < 0 || l >= d.depth || l > stage_hi) return MFVIT_OK;
+        return hipStreamWaitEvent(st, ss.done[l & 63], 0) == hipSuccess ? MFVIT_OK : MFVIT_ELAUNCH;
+    };
 
     for (int s = stage_hi; s >= stage_lo; --s) {
         if (s == d.depth) {
             // final LayerNorm backward: dfeatures -> gx (grad of x_depth); dcol = d fc2_b of the last block
             if (!dfeatures) return MFVIT_EINVAL;
             MFVIT_TRY(ln_bwd_rows(d.dtype, d.D, dfeatures, D, xbuf(d.depth), D, stat(d.depth), stat(d.depth) + d.M, params + L.norm_w,
-                                  nullptr, 0, gx, D, gxT, D, dparams + L.norm_w, dparams + L.norm_b, gblk(d.depth - 1) + L.fc2_b, colpart,
-                                  d.M, 1, 0, st));
+                                  nullptr, 0, gx, D, pp(W.gxT, d.depth - 1), D, dparams + L.norm_w, dparams + L.norm_b,
+                                  gblk(d.depth - 1) + L.fc2_b, colpart, d.M, 1, 0, st));
         } else if (s >= 0) {
             const int l = s;
             char* b = blk(l);
             const float* pb = pblk(l);
             float* gb = gblk(l);
             const char* sb = sblk(l);
+            void* gxT = pp(W.gxT, l);
+            void* gmidT = pp(W.gmidT, l);
+            void* dhpre = pp(W.dhpre, l);
+            void* dqkv = pp(W.dqkv, l);
+            MFVIT_TRY(wait_layer(l + 2));                         // layer l+2's wgrads read this parity's dhpre / gmidT / dqkv
+            MFVIT_TRY(fork());                                    // gxT(l) is ready on the main stream
             {   // dW2 += gx^T hact
                 GemmP p = zero_gemm();
                 p.A = gxT; p.lda = D; p.W = b + W.hact; p.ldw = F;
                 p.M = d.M; p.N = d.D; p.K = d.F;
                 p.out0 = gb + L.fc2_w; p.ldo0 = F;
-                MFVIT_TRY(gemm_tn(d.dtype, p, st));
+                MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
             {   // dhpre = (gx W2) * gelu'(hpre) ; d fc1_b += colsum
                 GemmP p = zero_gemm();
                 p.A = gxT; p.lda = D; p.W = sb + S.fc2_t; p.ldw = D;
                 p.M = d.M; p.N = d.F; p.K = d.D;
                 p.aux = b + W.hpre; p.ldaux = F;
-                p.out0 = ws + W.dhpre; p.ldo0 = F;
+                p.out0 = dhpre; p.ldo0 = F;
                 p.cs0 = gb + L.fc1_b; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_GELU_BWD, p, st));
             }
+            MFVIT_TRY(fork());
             {   // dW1 += dhpre^T y2
                 GemmP p = zero_gemm();
-                p.A = ws + W.dhpre; p.lda = F; p.W = b + W.y2; p.ldw = D;
+                p.A = dhpre; p.lda = F; p.W = b + W.y2; p.ldw = D;
                 p.M = d.M; p.N = d.F; p.K = d.D;
                 p.out0 = gb + L.fc1_w; p.ldo0 = D;
-                MFVIT_TRY(gemm_tn(d.dtype, p, st));
+                MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
             {   // gmid = LN2bwd(dhpre W1) + gx ; d ln2_w, d ln2_b, d proj_b
                 GemmP p = zero_gemm();
-                p.A = ws + W.dhpre; p.lda = F; p.W = sb + S.fc1_t; p.ldw = F;
+                p.A = dhpre; p.lda = F; p.W = sb + S.fc1_t; p.ldw = F;
                 p.M = d.M; p.N = d.D; p.K = d.F;
                 p.aux = b + W.xmid; p.ldaux = D;
                 p.mean = (float*)(b + W.st2); p.rstd = (float*)(b + W.st2) + d.M;
@@ -396,12 +457,13 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = gb + L.proj_b; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
+            MFVIT_TRY(fork());
             {   // dWproj += gmid^T attn
                 GemmP p = zero_gemm();
                 p.A = gmidT; p.lda = D; p.W = b + W.attn; p.ldw = D;
                 p.M = d.M; p.N = d.D; p.K = d.D;
                 p.out0 = gb + L.proj_w; p.ldo0 = D;
-                MFVIT_TRY(gemm_tn(d.dtype, p, st));
+                MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
             {   // dattn = gmid Wproj
                 GemmP p = zero_gemm();
@@ -410,26 +472,29 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.out0 = ws + W.dattn; p.ldo0 = D;
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, p, st));
             }
-            MFVIT_TRY(attn_bwd(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), ws + W.dqkv, nullptr,
-                                     d.B, d.T, d.H, d.HD, st));
+            MFVIT_TRY(attn_bwd(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, nullptr,
+                               d.B, d.T, d.H, d.HD, st));
+            MFVIT_TRY(fork());
             {   // dWqkv += dqkv^T y1 ; d qkv_b += column sums of dqkv (ones-fragment MFMA inside the wgrad kernel)
                 GemmP p = zero_gemm();
-                p.A = ws + W.dqkv; p.lda = 3 * D; p.W = b + W.y1; p.ldw = D;
+                p.A = dqkv; p.lda = 3 * D; p.W = b + W.y1; p.ldw = D;
                 p.M = d.M; p.N = 3 * d.D; p.K = d.D;
                 p.cs0 = gb + L.qkv_b;
                 p.out0 = gb + L.qkv_w; p.ldo0 = D;
-                MFVIT_TRY(gemm_tn(d.dtype, p, st));
+                MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
+            if (use_side && hipEventRecord(ss.done[l & 63], ss.s) != hipSuccess) return MFVIT_ELAUNCH;
+            MFVIT_TRY(wait_layer(l + 1));                         // fc2-wgrad of layer l+1 reads the gxT copy written next
             {   // gx = LN1bwd(dqkv Wqkv) + gmid ; d ln1_w, d ln1_b, d fc2_b of block l-1 (or scratch for the embed stage)
                 if (l == 0 && hipMemsetAsync(colscr, 0, 2 * D * sizeof(float), st) != hipSuccess) return MFVIT_ELAUNCH;
                 GemmP p = zero_gemm();
-                p.A = ws + W.dqkv; p.lda = 3 * D; p.W = sb + S.qkv_t; p.ldw = 3 * D;
+                p.A = dqkv; p.lda = 3 * D; p.W = sb + S.qkv_t; p.ldw = 3 * D;
                 p.M = d.M; p.N = d.D; p.K = 3 * d.D;
                 p.aux = xbuf(l); p.ldaux = D;
                 p.mean = stat(l); p.rstd = stat(l) + d.M;
                 p.gamma = pb + L.ln1_w;
                 p.res = gmid; p.ldres = D;
-                p.out0 = gx; p.ldo0 = D; p.out1 = gxT; p.ldo1 = D;
+                p.out0 = gx; p.ldo0 = D; p.out1 = pp(W.gxT, l - 1); p.ldo1 = D;
                 p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = l > 0 ? gblk(l - 1) + L.fc2_b : colscr; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
@@ -443,13 +508,16 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 MFVIT_TRY(axpy(dparams + L.pe_b, colscr, 1.0f, d.D, st));
                 MFVIT_TRY(axpy(dparams + L.pe_b, colscr + D, -1.0f, d.D, st));
                 GemmP p = zero_gemm();   // d pe_w += gx[patch rows]^T patches
-                p.A = gxT; p.lda = D; p.W = ws + W.patches; p.ldw = 768;
+                p.A = pp(W.gxT, -1); p.lda = D; p.W = ws + W.patches; p.ldw = 768;
                 p.M = d.Mp; p.N = d.D; p.K = 768;
                 p.orow_in = d.np; p.orow_out = d.T; p.orow_off = 1;
                 p.out0 = dparams + L.pe_w; p.ldo0 = 768;
                 MFVIT_TRY(gemm_tn(d.dtype, p, st));
             }
         }
+    }
+    if (use_side) {   // join: everything the side stream did is ordered before whatever the caller queues next
+        if (hipEventRecord(ss.end, ss.s) != hipSuccess || hipStreamWaitEvent(st, ss.end, 0) != hipSuccess) return MFVIT_ELAUNCH;
     }
     return MFVIT_OK;
 }
