@@ -143,14 +143,15 @@ template <typename T, int R, int KR, int NT> struct SStage {
     // m rows >= mmax are zero-filled (they would otherwise add into the reduction)
     // BRANCH-FREE (a load in its own basic block gets a vmcnt(0) behind it): out-of-range rows are clamped for the load and
     // zeroed by a select.  REMAP: row m -> (m / rin) * rout + m % rin + roff  (patch rows -> token rows), compile-time switch.
-    template <bool REMAP>
+    // CHECK = false: the whole stage is in range (every stage but possibly the last of a split) - no compare, no select.
+    template <bool REMAP, bool CHECK>
     __device__ __forceinline__ void load(const T* base, long ld, int m0, int mmax, int c0, int tid, int rin = 0, int rout = 0,
                                          int roff = 0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int q = tid + i * NT, m = q / CPRW, c = q % CPRW;
             const int mm = m0 + m;
-            const bool ok = mm < mmax;
+            const bool ok = !CHECK || mm < mmax;
             const int mc = ok ? mm : mmax - 1;
             long gr = mc;
             if (REMAP) gr = (long)(mc / rin) * rout + (mc % rin) + roff;

@@ -15,6 +15,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace mfvit {
 
 
@@ -418,43 +420,56 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
     const int nst = (mend - mbeg + KR - 1) / KR;
-    sa.template load<REMAP>(A, p.lda, mbeg, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
-    sb.template load<false>(X, p.ldw, mbeg, mend, k0, tid);
-    sa.store(lds, tid);
-    sb.store(lds + TA::BYTES, tid);
-    __syncthreads();
-    int cur = 0;
-    for (int st = 0; st < nst; ++st) {
-        const char* ta = lds + cur * STAGE;
-        const char* tb = ta + TA::BYTES;
-        if (st + 1 < nst) {
-            sa.template load<REMAP>(A, p.lda, mbeg + (st + 1) * KR, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
-            sb.template load<false>(X, p.ldw, mbeg + (st + 1) * KR, mend, k0, tid);
+    const int nfull = (mend - mbeg) / KR;          // stages that lie completely inside [mbeg, mend): loaded without range checks
+    auto load_stage = [&](int stg) {
+        if (stg < nfull) {
+            sa.template load<REMAP, false>(A, p.lda, mbeg + stg * KR, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
+            sb.template load<false, false>(X, p.ldw, mbeg + stg * KR, mend, k0, tid);
+        } else {
+            sa.template load<REMAP, true>(A, p.lda, mbeg + stg * KR, mend, n0, tid, p.orow_in, p.orow_out, p.orow_off);
+            sb.template load<false, true>(X, p.ldw, mbeg + stg * KR, mend, k0, tid);
         }
-#pragma unroll
-        for (int s = 0; s < TA::KSTEPS; ++s) {
-            typename MmaTraits<T>::frag_t a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = TA::frag(ta, (wm * 2 + i) * 32, s, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = TB::frag(tb, (wn * 2 + j) * 32, s, lane);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<T>::mma(a[i], b[j], acc[i][j]);
-            if (do_cs) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) bacc[i] = MmaTraits<T>::mma(a[i], ones, bacc[i]);
-            }
-        }
-        if (st + 1 < nst) {
-            char* na = lds + (cur ^ 1) * STAGE;
-            sa.store(na, tid);
-            sb.store(na + TA::BYTES, tid);
-        }
+    };
+    // the bias-column-sum MFMAs are selected ONCE per kernel (CS template flag), not per k-step: a branch inside the hot loop
+    // splits it into basic blocks and serialises the ds_read -> MFMA software pipeline
+    auto main_loop = [&](auto cs_tag) {
+        constexpr bool CS = decltype(cs_tag)::value;
+        load_stage(0);
+        sa.store(lds, tid);
+        sb.store(lds + TA::BYTES, tid);
         __syncthreads();
-        cur ^= 1;
-    }
+        int cur = 0;
+        for (int st = 0; st < nst; ++st) {
+            const char* ta = lds + cur * STAGE;
+            const char* tb = ta + TA::BYTES;
+            if (st + 1 < nst) load_stage(st + 1);
+#pragma unroll
+            for (int s = 0; s < TA::KSTEPS; ++s) {
+                typename MmaTraits<T>::frag_t a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = TA::frag(ta, (wm * 2 + i) * 32, s, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = TB::frag(tb, (wn * 2 + j) * 32, s, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<T>::mma(a[i], b[j], acc[i][j]);
+                if constexpr (CS) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) bacc[i] = MmaTraits<T>::mma(a[i], ones, bacc[i]);
+                }
+            }
+            if (st + 1 < nst) {
+                char* na = lds + (cur ^ 1) * STAGE;
+                sa.store(na, tid);
+                sb.store(na + TA::BYTES, tid);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    };
+    if (do_cs) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
     float* out = (float*)p.out0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
