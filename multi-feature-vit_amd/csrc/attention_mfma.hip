@@ -31,8 +31,8 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // natural-order fragment: row (rowbase + lane&31), elements d = 16 s + 8 (lane>>5) .. +8
-__device__ __forceinline__ bf16x8 row_frag(const char* img, int rowbase, int s, int lane) {
-    return *(const bf16x8*)(img + (rowbase + (lane & 31)) * RSB + 32 * s + 16 * (lane >> 5));
+template <int PITCH = RSB> __device__ __forceinline__ bf16x8 row_frag(const char* img, int rowbase, int s, int lane) {
+    return *(const bf16x8*)(img + (rowbase + (lane & 31)) * PITCH + 32 * s + 16 * (lane >> 5));
 }
 // transposed fragment in ACCUMULATOR k order: lane holds column d = lane&31; element j = row (rowbase + 16 s + 8 (j>>2) + 4 h + (j&3))
 __device__ __forceinline__ bf16x8 tr_frag(const char* img, int pitch, int rowbase, int s, int lane) {
@@ -152,16 +152,18 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
     }
 }
 
+// PITCH = 80: conflict-free row reads (T <= 480); PITCH = 64: the four images of a 577-token head fit the 160 KiB LDS
+template <int PITCH>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                             bf16* __restrict__ dqkv, int Tn, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tpad = (Tn + 31) & ~31;
     char* Qs = lds;
-    char* Ks = Qs + Tpad * RSB;
-    char* Vs = Ks + Tpad * RSB;
-    char* Os = Vs + Tpad * RSB;  // dO
-    float* Ls = (float*)(Os + Tpad * RSB);
+    char* Ks = Qs + Tpad * PITCH;
+    char* Vs = Ks + Tpad * PITCH;
+    char* Os = Vs + Tpad * PITCH;  // dO
+    float* Ls = (float*)(Os + Tpad * PITCH);
     float* Ds = Ls + Tpad;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -170,10 +172,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
     bf16* dbase = dqkv + (long)b * Tn * rs + h * HD;
     const bf16* obase = out + (long)b * Tn * os + h * HD;
     const bf16* dobase = dout + (long)b * Tn * os + h * HD;
-    stage(base, rs, Tn, Tpad, Qs, RSB);
-    stage(base + (long)H * HD, rs, Tn, Tpad, Ks, RSB);
-    stage(base + 2L * H * HD, rs, Tn, Tpad, Vs, RSB);
-    stage(dobase, os, Tn, Tpad, Os, RSB);
+    stage(base, rs, Tn, Tpad, Qs, PITCH);
+    stage(base + (long)H * HD, rs, Tn, Tpad, Ks, PITCH);
+    stage(base + 2L * H * HD, rs, Tn, Tpad, Vs, PITCH);
+    stage(dobase, os, Tn, Tpad, Os, PITCH);
     const float LOG2E = 1.4426950408889634f;
     for (int i = threadIdx.x; i < Tpad; i += blockDim.x) {
         float D = 0.f, L = 1e30f;  // padded queries: p = exp2(s - 1e30) = 0
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
     for (int qt = wave; qt < nt; qt += 4) {
         bf16x8 qf[2], dof[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { qf[s] = row_frag(Qs, qt * 32, s, lane); dof[s] = row_frag(Os, qt * 32, s, lane); }
+        for (int s = 0; s < 2; ++s) { qf[s] = row_frag<PITCH>(Qs, qt * 32, s, lane); dof[s] = row_frag<PITCH>(Os, qt * 32, s, lane); }
         const float L = Ls[qt * 32 + (lane & 31)], Dq = Ds[qt * 32 + (lane & 31)];
         f32x16 dq;
 #pragma unroll
@@ -208,8 +210,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
             for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                st = mma(row_frag(Ks, kt * 32, s, lane), qf[s], st);
-                dp = mma(row_frag(Vs, kt * 32, s, lane), dof[s], dp);
+                st = mma(row_frag<PITCH>(Ks, kt * 32, s, lane), qf[s], st);
+                dp = mma(row_frag<PITCH>(Vs, kt * 32, s, lane), dof[s], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
                 st[r] = p * (dp[r] - Dq) * scale;  // dS^T (padded keys: K rows are zero, so their dQ contribution vanishes)
             }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) dq = mma(tr_frag(Ks, RSB, kt * 32, s, lane), pack8(st, s), dq);
+            for (int s = 0; s < 2; ++s) dq = mma(tr_frag(Ks, PITCH, kt * 32, s, lane), pack8(st, s), dq);
         }
         const int q = qt * 32 + (lane & 31);
         if (q < Tn) store_tile_T(dbase + (long)q * rs, dq, 1.0f, lane);
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
     for (int kt = wave; kt < nt; kt += 4) {
         bf16x8 kf[2], vf[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { kf[s] = row_frag(Ks, kt * 32, s, lane); vf[s] = row_frag(Vs, kt * 32, s, lane); }
+        for (int s = 0; s < 2; ++s) { kf[s] = row_frag<PITCH>(Ks, kt * 32, s, lane); vf[s] = row_frag<PITCH>(Vs, kt * 32, s, lane); }
         f32x16 dk, dv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
@@ -236,8 +238,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
             for (int r = 0; r < 16; ++r) sm[r] = dp[r] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                sm = mma(row_frag(Qs, qt * 32, s, lane), kf[s], sm);  // S[q][key]
-                dp = mma(row_frag(Os, qt * 32, s, lane), vf[s], dp);  // dP[q][key]
+                sm = mma(row_frag<PITCH>(Qs, qt * 32, s, lane), kf[s], sm);  // S[q][key]
+                dp = mma(row_frag<PITCH>(Os, qt * 32, s, lane), vf[s], dp);  // dP[q][key]
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -254,8 +256,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                dv = mma(tr_frag(Os, RSB, qt * 32, s, lane), pack8(sm, s), dv);
-                dk = mma(tr_frag(Qs, RSB, qt * 32, s, lane), pack8(dp, s), dk);
+                dv = mma(tr_frag(Os, PITCH, qt * 32, s, lane), pack8(sm, s), dv);
+                dk = mma(tr_frag(Qs, PITCH, qt * 32, s, lane), pack8(dp, s), dk);
             }
         }
         const int k = kt * 32 + (lane & 31);
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict
 bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward) {
     if (dtype != MFVIT_BF16 || HDim != HD || Tn < 1) return false;
     const int Tpad = (Tn + 31) & ~31;
-    const int bytes = backward ? 4 * Tpad * RSB + 2 * Tpad * 4 : Tpad * RSB + Tpad * 64;
+    const int bytes = backward ? 4 * Tpad * 64 + 2 * Tpad * 4 : Tpad * RSB + Tpad * 64;
     return bytes <= 160 * 1024;
 }
 
@@ -306,13 +308,22 @@ int attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int Tn, int H, 
 int attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
                   hipStream_t st) {
     const int Tpad = (Tn + 31) & ~31;
-    const int bytes = 4 * Tpad * RSB + 2 * Tpad * 4;
+    const bool wide = 4 * Tpad * RSB + 2 * Tpad * 4 <= 160 * 1024;
+    const int bytes = 4 * Tpad * (wide ? RSB : 64) + 2 * Tpad * 4;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<RSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
     {
         ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
-        MFVIT_LAUNCH(attn_bwd_mfma_kernel, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
-                           lse, (bf16*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
+        if (wide)
+            MFVIT_LAUNCH(attn_bwd_mfma_kernel<RSB>, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
+                         lse, (bf16*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
+        else
+            MFVIT_LAUNCH(attn_bwd_mfma_kernel<64>, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
+                         lse, (bf16*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
         MFVIT_CHECK_LAUNCH();
     }
     if (dbias) {
