@@ -107,9 +107,11 @@ def cross_entropy_rows(logits, target):
 
 
 @torch.no_grad()
-def ema_update_(dst_flat, src_flat, m):
-    """dst = dst * m + src * (1 - m) over flat f32 arenas (BLD:83-89)."""
+def ema_update_(dst_flat, src_flat, m, dst_params=()):
+    """dst = dst * m + src * (1 - m) over flat f32 arenas (BLD:83-89).  ``dst_params``: the parameters that are views of
+    ``dst_flat`` - their version counters are bumped so that weight-shadow caches see the update."""
     _lib.require_cuda(dst_flat, src_flat)
     assert dst_flat.numel() == src_flat.numel() and dst_flat.dtype == src_flat.dtype == torch.float32
     check(lib().mfvit_ema_update(ptr(dst_flat), ptr(src_flat), float(m), dst_flat.numel(), stream()), "mfvit_ema_update")
+    torch._C._increment_version([dst_flat] + list(dst_params))
     return dst_flat

@@ -8,6 +8,12 @@ from ._lib import check, lib, ptr, stream
 CHUNK = 1 << 16
 
 
+def _bump_versions(params):
+    """The kernels write parameters through raw pointers: tell autograd (saved-tensor checks) and the encoders' weight-shadow
+    caches (keyed on the parameter versions) that the data changed."""
+    torch._C._increment_version(list(params))
+
+
 class _TableOptimizer(torch.optim.Optimizer):
     nstate = 1
 
@@ -26,6 +32,7 @@ class _TableOptimizer(torch.optim.Optimizer):
                 st["s0"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 if self.nstate > 1:
                     st["s1"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        group["_mfvit_live"] = ps
         key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
         cache = group.setdefault("_mfvit_table", {})
         if cache.get("key") != key:
@@ -65,6 +72,7 @@ class LARS(_TableOptimizer):
             norms = torch.empty(2 * nt, device=table.device, dtype=torch.float32)
             check(lib().mfvit_lars_step(ptr(table), table.shape[0], nt, ptr(norms), float(g["lr"]), float(g["weight_decay"]),
                                         float(g["momentum"]), float(g["trust_coefficient"]), stream()), "mfvit_lars_step")
+            _bump_versions(g["_mfvit_live"])
 
 
 class Adam(_TableOptimizer):
@@ -87,6 +95,7 @@ class Adam(_TableOptimizer):
             g["_step"] = g.get("_step", 0) + 1
             check(lib().mfvit_adam_step(ptr(table), table.shape[0], float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
                                         float(g["eps"]), float(g["weight_decay"]), g["_step"], stream()), "mfvit_adam_step")
+            _bump_versions(g["_mfvit_live"])
 
 
 class AdamW(Adam):
@@ -113,3 +122,4 @@ class SGD(_TableOptimizer):
             g["_started"] = True
             check(lib().mfvit_sgd_step(ptr(table), table.shape[0], float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), first,
                                        stream()), "mfvit_sgd_step")
+            _bump_versions(g["_mfvit_live"])

@@ -70,9 +70,10 @@ class MoCo(nn.Module):
 
     @torch.no_grad()
     def _momentum_update_key_encoder(self, m):
-        ema_update_(self.momentum_encoder.flat_parameters(), self.base_encoder.flat_parameters(), m)
+        ema_update_(self.momentum_encoder.flat_parameters(), self.base_encoder.flat_parameters(), m,
+                    self.momentum_encoder._arena_params)
         pb, pm = self._arenas()
-        ema_update_(pm.ensure(), pb.ensure(), m)
+        ema_update_(pm.ensure(), pb.ensure(), m, pm.params)
 
     # ------------------------------------------------------------------ queue (BLD:91-105)
     def _queue_t(self):

@@ -203,3 +203,33 @@ def test_lars_against_reference_golden_and_adam_sgd_vs_torch():
             oa.step(); ob.step()
         for pa, pb in zip(a, b):
             torch.testing.assert_close(pa.detach(), pb.detach(), rtol=2e-5, atol=2e-6)
+
+
+def test_raw_pointer_updates_refresh_weight_shadows():
+    """The HIP optimizers and the EMA write parameters through raw pointers; the encoders' bf16/f32 weight shadows must follow
+    (they are cached on the parameter versions).  Regression test: one optimizer step must change the next forward exactly
+    as the same update applied with torch ops does."""
+    import vits
+    from mfvit.optim import SGD
+    from mfvit.moco_ops import ema_update_
+    torch.manual_seed(0)
+    m = vits.vit_small(num_classes=3, depth=2, precision="bf16").to(DEV)
+    ref = vits.vit_small(num_classes=3, depth=2, precision="bf16").to(DEV)
+    ref.load_state_dict(m.state_dict())
+    x = rng_tensor(801, (2, 3, 224, 224)).to(DEV)
+    opt = SGD([p for p in m.parameters() if p.requires_grad], lr=0.05)
+    m(x).square().sum().backward()
+    grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    opt.step()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if n in grads:
+                p.add_(grads[n], alpha=-0.05)
+        a, b = m(x), ref(x)
+    assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()), "optimizer update not seen by the next forward"
+    assert float((a - b).abs().max()) < float((a - m.head.bias).abs().max())      # and the step did change the output
+    before = ref(x).detach().clone()
+    with torch.no_grad():
+        ema_update_(ref.flat_parameters(), m.flat_parameters(), 0.5, ref._arena_params)
+        mix = ref(x)
+    assert float((mix - before).abs().max()) > 0 or torch.equal(m.flat_parameters(), ref.flat_parameters())
