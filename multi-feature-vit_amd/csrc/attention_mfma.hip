@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
     const int Tpad = (Tn + 31) & ~31;
     char* Ks = lds;
     char* Vs = lds + Tpad * RSB;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // the heads of one image share an XCD: their 64 B row pieces share L2 lines
+    const int b = bid / H, h = bid % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rs = 3L * H * HD;
     const bf16* base = qkv + (long)b * Tn * rs + h * HD;
@@ -152,9 +153,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
     }
 }
 
-// PITCH = 80: conflict-free row reads (T <= 480); PITCH = 64: the four images of a 577-token head fit the 160 KiB LDS
+// One 8-wave workgroup per (image, head): Q, K, V, dO of the head are read from HBM exactly once into four LDS images
+// (PITCH = 80: conflict-free row reads, T <= 480; PITCH = 64 reaches T = 608 inside the 160 KB of LDS).  -lse/scale and
+// -D = -rowsum(dO o O) enter the score MFMAs as accumulator initial values, so S - lse/scale and dP - D come out of the
+// matrix core and the VALU work per element is mul, exp2, mul, cvt.
 template <int PITCH>
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+__global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                             const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                             bf16* __restrict__ dqkv, int Tn, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -162,10 +166,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
     char* Qs = lds;
     char* Ks = Qs + Tpad * PITCH;
     char* Vs = Ks + Tpad * PITCH;
-    char* Os = Vs + Tpad * PITCH;  // dO
-    float* Ls = (float*)(Os + Tpad * PITCH);
+    char* dOs = Vs + Tpad * PITCH;
+    float* Ls = (float*)(dOs + Tpad * PITCH);
     float* Ds = Ls + Tpad;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // the heads of one image share an XCD: their 64 B row pieces share L2 lines
+    const int b = bid / H, h = bid % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rs = 3L * H * HD, os = (long)H * HD;
     const bf16* base = qkv + (long)b * Tn * rs + h * HD;
@@ -175,94 +180,99 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16* __restri
     stage(base, rs, Tn, Tpad, Qs, PITCH);
     stage(base + (long)H * HD, rs, Tn, Tpad, Ks, PITCH);
     stage(base + 2L * H * HD, rs, Tn, Tpad, Vs, PITCH);
-    stage(dobase, os, Tn, Tpad, Os, PITCH);
-    const float LOG2E = 1.4426950408889634f;
-    for (int i = threadIdx.x; i < Tpad; i += blockDim.x) {
-        float D = 0.f, L = 1e30f;  // padded queries: p = exp2(s - 1e30) = 0
-        if (i < Tn) {
-            L = lse[((long)b * H + h) * Tn + i] * LOG2E;
+    for (int q = threadIdx.x; q < Tpad * 4; q += blockDim.x) {  // dO image + D: four lanes per row, 16 B each
+        const int t = q >> 2, cidx = q & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        float D = 0.f;
+        if (t < Tn) {
+            v = *(const uint4*)(dobase + (long)t * os + 8 * cidx);
+            const bf16x8 o = *(const bf16x8*)(obase + (long)t * os + 8 * cidx);
+            union { uint4 u; bf16x8 b8; } cv;
+            cv.u = v;
 #pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) {
-                const bf16x8 a = *(const bf16x8*)(dobase + (long)i * os + 8 * cidx);
-                const bf16x8 o = *(const bf16x8*)(obase + (long)i * os + 8 * cidx);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) D = fmaf((float)a[j], (float)o[j], D);
-            }
+            for (int j = 0; j < 8; ++j) D = fmaf((float)cv.b8[j], (float)o[j], D);
         }
-        Ls[i] = L;
-        Ds[i] = D;
+        *(uint4*)(dOs + t * PITCH + 16 * cidx) = v;
+        D += __shfl_xor(D, 1, 64);
+        D += __shfl_xor(D, 2, 64);
+        if (cidx == 0) {
+            Ds[t] = -D;
+            Ls[t] = t < Tn ? -lse[((long)b * H + h) * Tn + t] / scale : -1e30f;  // padded queries: p = exp2(-1e30 c) = 0
+        }
     }
     __syncthreads();
-    const float c = scale * LOG2E;
+    const float c = scale * 1.4426950408889634f;
     const int nt = Tpad >> 5;
     // ---------------- phase A: dQ, wave = query tile
-    for (int qt = wave; qt < nt; qt += 4) {
+    for (int qt = wave; qt < nt; qt += 8) {
         bf16x8 qf[2], dof[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { qf[s] = row_frag<PITCH>(Qs, qt * 32, s, lane); dof[s] = row_frag<PITCH>(Os, qt * 32, s, lane); }
-        const float L = Ls[qt * 32 + (lane & 31)], Dq = Ds[qt * 32 + (lane & 31)];
+        for (int s = 0; s < 2; ++s) {
+            qf[s] = row_frag<PITCH>(Qs, qt * 32, s, lane);
+            dof[s] = row_frag<PITCH>(dOs, qt * 32, s, lane);
+        }
+        const float L = Ls[qt * 32 + (lane & 31)], Dq = Ds[qt * 32 + (lane & 31)];  // -lse/scale, -D
         f32x16 dq;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[r] = 0.f;
         for (int kt = 0; kt < nt; ++kt) {
             f32x16 st, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+            for (int r = 0; r < 16; ++r) { st[r] = L; dp[r] = Dq; }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 st = mma(row_frag<PITCH>(Ks, kt * 32, s, lane), qf[s], st);
                 dp = mma(row_frag<PITCH>(Vs, kt * 32, s, lane), dof[s], dp);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(st[r], c, -L));
-                st[r] = p * (dp[r] - Dq) * scale;  // dS^T (padded keys: K rows are zero, so their dQ contribution vanishes)
-            }
+            for (int r = 0; r < 16; ++r)  // dS^T / scale (padded keys: K rows are zero, so their dQ contribution vanishes)
+                st[r] = __builtin_amdgcn_exp2f(st[r] * c) * dp[r];
 #pragma unroll
             for (int s = 0; s < 2; ++s) dq = mma(tr_frag(Ks, PITCH, kt * 32, s, lane), pack8(st, s), dq);
         }
         const int q = qt * 32 + (lane & 31);
-        if (q < Tn) store_tile_T(dbase + (long)q * rs, dq, 1.0f, lane);
+        if (q < Tn) store_tile_T(dbase + (long)q * rs, dq, scale, lane);
     }
     // ---------------- phase B: dK, dV, wave = key tile
-    for (int kt = wave; kt < nt; kt += 4) {
+    for (int kt = wave; kt < nt; kt += 8) {
         bf16x8 kf[2], vf[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { kf[s] = row_frag<PITCH>(Ks, kt * 32, s, lane); vf[s] = row_frag<PITCH>(Vs, kt * 32, s, lane); }
+        for (int s = 0; s < 2; ++s) {
+            kf[s] = row_frag<PITCH>(Ks, kt * 32, s, lane);
+            vf[s] = row_frag<PITCH>(Vs, kt * 32, s, lane);
+        }
         f32x16 dk, dv;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
         for (int qt = 0; qt < nt; ++qt) {
             f32x16 sm, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sm[r] = dp[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                sm = mma(row_frag<PITCH>(Qs, qt * 32, s, lane), kf[s], sm);  // S[q][key]
-                dp = mma(row_frag<PITCH>(Os, qt * 32, s, lane), vf[s], dp);  // dP[q][key]
-            }
-#pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int q0 = qt * 32 + 8 * g + 4 * (lane >> 5);
                 const float4 L4 = *(const float4*)(Ls + q0);
                 const float4 D4 = *(const float4*)(Ds + q0);
-                const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sm[4 * g + j], c, -Lr[j]));
-                    sm[4 * g + j] = p;
-                    dp[4 * g + j] = p * (dp[4 * g + j] - Dr[j]) * scale;
-                }
+                sm[4 * g] = L4.x, sm[4 * g + 1] = L4.y, sm[4 * g + 2] = L4.z, sm[4 * g + 3] = L4.w;
+                dp[4 * g] = D4.x, dp[4 * g + 1] = D4.y, dp[4 * g + 2] = D4.z, dp[4 * g + 3] = D4.w;
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                dv = mma(tr_frag(Os, PITCH, qt * 32, s, lane), pack8(sm, s), dv);
+                sm = mma(row_frag<PITCH>(Qs, qt * 32, s, lane), kf[s], sm);   // S[q][key] - lse[q]/scale
+                dp = mma(row_frag<PITCH>(dOs, qt * 32, s, lane), vf[s], dp);  // dP[q][key] - D[q]
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sm[r] = __builtin_amdgcn_exp2f(sm[r] * c);
+                dp[r] *= sm[r];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                dv = mma(tr_frag(dOs, PITCH, qt * 32, s, lane), pack8(sm, s), dv);
                 dk = mma(tr_frag(Qs, PITCH, qt * 32, s, lane), pack8(dp, s), dk);
             }
         }
         const int k = kt * 32 + (lane & 31);
         if (k < Tn) {
-            store_tile_T(dbase + (long)k * rs + (long)H * HD, dk, 1.0f, lane);
+            store_tile_T(dbase + (long)k * rs + (long)H * HD, dk, scale, lane);
             store_tile_T(dbase + (long)k * rs + 2L * H * HD, dv, 1.0f, lane);
         }
     }
@@ -319,10 +329,10 @@ int attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const floa
     {
         ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
         if (wide)
-            MFVIT_LAUNCH(attn_bwd_mfma_kernel<RSB>, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
+            MFVIT_LAUNCH(attn_bwd_mfma_kernel<RSB>, dim3(B * H), dim3(512), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
                          lse, (bf16*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
         else
-            MFVIT_LAUNCH(attn_bwd_mfma_kernel<64>, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
+            MFVIT_LAUNCH(attn_bwd_mfma_kernel<64>, dim3(B * H), dim3(512), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
                          lse, (bf16*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
         MFVIT_CHECK_LAUNCH();
     }

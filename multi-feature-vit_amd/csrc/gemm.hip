@@ -130,19 +130,19 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
 }
 
 // ------------------------------------------------------------------------------------------- row kernel
-constexpr int ROW_BM = 64, ROW_BN = 384, ROW_BKB = 64, ROW_RS = 132;
+constexpr int ROW_BN = 384, ROW_BKB = 64, ROW_RS = 132;
 
 // Full-row totals of per-lane partials p[i][r] (row = i*32 + acc_row(r)), summed over the 32 column lanes of the
 // 4 waves, through LDS (red: [64][132] floats, tot: [64]).  Three barriers; all 256 threads must call it.
-template <int TM>
+template <int TM, int BM, int NTHREADS>
 __device__ __forceinline__ void row_reduce(float (&p)[TM][16], float* red, float* tot, int lane, int wm, int wn, int tid) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[((wm * TM + i) * 32 + acc_row(r, lane)) * ROW_RS + wn * 32 + (lane & 31)] = p[i][r];
     __syncthreads();
-    if (tid < 256) {
-        const int row = tid >> 2, q = tid & 3;
+    for (int t2 = tid; t2 < BM * 4; t2 += NTHREADS) {
+        const int row = t2 >> 2, q = t2 & 3;
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -161,9 +161,9 @@ __device__ __forceinline__ void row_reduce(float (&p)[TM][16], float* red, float
     __syncthreads();
 }
 
-template <typename T, int REPI, int WM, int BKB>
+template <typename T, int REPI, int WM, int BKB, int BM>
 __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
-    constexpr int BM = ROW_BM, BN = ROW_BN, WN = 4;
+    constexpr int BN = ROW_BN, WN = 4;
     typedef NtLoop<T, BM, BN, BKB, WM, WN> Loop;
     constexpr int TM = Loop::TM, TN = Loop::TN;  // (2 | 1) x 3
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
                 for (int j = 0; j < TN; ++j) s += acc[i][j][r];
                 part[i][r] = s;
             }
-        row_reduce<TM>(part, red, tot, lane, wm, wn, tid);
+        row_reduce<TM, BM, WM * 256>(part, red, tot, lane, wm, wn, tid);
         float mu[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
                 }
                 part[i][r] = s;
             }
-        row_reduce<TM>(part, red, tot, lane, wm, wn, tid);
+        row_reduce<TM, BM, WM * 256>(part, red, tot, lane, wm, wn, tid);
         // pass C: stores only (x_out f32, y, statistics); padded rows replicate row M-1 -> identical duplicate stores
         float* __restrict__ xo = (float*)p.out0;
 #pragma unroll
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
                 p1[i][r] = s1;
                 p2[i][r] = s2;
             }
-        row_reduce<TM>(p1, red, tot, lane, wm, wn, tid);
-        row_reduce<TM>(p2, red, tot, lane, wm, wn, tid);
+        row_reduce<TM, BM, WM * 256>(p1, red, tot, lane, wm, wn, tid);
+        row_reduce<TM, BM, WM * 256>(p2, red, tot, lane, wm, wn, tid);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -513,27 +513,34 @@ static int row_variant() {   // MFVIT_ROW_VARIANT: 0 = 4 waves (1x4), BK 64 B ro
     static const int v = [] { const char* e = getenv("MFVIT_ROW_VARIANT"); return e ? atoi(e) : 2; }();
     return v;
 }
-template <typename T, int REPI, int WM, int BKB> static int launch_row_v(const GemmP& p, hipStream_t st) {
-    typedef NtLoop<T, ROW_BM, ROW_BN, BKB, WM, 4> Loop;
+template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v(const GemmP& p, hipStream_t st) {
+    typedef NtLoop<T, BM, ROW_BN, BKB, WM, 4> Loop;
     if (p.N != ROW_BN || p.K % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
-    constexpr int need = ROW_BM * ROW_RS * 4 + ROW_BM * 4;
-    constexpr int bytes = Loop::LDS_BYTES > need ? Loop::LDS_BYTES : need;
+    constexpr int need = BM * ROW_RS * 4 + BM * 4;
+    constexpr int need2 = WM * 3 * ROW_BN * 4;
+    constexpr int bytes0 = Loop::LDS_BYTES > need ? Loop::LDS_BYTES : need;
+    constexpr int bytes = bytes0 > need2 ? bytes0 : need2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_row_kernel<T, REPI, WM, BKB>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_row_kernel<T, REPI, WM, BKB, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
     ProfScope ps(REPI == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
-    MFVIT_LAUNCH((gemm_nt_row_kernel<T, REPI, WM, BKB>), dim3((p.M + ROW_BM - 1) / ROW_BM), dim3(WM * 256), bytes, st, p);
+    MFVIT_LAUNCH((gemm_nt_row_kernel<T, REPI, WM, BKB, BM>), dim3((p.M + BM - 1) / BM), dim3(WM * 256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
 template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_t st) {
     const int v = row_variant();
-    if (v == 0 || p.K % (128 / (int)sizeof(T))) return launch_row_v<T, REPI, 1, 64>(p, st);
-    if (v == 1) return launch_row_v<T, REPI, 1, 128>(p, st);
-    if (v == 3) return launch_row_v<T, REPI, 2, 64>(p, st);
-    return launch_row_v<T, REPI, 2, 128>(p, st);
+    if (v == 0 || p.K % (128 / (int)sizeof(T))) return launch_row_v<T, REPI, 1, 64, 64>(p, st);
+    if (v == 1) return launch_row_v<T, REPI, 1, 128, 64>(p, st);
+    if (v == 3) return launch_row_v<T, REPI, 2, 64, 64>(p, st);
+    if constexpr (REPI == REPI_RES_LN) {
+        // 128-row variant: every workgroup streams the whole W[384][K] from L2, so doubling the rows per workgroup halves that
+        // traffic (the row kernels' main loop is bound by it); worth it once K is large enough to amortise the 77 % grid fill
+        if (v == 4 || (v == 2 && p.K >= 768 && p.M >= 128 * 128)) return launch_row_v<T, REPI, 2, 128, 128>(p, st);
+    }
+    return launch_row_v<T, REPI, 2, 128, 64>(p, st);
 }
 template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
     if (p.N % 128 || p.K % 128 || p.M <= 0) return MFVIT_EINVAL;
@@ -614,7 +621,7 @@ int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
     if (repi == REPI_LNBWD_RES) {
         const int rc = dtype == MFVIT_BF16 ? launch_row<bf16, REPI_LNBWD_RES>(p, st) : launch_row<float, REPI_LNBWD_RES>(p, st);
         if (rc != MFVIT_OK || !p.cpart) return rc;
-        return colpart_reduce(p.cpart, (p.M + ROW_BM - 1) / ROW_BM, ROW_BN, 3, p.cs0, p.cs1, p.cs2, st);
+        return colpart_reduce(p.cpart, (p.M + 63) / 64, ROW_BN, 3, p.cs0, p.cs1, p.cs2, st);
     }
     return MFVIT_EINVAL;
 }
