@@ -271,6 +271,25 @@ def main():
     dt = time.perf_counter() - t0
     lib.mfvit_prof_collect(buf, NCLS)
     lib.mfvit_prof_enable(0)
+    # attribution pass (untimed, after the timed region): same step with the two encoder streams and the wgrad side stream
+    # serialised, so that every kernel's event-timed duration is its own rather than a share of a co-scheduled GPU
+    solo = (ctypes.c_double * (NCLS * 4))()
+    solo_ms_per_step = 0.0
+    if True:   # every rank runs it (the step contains the gradient all-reduce); rank 0 reports
+        model._two_streams = False
+        lib.mfvit_set_wgrad_stream(0)
+        step()
+        torch.cuda.synchronize()
+        lib.mfvit_prof_enable((1 << NCLS) - 1)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        solo_ms_per_step = 1e3 * (time.perf_counter() - t1) / 3
+        lib.mfvit_prof_collect(solo, NCLS)
+        lib.mfvit_prof_enable(0)
+        lib.mfvit_set_wgrad_stream(1)
+        model._two_streams = True
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -294,6 +313,20 @@ def main():
                 roof["traffic_source"] = "profiles/r01_hbm_traffic_by_class.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         except (OSError, ValueError, KeyError):
             pass
+        peak_t = PEAK_TFLOPS[args.precision]
+        per = {}
+        for c in range(NCLS):
+            n, ms_c, fl, by = (solo[c * 4 + i] for i in range(4))
+            if n > 0:
+                e = dict(launches_per_step=n / 3, avg_us=round(1e3 * ms_c / n, 2), ms_per_step=round(ms_c / 3, 3))
+                if fl > 0:
+                    e.update(tflops=round(fl / (ms_c * 1e-3) / 1e12, 1), frac_of_mfma_peak=round(fl / (ms_c * 1e-3) / 1e12 / peak_t, 4))
+                elif by > 0:
+                    e.update(gbs=round(by / (ms_c * 1e-3) / 1e9, 1), frac_of_hbm_peak=round(by / (ms_c * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+                per[lib.mfvit_prof_class_name(c).decode()] = e
+        roof["serialized_pass"] = dict(note="untimed attribution pass after the timed region: one stream, no wgrad side stream; "
+                                            "achieved/avg_us above are from the timed region where up to four streams share the GPU",
+                                       ms_per_step=round(solo_ms_per_step, 3), per_class=per)
         total = sum(cls_ms) or 1.0
         roof["warmup_time_share_by_class"] = {lib.mfvit_prof_class_name(c).decode(): round(cls_ms[c] / total, 4)
                                               for c in range(NCLS) if cls_ms[c] > 0}

@@ -87,9 +87,19 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
  * writing gelu'(pre-activation) to y (what the backward needs) and the activation to y2, 3 none).  N % 128 == 0, K % 64 == 0. */
 int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                      int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream);
+/* Experimental second implementation of the same linear (bf16 only; N % 128 == 0, N <= 1536, K % 32 == 0, K >= 128, M >= 1024):
+ * persistent 256x128-tile kernel with an LDS-DMA ring pipelined across tiles (csrc/gemm_pers.hip).  Same results; opt-in
+ * for the encoder with MFVIT_PERS=1. */
+int mfvit_linear_fwd_persistent(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
+                                int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream);
 /* dW[N][K] (f32, accumulated) += dy[M][N]^T x[M][K]   (nn.Linear weight gradient).  N % 128 == 0, K % 128 == 0. */
 int mfvit_linear_wgrad(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N, int K,
                        mfvit_stream_t stream);
+/* Same, with caller-owned scratch for the partial sums of the M-splits (MFVIT_WGRAD_SCRATCH_FLOATS floats, may be NULL): the
+ * partials then leave the kernel as plain stores and a second small kernel adds them into dW, instead of float atomics. */
+#define MFVIT_WGRAD_SCRATCH_FLOATS (384 * 128 * 128)
+int mfvit_linear_wgrad_ws(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N,
+                          int K, float* scratch, mfvit_stream_t stream);
 /* proj / fc2 (+ residual + following LayerNorm): x_out = a W^T + bias + res ; y = LN(x_out).  N == 384. */
 int mfvit_linear_res_ln_fwd(int dtype, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res,
                             int64_t ldres, float* x_out, void* y, int y_f32, const float* gamma, const float* beta, float eps,
@@ -174,6 +184,10 @@ int mfvit_prenorm_xattn_backward(const mfvit_fusion_cfg* cfg, const float* param
  * mfvit_prof_collect waits for the recorded events and fills out[cls*4 + {0 launches, 1 ms, 2 algorithmic flops,
  * 3 algorithmic bytes}] (ncls <= 10), then clears the records. */
 int mfvit_prof_enable(int class_mask); /* bit c set = time class c; 0 = off */
+/* Weight-gradient GEMMs of mfvit_vit_backward run on a library-owned side stream beside the dgrad chain (default on; also
+ * MFVIT_WGRAD_STREAM=0).  0 serialises them on the caller's stream - used by bench.py's attribution pass so that a kernel's
+ * event-timed duration is its own, not a share of a co-scheduled GPU.  Results are identical either way. */
+int mfvit_set_wgrad_stream(int enabled);
 int mfvit_prof_collect(double* out, int ncls);
 const char* mfvit_prof_class_name(int cls);
 

@@ -14,6 +14,12 @@
 // C/D map (both): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 #pragma once
 #include "common.cuh"
+#ifndef MFVIT_NT_PIPE
+#define MFVIT_NT_PIPE 1
+#endif
+#ifndef MFVIT_TN_PIPE
+#define MFVIT_TN_PIPE 1
+#endif
 
 namespace mfvit {
 
@@ -214,6 +220,7 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // NT main loop:  acc[TM][TN] (32x32 tiles) += A[m0.., :] * W[n0.., :]^T, double-buffered LDS, one barrier
 // per K tile, next tile's global loads issued before the MFMAs of the current one (write after).
 template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
+    static constexpr bool PIPE = MFVIT_NT_PIPE;
     static constexpr int NT = WM * WN * 64;
     static constexpr int BK = BKB / (int)sizeof(T);
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -249,17 +256,27 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
                 sa.load(A, p.lda, m0, p.M, (kt + 1) * BK, tid);
                 sb.load(W, p.ldw, n0, p.N, (kt + 1) * BK, tid);
             }
+            // fragments double-buffered by hand: the LDS reads of sub-step s+1 are issued before the MFMAs of sub-step s (left to
+            // itself the compiler waits right behind each read, which at 1-2 waves per SIMD exposes the LDS latency every sub-step)
+            typename MmaTraits<T>::frag_t a[2][TM], b[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[0][i] = TA::frag(ta, (wm * TM + i) * 32, 0, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[0][j] = TB::frag(tb, (wn * TN + j) * 32, 0, lane);
 #pragma unroll
             for (int s = 0; s < TA::KSTEPS; ++s) {
-                typename MmaTraits<T>::frag_t a[TM], b[TN];
+                if (s + 1 < TA::KSTEPS) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = TA::frag(ta, (wm * TM + i) * 32, s, lane);
+                    for (int i = 0; i < TM; ++i) a[(s + 1) & 1][i] = TA::frag(ta, (wm * TM + i) * 32, s + 1, lane);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = TB::frag(tb, (wn * TN + j) * 32, s, lane);
+                    for (int j = 0; j < TN; ++j) b[(s + 1) & 1][j] = TB::frag(tb, (wn * TN + j) * 32, s + 1, lane);
+                }
+                if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][i], b[s & 1][j], acc[i][j]);
+                if (PIPE) __builtin_amdgcn_sched_barrier(0);
             }
             if (kt + 1 < nk) {
                 char* na = lds + (cur ^ 1) * STAGE_BYTES;

@@ -381,11 +381,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     // one m-split read the same dY / X rows, so a split's tiles are kept on ONE XCD (split = xcd + 8 * ...): the operands are
     // then fetched into that L2 once and re-read from it by the other tiles instead of 3-12 times from HBM / Infinity Cache.
     int tile = blockIdx.x, split = blockIdx.y;
-    if (gridDim.y == 1 && p.splits > 1) {          // 1-D launch: splits is a multiple of 8
+    if (gridDim.y == 1 && p.splits > 1) {          // 1-D launch: each XCD gets a contiguous run of the split-major block order
         const int tiles = ntk * (p.N / BN);
-        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-        split = xcd + 8 * (loc / tiles);
-        tile = loc % tiles;
+        const int lin = xcd_remap(blockIdx.x, gridDim.x);
+        split = lin / tiles;
+        tile = lin % tiles;
     }
     const int n0 = (tile / ntk) * BN, k0 = (tile % ntk) * BK2;
     int chunk = (p.M + p.splits - 1) / p.splits;
@@ -443,21 +443,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
             const char* ta = lds + cur * STAGE;
             const char* tb = ta + TA::BYTES;
             if (st + 1 < nst) load_stage(st + 1);
+            // hand double-buffered fragments (see NtLoop): reads of sub-step s+1 go out before the MFMAs of sub-step s
+            typename MmaTraits<T>::frag_t a[2][2], b[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[0][i] = TA::frag(ta, (wm * 2 + i) * 32, 0, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[0][j] = TB::frag(tb, (wn * 2 + j) * 32, 0, lane);
 #pragma unroll
             for (int s = 0; s < TA::KSTEPS; ++s) {
-                typename MmaTraits<T>::frag_t a[2], b[2];
+                if (s + 1 < TA::KSTEPS) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = TA::frag(ta, (wm * 2 + i) * 32, s, lane);
+                    for (int i = 0; i < 2; ++i) a[(s + 1) & 1][i] = TA::frag(ta, (wm * 2 + i) * 32, s + 1, lane);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = TB::frag(tb, (wn * 2 + j) * 32, s, lane);
+                    for (int j = 0; j < 2; ++j) b[(s + 1) & 1][j] = TB::frag(tb, (wn * 2 + j) * 32, s + 1, lane);
+                }
+                if (MFVIT_TN_PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<T>::mma(a[i], b[j], acc[i][j]);
+                    for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][i], b[s & 1][j], acc[i][j]);
                 if constexpr (CS) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) bacc[i] = MmaTraits<T>::mma(a[i], ones, bacc[i]);
+                    for (int i = 0; i < 2; ++i) bacc[i] = MmaTraits<T>::mma(a[s & 1][i], ones, bacc[i]);
                 }
+                if (MFVIT_TN_PIPE) __builtin_amdgcn_sched_barrier(0);
             }
             if (st + 1 < nst) {
                 char* na = lds + (cur ^ 1) * STAGE;
@@ -470,23 +479,58 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     };
     if (do_cs) main_loop(std::true_type{});
     else main_loop(std::false_type{});
-    float* out = (float*)p.out0;
+    if (p.cpart) {
+        // split partials as PLAIN stores into scratch [split][N][K] (summed into out0 by tn_reduce_kernel): float atomics run at
+        // ~1.3 TB/s chip-wide and one 256-B wave-instruction per ~50 ns per CU, i.e. ~13 us for the 256 of a 128x128 tile
+        float* part = p.cpart + (long)split * p.N * p.K;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + (wm * 2 + i) * 32 + acc_row(r, lane);
-                const int k = k0 + (wn * 2 + j) * 32 + (lane & 31);
-                atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + (wm * 2 + i) * 32 + acc_row(r, lane);
+                    const int k = k0 + (wn * 2 + j) * 32 + (lane & 31);
+                    part[(long)n * p.K + k] = acc[i][j][r];
+                }
+    } else {
+        float* out = (float*)p.out0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + (wm * 2 + i) * 32 + acc_row(r, lane);
+                    const int k = k0 + (wn * 2 + j) * 32 + (lane & 31);
+                    atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
+                }
+    }
     if (do_cs && (lane & 31) == 0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + n0 + (wm * 2 + i) * 32 + acc_row(r, lane), bacc[i][r]);
     }
+}
+
+// out[n][k] += sum_s part[s][n][k]   (K % 4 == 0; one float4 per thread)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int splits, int N, int K, float* __restrict__ out,
+                                                        long ldo) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total4 = (long)N * K / 4;
+    if (q >= total4) return;
+    const long e = q * 4;
+    float4 s = *(const float4*)(part + e);
+    for (int t = 1; t < splits; ++t) {
+        const float4 v = *(const float4*)(part + (long)t * N * K + e);
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    const int n = (int)(e / K), k = (int)(e % K);
+    float4* o = (float4*)(out + (long)n * ldo + k);
+    float4 c = *o;
+    c.x += s.x, c.y += s.y, c.z += s.z, c.w += s.w;
+    *o = c;
 }
 
 // ------------------------------------------------------------------------------------------- launchers
@@ -548,13 +592,13 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
     const int tiles = (p.N / 128) * (p.K / 128);
     if (p.splits <= 0) {
         static const int target = [] { const char* e = getenv("MFVIT_TN_TARGET"); return e ? atoi(e) : 384; }();
-        int s = (target + tiles - 1) / tiles;            // aim at `target` blocks on the chip
+        // Fill the chip evenly: two workgroups fit a CU (2 x 80 KB of LDS), so aim just BELOW a multiple of 256 blocks - 288
+        // blocks on 256 CUs leave 224 CUs idle while 32 run two (the makespan is the slowest CU's).
+        int s = (tiles >= 16 ? target : (target * 2) / 3) / tiles;
         const int maxs = (p.M + 4 * KR - 1) / (4 * KR);  // at least 4 stages per split
         p.splits = s < 1 ? 1 : (s > maxs ? maxs : s);
-        if (p.splits < 1) p.splits = 1;
-        if (p.splits >= 8) p.splits = (p.splits + 4) / 8 * 8;   // multiple of 8 -> XCD-aware 1-D launch
     }
-    const bool xcd1d = p.splits >= 8 && p.splits % 8 == 0 && p.nb <= 1;
+    const bool xcd1d = p.splits > 1 && p.nb <= 1;
     constexpr int bytes = 2 * (STile<T, 128, KR>::BYTES * 2);
     static bool attr_set = false;
     if (!attr_set) {
@@ -562,6 +606,9 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_set = true;
     }
+    // p.cpart (optional, >= splits * N * K floats): split partials go there as plain stores and are summed by a second kernel
+    static const bool use_part = [] { const char* e = getenv("MFVIT_TN_PART"); return !(e && e[0] == '0'); }();
+    if (!use_part || p.nb > 1 || p.splits < 2 || p.ldo0 % 4 || (long)tiles * p.splits > 384) p.cpart = nullptr;   // scratch holds 384 tiles
     ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
     const dim3 grid = xcd1d ? dim3(tiles * p.splits, 1, 1) : dim3(tiles, p.splits, p.nb > 1 ? p.nb : 1);
     if (p.orow_in)
@@ -569,6 +616,12 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
     else
         MFVIT_LAUNCH((gemm_tn_kernel<T, false>), grid, dim3(256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
+    if (p.cpart) {
+        const long total4 = (long)p.N * p.K / 4;
+        MFVIT_LAUNCH(tn_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, p.cpart, p.splits, p.N, p.K, (float*)p.out0,
+                     p.ldo0);
+        MFVIT_CHECK_LAUNCH();
+    }
     return MFVIT_OK;
 }
 
@@ -599,6 +652,7 @@ int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float
 }
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
+    if (gemm_nt_pers_supported(dtype, epi, p)) return gemm_nt_pers(epi, p, st);
 #define MFVIT_TILE_CASE(E)                                              \
     case E:                                                             \
         return dtype == MFVIT_BF16 ? launch_tile<bf16, E>(p, st) : launch_tile<float, E>(p, st);

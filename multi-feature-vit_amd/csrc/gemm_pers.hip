@@ -1,0 +1,335 @@
+// Persistent bf16 NT GEMM for the short-K (K = 384) linears of the encoder:  out[M][N] = epi(A[M][K] W[N][K]^T).
+//
+// Why a second tile kernel: at K = 384 a 128x128 tile's main loop is only six K-steps, so pipeline fill, the epilogue and the
+// L2 re-fetch of both operands (1/64 B per flop) dominate; with 64x64 per wave the LDS fragment traffic equals the MFMA time.
+//   * 256 x 128 workgroup tile, 4 waves as 2 x 2, 128 x 64 per wave (4 x 2 MFMA tiles of 32x32x16): 6 KB of fragment reads per
+//     8 MFMAs (75 % of the LDS rate instead of 100 %), operand traffic 1/85 B per flop.
+//   * one workgroup per CU, persistent over its tiles; the K-steps of ALL its tiles form one flat pipeline: a 3-slot LDS ring
+//     (3 x 48 KB) filled by LDS-DMA (global_load_lds_dwordx4) two steps ahead, so the first stages of tile t+1 are in flight
+//     while tile t finishes and runs its epilogue - no per-tile fill bubble.
+//   * MFMA operands swapped (W fragment as A, activation fragment as B): the accumulator holds out^T, i.e. a lane owns ONE
+//     output row and 4 consecutive columns per register quad -> bias comes in as float4, outputs leave as packed bf16x4.
+//   * tiles are dealt so that the 32 workgroups of an XCD work on neighbouring tiles of the n-fastest order at the same time
+//     (they share activation rows in that XCD's L2).
+// Synchronisation per K-step: counted s_waitcnt vmcnt (never 0 while a younger stage is in flight) -> raw s_barrier -> issue
+// the stage two steps ahead into the slot every wave has just finished reading -> MFMAs.  vmcnt retires in order, so
+// "at most LPS operations outstanding" proves the stage before the youngest one has landed, whatever the epilogue stored
+// in between (cdna_hip_programming.md 5, "Pipelining across barriers").
+#include "gemm.cuh"
+#include "kernels.h"
+#include "prof.h"
+
+namespace mfvit {
+
+namespace {
+
+constexpr int PBM = 256, PBN = 128, PNS = 3;
+constexpr int PTM = 4, PTN = 2;
+constexpr int PMAXN = 1536;                              // bias vector kept in LDS
+
+// BKB = bytes of K per LDS row: 128 (BK 64, 48 KB stages, one workgroup per CU) or 64 (BK 32, 24 KB stages, two per CU)
+template <int BKB> struct PCfg {
+    typedef KTile<bf16, PBM, BKB> TA;
+    typedef KTile<bf16, PBN, BKB> TB;
+    static constexpr int BK = BKB / 2;
+    static constexpr int CPR = BKB / 16;                              // 16-B chunks per row
+    static constexpr int STAGE = TA::BYTES + TB::BYTES;
+    static constexpr int LA = PBM * CPR / 256, LB = PBN * CPR / 256;  // LDS-DMA instructions per thread per stage
+    static constexpr int LPS = LA + LB;
+    static constexpr int RPI = 256 / CPR;                             // tile rows covered by one LDS-DMA of the block
+    static constexpr int KS = TA::KSTEPS;
+    static constexpr int LDS_BYTES = PNS * STAGE + PMAXN * 4;
+};
+
+template <int N> __device__ __forceinline__ void wait_vm_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_off)
+                 : "memory");
+}
+
+template <int EPI, int BKB>
+__global__ __launch_bounds__(256, BKB == 64 ? 2 : 1) void gemm_nt_pers_kernel(GemmP p, int ntm, int ntn) {
+#ifdef MFVIT_PERS_DBG
+    constexpr int dbg = MFVIT_PERS_DBG;   // build-time experiment switch: 1 no epilogue, 2 no MFMAs, 4 no in-loop LDS-DMA
+#else
+    constexpr int dbg = 0;
+#endif
+    typedef PCfg<BKB> C;
+    typedef typename C::TA TA;
+    typedef typename C::TB TB;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int G = gridDim.x, ntiles = ntm * ntn;
+    // chunk-local slot of this workgroup: the workgroups of one XCD (blockIdx & 7) get consecutive tiles of every round
+    const int cslot = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+    if (cslot >= ntiles) return;
+    const int nloc = (ntiles - cslot + G - 1) / G;
+    const int nk = p.K / C::BK;
+    const int S = nloc * nk;
+
+    // ---- issue side state: byte offsets of this thread's 16-B chunks (row of the tile, swizzled chunk), per tile
+    const int crow = tid / C::CPR;                                            // + RPI i
+    const int cchunk = (tid % C::CPR) ^ ((crow / TA::RPW) % C::CPR);          // source chunk landing on LDS chunk position tid % CPR
+    static_assert((C::RPI / TA::RPW) % C::CPR == 0, "row step of successive LDS-DMAs must not change the swizzle");
+    unsigned offA[C::LA], offB[C::LB];
+    int it_tile = cslot, it_kt = 0;
+    auto set_tile_offsets = [&](int tile) {
+        const int m0 = (tile / ntn) * PBM, n0 = (tile % ntn) * PBN;
+#pragma unroll
+        for (int i = 0; i < C::LA; ++i) {
+            int gr = m0 + crow + C::RPI * i;
+            gr = gr < p.M ? gr : p.M - 1;
+            offA[i] = (unsigned)gr * (unsigned)(p.lda * 2) + cchunk * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < C::LB; ++i) offB[i] = (unsigned)(n0 + crow + C::RPI * i) * (unsigned)(p.ldw * 2) + cchunk * 16;
+    };
+    const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (unsigned)wave * 1024u);
+    auto issue = [&](int slot) {
+        if (it_kt == 0) set_tile_offsets(it_tile);
+        const unsigned sa = lbase + (unsigned)slot * C::STAGE, sb = sa + TA::BYTES;
+        const unsigned kb = (unsigned)it_kt * BKB;
+#pragma unroll
+        for (int i = 0; i < C::LA; ++i) glds16((const char*)p.A + (offA[i] + kb), sa + i * 4096);
+#pragma unroll
+        for (int i = 0; i < C::LB; ++i) glds16((const char*)p.W + (offB[i] + kb), sb + i * 4096);
+        if (++it_kt == nk) { it_kt = 0; it_tile += G; }
+    };
+
+    // bias vector -> LDS once (read back with ds_read in the epilogues: no vector-memory loads inside the pipelined loop,
+    // whose compiler-inserted vmcnt(0) waits would drain the in-flight LDS-DMA stages)
+    float* lbias = (float*)(lds + PNS * C::STAGE);
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU)
+        for (int n = tid; n < p.N; n += 256) lbias[n] = p.bias ? p.bias[n] : 0.f;
+
+    // fragment registers, double-buffered by hand: the reads of sub-step ks+1 are issued BEFORE the MFMAs of sub-step ks
+    // (one wave per SIMD cannot hide LDS latency any other way; left to itself the compiler waits right behind each read)
+    static_assert(C::KS % 2 == 0, "fragment double buffer assumes an even number of sub-steps");
+    bf16x8 fa[2][PTM], fb[2][PTN];
+    auto load_frags = [&](int slot, int ks, bf16x8 (&a)[PTM], bf16x8 (&b)[PTN]) {
+        if constexpr ((dbg & 16) != 0) {
+#pragma unroll
+            for (int j = 0; j < PTN; ++j) asm volatile("" : "+v"(b[j]));
+#pragma unroll
+            for (int i = 0; i < PTM; ++i) asm volatile("" : "+v"(a[i]));
+            return;
+        }
+        const char* ta = lds + slot * C::STAGE;
+        const char* tb = ta + TA::BYTES;
+#pragma unroll
+        for (int j = 0; j < PTN; ++j) b[j] = TB::frag(tb, (wn * PTN + j) * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < PTM; ++i) a[i] = TA::frag(ta, (wm * PTM + i) * 32, ks, lane);
+    };
+
+    // Two workgroups share a CU and do identical work: started together they would run their main loops and their epilogues
+    // in lockstep.  The second wave of workgroups starts half a tile late so that one's epilogue overlaps the other's MFMAs.
+    if (p.y_f32 > 0 && (int)blockIdx.x >= G / 2)
+        for (int z = 0; z < p.y_f32; ++z) __builtin_amdgcn_s_sleep(16);
+
+    issue(0);
+    if (S > 1) issue(1);
+    if (S > 2) issue(2);
+    if (S > 2) wait_vm_le<2 * C::LPS>();
+    else if (S > 1) wait_vm_le<C::LPS>();
+    else wait_vm_le<0>();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(0, 0, fa[0], fb[0]);
+
+    constexpr int NST = (EPI == EPI_BIAS_GELU ? 2 : 1) * PTM * 4;   // global stores per lane and epilogue
+    int slot = 0, s = 0, since = 2;                                  // since = steps since the last epilogue
+    int tile = cslot;
+    for (int t = 0; t < nloc; ++t, tile += G) {
+        // the accumulators live for ONE tile (zeroed here, consumed by the epilogue below): no loop-carried copies of 128 registers
+        f32x16 acc[PTM][PTN];
+#pragma unroll
+        for (int i = 0; i < PTM; ++i)
+#pragma unroll
+            for (int j = 0; j < PTN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        auto mfmas = [&](const bf16x8 (&a)[PTM], const bf16x8 (&b)[PTN]) {
+            if constexpr ((dbg & 2) != 0) return;
+#pragma unroll
+            for (int i = 0; i < PTM; ++i)
+#pragma unroll
+                for (int j = 0; j < PTN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        };
+        auto front = [&]() {   // all sub-steps but the last: prefetch the next fragments, then the MFMAs of this one
+#pragma unroll
+            for (int ks = 0; ks < C::KS - 1; ++ks) {
+                load_frags(slot, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(fa[ks & 1], fb[ks & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // Every LDS read of this slot has been issued: retire them, make sure stage s+1 has landed, meet the other waves.
+        // Younger operations that may stay in flight: stage s+2 (if there is one) and, in the step right after an epilogue,
+        // that epilogue's NST stores (issued after stage s+1, before stage s+2).  vmcnt retires in order.
+        auto sync = [&]() {
+            const bool young = s + 2 < S;
+            if (young && since == 0) wait_vm_le<C::LPS + NST>();
+            else if (young) wait_vm_le<C::LPS>();
+            else if (since == 0) wait_vm_le<NST>();
+            else wait_vm_le<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (!(dbg & 8)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            front();
+            sync();
+            const int nslot = slot == PNS - 1 ? 0 : slot + 1;
+            if (s + 3 < S && !(dbg & 4)) issue(slot);        // refill the slot every wave has finished reading, three steps ahead
+            load_frags(nslot, 0, fa[0], fb[0]);              // first fragments of the next step, hidden behind the last MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(fa[(C::KS - 1) & 1], fb[(C::KS - 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            slot = nslot;
+            ++since;
+            ++s;
+        }
+        // ---- last step of the tile: this wave's own pieces of the free slot first serve as the epilogue's staging buffer
+        front();
+        sync();
+        mfmas(fa[(C::KS - 1) & 1], fb[(C::KS - 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        since = 0;
+        {
+            // acc[i][j][r] = out[m][n], m = m0 + wm 128 + 32 i + (lane & 31), n = n0 + wn 64 + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3).
+            // Staged per wave through LDS (32 rows x 128 B in this wave's own four 1-KiB LDS-DMA pieces of the free slot, 16-B
+            // chunks XOR-swizzled by (row >> 1) & 7) so that the tile leaves as full 128-B rows: 16-B stores, 8 lanes per row.
+            const int m0 = (tile / ntn) * PBM, n0 = (tile % ntn) * PBN;
+            if constexpr ((dbg & 1) != 0) {
+#pragma unroll
+                for (int i = 0; i < PTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < PTN; ++j) asm volatile("" ::"v"(acc[i][j]));
+            } else {
+                char* stg = lds + slot * C::STAGE + wave * 1024;
+                const int mrow = lane & 31, h = lane >> 5;
+                char* wrow = stg + (mrow >> 3) * 4096 + (mrow & 7) * 128 + 8 * h;
+                const int wsw = (mrow >> 1) & 7;
+                const int nb = n0 + wn * 64 + 4 * h;
+                auto flush = [&](int i, void* out, long ldo) {   // staged 32 x 64 tile -> global, 4 x 16 B per lane
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int q = q4 * 64 + lane, row = q >> 3, ch = q & 7;
+                        const uint4 v = *(const uint4*)(stg + (row >> 3) * 4096 + (row & 7) * 128 + 16 * (ch ^ ((row >> 1) & 7)));
+                        int m = m0 + wm * 128 + 32 * i + row;
+                        m = m < p.M ? m : p.M - 1;   // rows past M replicate row M-1 exactly (clamped A loads): identical duplicate
+                        *(uint4*)((bf16*)out + (long)m * ldo + n0 + wn * 64 + 8 * ch) = v;   // stores, data-independent store count
+                    }
+                };
+#pragma unroll
+                for (int i = 0; i < PTM; ++i) {
+                    bf16x4 second[PTN][4];
+#pragma unroll
+                    for (int j = 0; j < PTN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 bq = (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) ? *(const float4*)(lbias + nb + 32 * j + 8 * g)
+                                                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                            float v[4] = {acc[i][j][4 * g] + bq.x, acc[i][j][4 * g + 1] + bq.y, acc[i][j][4 * g + 2] + bq.z,
+                                          acc[i][j][4 * g + 3] + bq.w};
+                            bf16x4 w0;
+                            if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float cdf, ex;
+                                    gelu_parts_fast(v[e], cdf, ex);
+                                    w0[e] = (bf16)fmaf(v[e] * 0.39894228040143267794f, ex, cdf);   // gelu'(pre)
+                                    second[j][g][e] = (bf16)(v[e] * cdf);                          // gelu(pre)
+                                }
+                            } else if (EPI == EPI_GELU_BWD) {
+                                int m = m0 + wm * 128 + 32 * i + mrow;
+                                m = m < p.M ? m : p.M - 1;
+                                const bf16x4 ax = *(const bf16x4*)((const bf16*)p.aux + (long)m * p.ldaux + nb + 32 * j + 8 * g);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) w0[e] = (bf16)(v[e] * (float)ax[e]);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) w0[e] = (bf16)v[e];
+                            }
+                            *(bf16x4*)(wrow + 16 * ((4 * j + g) ^ wsw)) = w0;
+                        }
+                    flush(i, p.out0, p.ldo0);
+                    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int j = 0; j < PTN; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) *(bf16x4*)(wrow + 16 * ((4 * j + g) ^ wsw)) = second[j][g];
+                        flush(i, p.out1, p.ldo1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the four row groups apart: interleaved, their temporaries spill
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's staging reads are done: its pieces may be refilled
+        __builtin_amdgcn_sched_barrier(0);
+        const int nslot = slot == PNS - 1 ? 0 : slot + 1;
+        if (s + 3 < S && !(dbg & 4)) issue(slot);
+        if (s + 1 < S) load_frags(nslot, 0, fa[0], fb[0]);
+        slot = nslot;
+        ++s;
+    }
+}
+
+template <int EPI, int BKB> int launch_pers_v(const GemmP& p, hipStream_t st, int wgs_per_cu) {
+    const int ntm = (p.M + PBM - 1) / PBM, ntn = p.N / PBN;
+    const int ntiles = ntm * ntn;
+    const int cap = 256 * wgs_per_cu;
+    const int G = ntiles < cap ? ntiles : cap;
+    constexpr int bytes = PCfg<BKB>::LDS_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_pers_kernel<EPI, BKB>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr = true;
+    }
+    ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K, 0, st);
+    GemmP q = p;
+    static const int stagger = [] { const char* e = getenv("MFVIT_PERS_STAGGER"); return e ? atoi(e) : 0; }();
+    q.y_f32 = wgs_per_cu > 1 ? stagger : 0;   // field reused as the stagger length (x 1024 cycles)
+    MFVIT_LAUNCH((gemm_nt_pers_kernel<EPI, BKB>), dim3(G), dim3(256), bytes, st, q, ntm, ntn);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+template <int EPI> int launch_pers(const GemmP& p, hipStream_t st) {
+    static const int bk = [] { const char* e = getenv("MFVIT_PERS_BK"); return e ? atoi(e) : 32; }();
+    if (bk == 64 && p.K % 64 == 0) return launch_pers_v<EPI, 128>(p, st, 1);
+    return launch_pers_v<EPI, 64>(p, st, 2);
+}
+
+}  // namespace
+
+// Opt-in (MFVIT_PERS=1, or the mfvit_linear_fwd_persistent entry point): measured on MI355X it ties the 128x128 kernel on an
+// isolated launch (qkv 38.0 vs 39.6 us, fc1+GELU 82 vs 80 us) and loses ~3 % inside the four-stream training step, where the
+// many small workgroups of the 128x128 kernel interleave better with the co-scheduled kernels of the other streams.
+bool gemm_nt_pers_supported(int dtype, int epi, const GemmP& p, bool force) {
+    static const int on = [] { const char* e = getenv("MFVIT_PERS"); return e ? atoi(e) : 0; }();
+    if ((!on && !force) || dtype != MFVIT_BF16 || p.nb > 1 || p.M < 1024) return false;
+    if (p.N % PBN || p.N > PMAXN || p.K % 32 || p.K < 128) return false;
+    if (epi == EPI_GELU_BWD && p.cs0) return false;            // column sums stay with the 128x128 kernel
+    if ((long)p.M * p.lda * 2 >= (1L << 32) || (long)p.N * p.ldw * 2 >= (1L << 32)) return false;   // 32-bit byte offsets
+    if (p.lda % 8 || p.ldw % 8 || p.ldo0 % 4 || (p.out1 && p.ldo1 % 4) || (p.aux && p.ldaux % 4)) return false;
+    return true;
+}
+
+int gemm_nt_pers(int epi, const GemmP& p, hipStream_t st) {
+    switch (epi) {
+        case EPI_BIAS: return launch_pers<EPI_BIAS>(p, st);
+        case EPI_BIAS_GELU: return launch_pers<EPI_BIAS_GELU>(p, st);
+        case EPI_GELU_BWD: return launch_pers<EPI_GELU_BWD>(p, st);
+        case EPI_NONE: return launch_pers<EPI_NONE>(p, st);
+    }
+    return MFVIT_EINVAL;
+}
+
+}  // namespace mfvit

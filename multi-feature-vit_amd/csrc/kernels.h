@@ -8,6 +8,8 @@ enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GELU_BWD = 2, EPI_NONE = 3 };
 enum { REPI_RES_LN = 0, REPI_LNBWD_RES = 1 };
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st);
+bool gemm_nt_pers_supported(int dtype, int epi, const GemmP& p, bool force = false);   // gemm_pers.hip: persistent 256x128 kernel (bf16, short K)
+int gemm_nt_pers(int epi, const GemmP& p, hipStream_t st);
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st);
 int gemm_tn(int dtype, const GemmP& p, hipStream_t st);
 int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float* d1, float* d2, hipStream_t st);

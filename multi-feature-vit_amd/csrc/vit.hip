@@ -4,6 +4,7 @@
 #include "../../include/mfvit.h"
 #include "kernels.h"
 
+#include <atomic>
 #include <stdlib.h>
 #include <string.h>
 
@@ -114,7 +115,7 @@ struct WsLayout {
     size_t blk0, blk_stride;    // per block (depth or 1 copies):
     size_t y1, qkv, attn, lse, xmid, st2, y2, hpre, hact;
     // backward scratch
-    size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart;
+    size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart, tnpart;
     size_t pp_stride;           // distance between the two ping-pong copies of gxT / gmidT / dhpre / dqkv (0 = none)
     size_t total;
 };
@@ -157,8 +158,11 @@ WsLayout ws_layout(const Dims& d) {
             n = n > c2 ? n : c2;
             W.colpart = o; o += align256(n * 4);
         }
+        // split partials of the weight-gradient GEMMs (side stream, one GEMM at a time): splits * N * K floats, and
+        // tiles * splits <= 384 blocks of 128 x 128  =>  at most 384 * 16384 floats
+        W.tnpart = o; o += align256((size_t)384 * 128 * 128 * 4);
     } else {
-        W.gx = W.gmid = W.gxT = W.gmidT = W.dhpre = W.dattn = W.dqkv = W.colscratch = W.colpart = o;
+        W.gx = W.gmid = W.gxT = W.gmidT = W.dhpre = W.dattn = W.dqkv = W.colscratch = W.colpart = W.tnpart = o;
         W.pp_stride = 0;
     }
     W.total = o;
@@ -180,6 +184,7 @@ struct SideStream {
     hipEvent_t done[64] = {};
     bool ok = false;
 };
+std::atomic<int> g_wgrad_stream{1};   // runtime switch (mfvit_set_wgrad_stream): attribution passes serialise the backward
 SideStream& side_stream(hipStream_t caller) {
     // one side stream per (thread, caller stream): two encoders running on two caller streams do not share a side queue
     static thread_local SideStream ss[8];
@@ -217,6 +222,10 @@ SideStream& side_stream(hipStream_t caller) {
 extern "C" {
 
 int mfvit_abi_version(void) { return 1; }
+int mfvit_set_wgrad_stream(int enabled) {
+    g_wgrad_stream.store(enabled ? 1 : 0, std::memory_order_relaxed);
+    return MFVIT_OK;
+}
 const char* mfvit_build_info(void) { return "libmfvit_hip gfx950 (MFMA bf16 32x32x16 / f32 32x32x2), wave64"; }
 
 size_t mfvit_vit_param_count(const mfvit_vit_cfg* cfg) {
@@ -386,10 +395,11 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
     float* gmid = (float*)(ws + W.gmid);
     float* colscr = (float*)(ws + W.colscratch);
     float* colpart = (float*)(ws + W.colpart);
+    float* tnpart = (float*)(ws + W.tnpart);
     // dY buffers by layer parity (the embed stage counts as layer -1 -> parity 1)
     auto pp = [&](size_t off, int l) { return (void*)(ws + off + (size_t)(l & 1) * W.pp_stride); };
     SideStream& ss = side_stream(st);
-    const bool use_side = ss.ok && W.pp_stride != 0;
+    const bool use_side = ss.ok && W.pp_stride != 0 && g_wgrad_stream.load(std::memory_order_relaxed) != 0;
     hipStream_t wst = use_side ? ss.s : st;                       // stream of the weight-gradient GEMMs
     // the side stream may only start after everything already queued on the caller's stream (activations, zeroed gradients)
     auto fork = [&]() -> int {                                    // main -> side dependency at this point of the main stream
@@ -426,15 +436,15 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.A = gxT; p.lda = D; p.W = b + W.hact; p.ldw = F;
                 p.M = d.M; p.N = d.D; p.K = d.F;
                 p.out0 = gb + L.fc2_w; p.ldo0 = F;
+                p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
                 MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
-            {   // dhpre = (gx W2) * gelu'(hpre) ; d fc1_b += colsum
+            {   // dhpre = (gx W2) * gelu'(hpre)
                 GemmP p = zero_gemm();
                 p.A = gxT; p.lda = D; p.W = sb + S.fc2_t; p.ldw = D;
                 p.M = d.M; p.N = d.F; p.K = d.D;
                 p.aux = b + W.hpre; p.ldaux = F;
                 p.out0 = dhpre; p.ldo0 = F;
-                p.cs0 = gb + L.fc1_b; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_GELU_BWD, p, st));
             }
             MFVIT_TRY(fork());
@@ -442,7 +452,9 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 GemmP p = zero_gemm();
                 p.A = dhpre; p.lda = F; p.W = b + W.y2; p.ldw = D;
                 p.M = d.M; p.N = d.F; p.K = d.D;
+                p.cs0 = gb + L.fc1_b;                             // d fc1_b += column sums of dhpre (ones-fragment MFMA in the wgrad kernel)
                 p.out0 = gb + L.fc1_w; p.ldo0 = D;
+                p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
                 MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
             {   // gmid = LN2bwd(dhpre W1) + gx ; d ln2_w, d ln2_b, d proj_b
@@ -463,6 +475,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.A = gmidT; p.lda = D; p.W = b + W.attn; p.ldw = D;
                 p.M = d.M; p.N = d.D; p.K = d.D;
                 p.out0 = gb + L.proj_w; p.ldo0 = D;
+                p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
                 MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
             {   // dattn = gmid Wproj
@@ -481,6 +494,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.M = d.M; p.N = 3 * d.D; p.K = d.D;
                 p.cs0 = gb + L.qkv_b;
                 p.out0 = gb + L.qkv_w; p.ldo0 = D;
+                p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
                 MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
             if (use_side && hipEventRecord(ss.done[l & 63], ss.s) != hipSuccess) return MFVIT_ELAUNCH;
@@ -533,12 +547,32 @@ int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const 
     p.bias = bias; p.out0 = y; p.ldo0 = ldy; p.out1 = y2; p.ldo1 = ldy2;
     return gemm_nt_tile(dtype, epilogue, p, (hipStream_t)stream);
 }
+int mfvit_linear_fwd_persistent(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
+                                int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream) {
+    if (!x || !w || !y) return MFVIT_EINVAL;
+    if (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU && epilogue != EPI_NONE) return MFVIT_EINVAL;
+    if (epilogue == EPI_BIAS_GELU && !y2) return MFVIT_EINVAL;
+    GemmP p = zero_gemm();
+    p.A = x; p.lda = ldx; p.W = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
+    p.bias = bias; p.out0 = y; p.ldo0 = ldy; p.out1 = y2; p.ldo1 = ldy2;
+    if (!gemm_nt_pers_supported(MFVIT_BF16, epilogue, p, true)) return MFVIT_EINVAL;
+    return gemm_nt_pers(epilogue, p, (hipStream_t)stream);
+}
 int mfvit_linear_wgrad(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N, int K,
                        mfvit_stream_t stream) {
     if (!dy || !x || !dw) return MFVIT_EINVAL;
     GemmP p = zero_gemm();
     p.A = dy; p.lda = lddy; p.W = x; p.ldw = ldx; p.M = M; p.N = N; p.K = K;
     p.out0 = dw; p.ldo0 = lddw;
+    return gemm_tn(dtype, p, (hipStream_t)stream);
+}
+int mfvit_linear_wgrad_ws(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N,
+                          int K, float* scratch, mfvit_stream_t stream) {
+    if (!dy || !x || !dw) return MFVIT_EINVAL;
+    GemmP p = zero_gemm();
+    p.A = dy; p.lda = lddy; p.W = x; p.ldw = ldx; p.M = M; p.N = N; p.K = K;
+    p.out0 = dw; p.ldo0 = lddw;
+    p.cpart = scratch;
     return gemm_tn(dtype, p, (hipStream_t)stream);
 }
 int mfvit_linear_res_ln_fwd(int dtype, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res,

@@ -12,7 +12,7 @@ import torch  # noqa: F401  MUST precede loading libmfvit_hip.so: torch bundles 
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmfvit_hip.so")
+LIB_PATH = os.environ.get("MFVIT_LIB") or os.path.join(_HERE, "libmfvit_hip.so")   # MFVIT_LIB: experiment builds
 
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_GELU, EPI_NONE = 0, 1, 3
@@ -46,7 +46,9 @@ SIGNATURES = {
     "mfvit_vit_forward": (I, [POINTER(VitCfg), P, P, P, P, P, P]),
     "mfvit_vit_backward": (I, [POINTER(VitCfg), P, P, P, P, P, I, I, P]),
     "mfvit_linear_fwd": (I, [I, I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
+    "mfvit_linear_fwd_persistent": (I, [I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
     "mfvit_linear_wgrad": (I, [I, P, L, P, L, P, L, I, I, I, P]),
+    "mfvit_linear_wgrad_ws": (I, [I, P, L, P, L, P, L, I, I, I, P, P]),
     "mfvit_linear_res_ln_fwd": (I, [I, P, L, P, L, P, P, L, P, P, I, P, P, F, P, P, I, I, P]),
     "mfvit_linear_dgrad_ln_bwd": (I, [I, P, L, P, L, P, P, P, P, P, P, P, P, P, P, I, I, P]),
     "mfvit_attention_fwd": (I, [I, P, P, P, I, I, I, I, P]),
@@ -76,6 +78,7 @@ SIGNATURES = {
     "mfvit_prenorm_xattn_forward": (I, [POINTER(FusionCfg), P, P, P, P, P, P]),
     "mfvit_prenorm_xattn_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P]),
     "mfvit_prof_enable": (I, [I]),
+    "mfvit_set_wgrad_stream": (I, [I]),
     "mfvit_prof_collect": (I, [POINTER(ctypes.c_double), I]),
     "mfvit_prof_class_name": (c_char_p, [I]),
     "mfvit_fusion_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),

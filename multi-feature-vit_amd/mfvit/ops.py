@@ -21,8 +21,9 @@ def _code_of(t):
     raise _lib.MfvitError(f"unsupported dtype {t.dtype}")
 
 
-def linear_fwd(x, w, bias=None, gelu=False):
-    """y = x @ w.T + bias (x [M,K], w [N,K] of the same dtype).  gelu=True returns (gelu'(y), gelu(y))."""
+def linear_fwd(x, w, bias=None, gelu=False, persistent=False):
+    """y = x @ w.T + bias (x [M,K], w [N,K] of the same dtype).  gelu=True returns (gelu'(y), gelu(y)).
+    persistent=True runs the experimental persistent 256x128 kernel (bf16 only)."""
     require_cuda(x, w, bias)
     code = _code_of(x)
     M, K = x.shape
@@ -30,21 +31,35 @@ def linear_fwd(x, w, bias=None, gelu=False):
     y = torch.empty(M, N, device=x.device, dtype=x.dtype)
     y2 = torch.empty_like(y) if gelu else None
     epi = EPI_BIAS_GELU if gelu else (EPI_BIAS if bias is not None else EPI_NONE)
+    if persistent:
+        check(lib().mfvit_linear_fwd_persistent(epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N, ptr(y2), N, M, N, K,
+                                                stream()), "mfvit_linear_fwd_persistent")
+        return (y, y2) if gelu else y
     check(lib().mfvit_linear_fwd(code, epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N, ptr(y2), N, M, N, K,
                                  stream()), "mfvit_linear_fwd")
     return (y, y2) if gelu else y
 
 
-def linear_wgrad(dy, x, out=None):
-    """dW [N,K] (f32) += dy[M,N].T @ x[M,K]."""
+WGRAD_SCRATCH_FLOATS = 384 * 128 * 128   # include/mfvit.h: MFVIT_WGRAD_SCRATCH_FLOATS
+
+
+def linear_wgrad(dy, x, out=None, scratch=None):
+    """dW [N,K] (f32) += dy[M,N].T @ x[M,K].  scratch: optional f32 tensor of WGRAD_SCRATCH_FLOATS elements (split partials
+    as plain stores + a reduce pass instead of float atomics)."""
     require_cuda(dy, x)
     code = _code_of(dy)
     M, N = dy.shape
     K = x.shape[1]
     if out is None:
         out = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
-    check(lib().mfvit_linear_wgrad(code, ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(out), out.stride(0), M, N, K, stream()),
-          "mfvit_linear_wgrad")
+    if scratch is not None:
+        if scratch.dtype != torch.float32 or scratch.numel() < WGRAD_SCRATCH_FLOATS:
+            raise _lib.MfvitError("wgrad scratch must be float32 with at least WGRAD_SCRATCH_FLOATS elements")
+        check(lib().mfvit_linear_wgrad_ws(code, ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(out), out.stride(0), M, N, K,
+                                          ptr(scratch), stream()), "mfvit_linear_wgrad_ws")
+    else:
+        check(lib().mfvit_linear_wgrad(code, ptr(dy), dy.stride(0), ptr(x), x.stride(0), ptr(out), out.stride(0), M, N, K, stream()),
+              "mfvit_linear_wgrad")
     return out
 
 

@@ -59,8 +59,29 @@ def test_linear_fwd(dtype, M, N, K):
     assert e1 < tol(dtype) and e2 < tol(dtype)
 
 
+@pytest.mark.parametrize("M,N,K", [(197 * 128, 1152, 384), (197 * 33 + 5, 1536, 384), (1100, 384, 1536), (4096, 128, 128)])
+def test_linear_fwd_persistent(M, N, K):
+    """The experimental persistent 256x128 kernel (csrc/gemm_pers.hip) against the same f64 reference and, bit for bit in the
+    bias epilogue, against the default 128x128 kernel (same products, same f32 accumulation order per output element)."""
+    from mfvit import ops
+    dtype = torch.bfloat16
+    x, w, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, 0.05), rnd((N,), torch.float32, 3)
+    xd, wd, bd = x.to(dev()), w.to(dev()), b.to(dev())
+    y = ops.linear_fwd(xd, wd, bd, persistent=True)
+    ref = x.double() @ w.double().t() + b.double()
+    e = rel_err(y, ref)
+    log(f"linear_fwd_persistent[{M},{N},{K}]", e)
+    assert e < tol(dtype)
+    assert torch.equal(y, ops.linear_fwd(xd, wd, bd))
+    dact, act = ops.linear_fwd(xd, wd, bd, gelu=True, persistent=True)
+    dact0, act0 = ops.linear_fwd(xd, wd, bd, gelu=True)
+    assert torch.equal(dact, dact0) and torch.equal(act, act0)
+    y3 = ops.linear_fwd(xd, wd, None, persistent=True)
+    assert torch.equal(y3, ops.linear_fwd(xd, wd, None))
+
+
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,N,K", [(777, 256, 384), (197 * 4, 1152, 384), (100, 384, 1536), (31, 128, 128)])
+@pytest.mark.parametrize("M,N,K", [(777, 256, 384), (197 * 4, 1152, 384), (100, 384, 1536), (31, 128, 128), (197 * 64, 1152, 384)])
 def test_linear_wgrad(dtype, M, N, K):
     from mfvit import ops
     dy, x = rnd((M, N), dtype, 4), rnd((M, K), dtype, 5)
@@ -76,6 +97,10 @@ def test_linear_wgrad(dtype, M, N, K):
     # accumulation into an existing gradient
     dw2 = ops.linear_wgrad(dy.to(dev()), x.to(dev()), out=dw.clone())
     assert rel_err(dw2, 2 * ref) < (2e-5 if dtype == torch.float32 else 1e-4)
+    # split partials through caller scratch (plain stores + reduce pass) instead of float atomics: same result, accumulating
+    scratch = torch.empty(ops.WGRAD_SCRATCH_FLOATS, device=dev())
+    dw3 = ops.linear_wgrad(dy.to(dev()), x.to(dev()), out=dw.clone(), scratch=scratch)
+    assert rel_err(dw3, 2 * ref) < (2e-5 if dtype == torch.float32 else 1e-4)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -1,0 +1,49 @@
+"""Run ONE op of the hot path a few times (for rocprofv3 --pmc passes): python3 tools/one_op.py <op> [n]."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "multi-feature-vit_amd"))
+import torch
+from mfvit import ops
+dev = torch.device("cuda:0")
+M, D = 128 * 197, 384
+op = sys.argv[1]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+def r(*s, dt=torch.bfloat16, sc=1.0): return (torch.randn(*s, device=dev) * sc).to(dt)
+if op == "qkv":
+    x, w, b = r(M, D), r(3 * D, D, sc=.05), r(3 * D, dt=torch.float32)
+    fn = lambda: ops.linear_fwd(x, w, b)
+elif op == "fc1":
+    x, w, b = r(M, D), r(4 * D, D, sc=.05), r(4 * D, dt=torch.float32)
+    fn = lambda: ops.linear_fwd(x, w, b, gelu=True)
+elif op == "dgrad_fc1":   # dY[M,1536] @ W[384,1536]^T... plain tile GEMM N=384? (runs on the row kernel in the encoder)
+    x, w = r(M, 4 * D), r(D, 4 * D, sc=.05)
+    fn = lambda: ops.linear_fwd(x, w, None)
+elif op == "wgrad_fc1":
+    dy, x = r(M, 4 * D), r(M, D)
+    out = torch.zeros(4 * D, D, device=dev)
+    fn = lambda: ops.linear_wgrad(dy, x, out=out)
+elif op == "wgrad_qkv":
+    dy, x = r(M, 3 * D), r(M, D)
+    out = torch.zeros(3 * D, D, device=dev)
+    fn = lambda: ops.linear_wgrad(dy, x, out=out)
+elif op in ("row_proj", "row_fc2"):
+    K = D if op == "row_proj" else 4 * D
+    a, w, b = r(M, K), r(D, K, sc=.05), r(D, dt=torch.float32)
+    res, g, be = r(M, D, dt=torch.float32), r(D, dt=torch.float32), r(D, dt=torch.float32)
+    fn = lambda: ops.linear_res_ln_fwd(a, w, b, res, g, be, 1e-6)
+elif op in ("rowb_proj", "rowb_fc1"):   # dgrad + LN backward: dy [M,K] @ wt[384,K]^T
+    K = 3 * D if op == "rowb_proj" else 4 * D
+    dy, wt = r(M, K), r(D, K, sc=.05)
+    x = r(M, D, dt=torch.float32); mean = x.mean(1); rstd = 1 / x.std(1)
+    g, dres = r(D, dt=torch.float32), r(M, D, dt=torch.float32)
+    fn = lambda: ops.linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, g, dres)
+elif op in ("attn_fwd", "attn_bwd"):
+    qkv = r(128, 197, 3 * D)
+    o, lse = ops.attention_fwd(qkv, 12)
+    do = r(128, 197, D)
+    fn = (lambda: ops.attention_fwd(qkv, 12)) if op == "attn_fwd" else (lambda: ops.attention_bwd(qkv, o, do, lse, 12, want_dbias=False))
+else:
+    raise SystemExit("unknown op")
+for _ in range(n):
+    fn()
+torch.cuda.synchronize()

@@ -53,6 +53,11 @@ if tag in ("default", "2"):
     timeit(lambda: ops.linear_wgrad(x384, x1536, out=out3), 2.0 * M * D * F, "wgrad fc2  [384x1536]")
     out4 = torch.zeros(D, D, device=dev)
     timeit(lambda: ops.linear_wgrad(x384, x384, out=out4), 2.0 * M * D * D, "wgrad proj [384x384]")
+    scr = torch.empty(ops.WGRAD_SCRATCH_FLOATS, device=dev)
+    timeit(lambda: ops.linear_wgrad(dy1152, x384, out=out, scratch=scr), 2.0 * M * D * 3 * D, "wgrad qkv  + scratch")
+    timeit(lambda: ops.linear_wgrad(dy1536, x384, out=out2, scratch=scr), 2.0 * M * D * F, "wgrad fc1  + scratch")
+    timeit(lambda: ops.linear_wgrad(x384, x1536, out=out3, scratch=scr), 2.0 * M * D * F, "wgrad fc2  + scratch")
+    timeit(lambda: ops.linear_wgrad(x384, x384, out=out4, scratch=scr), 2.0 * M * D * D, "wgrad proj + scratch")
     qkv = r(128, 197, 3 * D)
     o, lse = ops.attention_fwd(qkv, 12)
     timeit(lambda: ops.attention_fwd(qkv, 12), 4.0 * 128 * 12 * 197 * 197 * 32, "attention fwd")
