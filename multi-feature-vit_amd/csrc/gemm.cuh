@@ -194,6 +194,7 @@ struct GemmP {
                        // hundreds of workgroups hammering the same few hundred addresses with float atomics (14x slower)
     int y_f32;
     int splits;        // wgrad: number of m-splits (grid.y)
+    int rows_per_wg;   // row kernels: token rows owned by one workgroup (<= its tile height; 0 = the tile height), see launch_row
     // two-level batch over blockIdx.z = zo * nbi + zi (element offsets; bias/out0 only)
     int nb, nbi;
     long sAo, sAi, sWo, sWi, sOo, sOi, sBo, sBi;

@@ -167,7 +167,12 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
     typedef NtLoop<T, BM, BN, BKB, WM, WN> Loop;
     constexpr int TM = Loop::TM, TN = Loop::TN;  // (2 | 1) x 3
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int m0 = blockIdx.x * BM;
+    // A workgroup owns rows [m0, m0 + rows_per_wg) of its BM-row MFMA tile; the rest of the tile is padding (clamped loads,
+    // duplicate stores).  rows_per_wg is chosen so that the grid is just under a multiple of the CU count: at M = 25,216 full
+    // 128-row tiles make 197 workgroups for 256 CUs (77 %), 99 rows each make 255.
+    const int rpw = p.rows_per_wg > 0 ? p.rows_per_wg : BM;
+    const int m0 = blockIdx.x * rpw;
+    p.M = p.M < m0 + rpw ? p.M : m0 + rpw;   // everything below treats rows >= p.M as padding
     f32x16 acc[TM][TN];
     Loop::run(p, m0, 0, lds, acc);  // ends with a barrier: the staging LDS is free from here on
 
@@ -557,7 +562,26 @@ static int row_variant() {   // MFVIT_ROW_VARIANT: 0 = 4 waves (1x4), BK 64 B ro
     static const int v = [] { const char* e = getenv("MFVIT_ROW_VARIANT"); return e ? atoi(e) : 2; }();
     return v;
 }
-template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v(const GemmP& p, hipStream_t st) {
+static int row_grid(const GemmP& p, int BM) {
+    const int rpw = p.rows_per_wg > 0 ? p.rows_per_wg : BM;
+    return (p.M + rpw - 1) / rpw;
+}
+// rows per workgroup that fill the chip evenly: the smallest whole number of rounds of 256 workgroups (one per CU) that covers M
+// with tiles of BM rows, then the rows spread evenly over rounds * 256 workgroups.  OPT-IN (MFVIT_ROW_BALANCE=1): measured on
+// MI355X it is 6-15 % SLOWER than full tiles (fc2+LN 80.8 vs 75.9 us, qkv-dgrad+LN-backward 93 vs 80 us) - every workgroup streams
+// the whole W[384][K] from L2, so 505 workgroups of 50 rows move more operand bytes than 394 of 64, and that traffic, not the
+// 77 % grid fill, is what bounds these kernels.
+static int balanced_rows(int M, int BM) {
+    static const bool on = [] { const char* e = getenv("MFVIT_ROW_BALANCE"); return e && e[0] == '1'; }();
+    if (!on || M < 256 * 32) return 0;
+    const int rounds = (M + 256 * BM - 1) / (256 * BM);
+    int rpw = (M + 256 * rounds - 1) / (256 * rounds);
+    if (rpw < 32) rpw = 32;
+    return rpw >= BM ? 0 : rpw;
+}
+template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v(const GemmP& pin, hipStream_t st) {
+    GemmP p = pin;
+    p.rows_per_wg = balanced_rows(p.M, BM);
     typedef NtLoop<T, BM, ROW_BN, BKB, WM, 4> Loop;
     if (p.N != ROW_BN || p.K % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
     constexpr int need = BM * ROW_RS * 4 + BM * 4;
@@ -570,7 +594,7 @@ template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v
         attr_set = true;
     }
     ProfScope ps(REPI == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
-    MFVIT_LAUNCH((gemm_nt_row_kernel<T, REPI, WM, BKB, BM>), dim3((p.M + BM - 1) / BM), dim3(WM * 256), bytes, st, p);
+    MFVIT_LAUNCH((gemm_nt_row_kernel<T, REPI, WM, BKB, BM>), dim3(row_grid(p, BM)), dim3(WM * 256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -675,7 +699,9 @@ int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
     if (repi == REPI_LNBWD_RES) {
         const int rc = dtype == MFVIT_BF16 ? launch_row<bf16, REPI_LNBWD_RES>(p, st) : launch_row<float, REPI_LNBWD_RES>(p, st);
         if (rc != MFVIT_OK || !p.cpart) return rc;
-        return colpart_reduce(p.cpart, (p.M + 63) / 64, ROW_BN, 3, p.cs0, p.cs1, p.cs2, st);
+        GemmP q = p;
+        q.rows_per_wg = balanced_rows(p.M, 64);     // the LN-backward variants all use 64-row tiles (see launch_row)
+        return colpart_reduce(p.cpart, row_grid(q, 64), ROW_BN, 3, p.cs0, p.cs1, p.cs2, st);
     }
     return MFVIT_EINVAL;
 }

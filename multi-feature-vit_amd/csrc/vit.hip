@@ -153,7 +153,7 @@ WsLayout ws_layout(const Dims& d) {
         W.dattn = o; o += align256(M * D * es);
         W.colscratch = o; o += align256(2 * D * 4);
         {   // per-workgroup column-sum partials: max over the kernels that use them
-            size_t a = ((M + 63) / 64) * 3 * D, b2 = ((M + 127) / 128) * F, c2 = 256 * 3 * D;
+            size_t a = ((M + 63) / 64 + 256) * 3 * D, b2 = ((M + 127) / 128) * F, c2 = 256 * 3 * D;   // row kernels: <= M/64 + 256 blocks (balanced rows)
             size_t n = a > b2 ? a : b2;
             n = n > c2 ? n : c2;
             W.colpart = o; o += align256(n * 4);
