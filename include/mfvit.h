@@ -132,6 +132,15 @@ int mfvit_head_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, c
 int mfvit_cross_entropy(const float* logits, const int64_t* target, float* loss_mean, float* dlogits, int64_t* preds, int B, int C,
                         mfvit_stream_t stream);
 
+/* Epoch metrics on the device (replaces the per-batch .cpu() copies MAIN_CA:886-899 and the scikit-learn calls
+ * MAIN_CA:901-911).  scores f32 [n][C] (row stride ld), labels int64 [n].  ACCUMULATES into caller-zeroed uint64 arrays:
+ * confusion[t][p] (+ optional preds[n] = first-maximum argmax, as torch.max MAIN_CA:870), and per class c the pair counts of the
+ * one-vs-rest ROC AUC: u2[c] = 2 #{(pos, neg): s_pos > s_neg} + #{s_pos == s_neg}, npos[c] = #{label == c}; AUC_c = u2 /
+ * (2 npos (n - npos)) = the trapezoid area of sklearn's roc_curve.  The pair counts are over THIS call's n samples (call it
+ * once on the whole epoch's scores); the confusion matrix may be accumulated batch by batch.  Either half may be NULL. */
+int mfvit_eval_counts(const float* scores, int64_t ld, const int64_t* labels, int n, int C, uint64_t* confusion, int64_t* preds,
+                      uint64_t* u2, uint64_t* npos, mfvit_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Two-stream fusion: bidirectional cls<->patch cross-attention exchange + heads (f32).
  * Replaces PreNorm / CrossAttention (MOD:15-21,108-137), MultiScaleTransformerEncoder.forward (FUS:35-65) and

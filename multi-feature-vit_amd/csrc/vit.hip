@@ -537,6 +537,12 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
 }
 
 // ------------------------------------------------------------------------------------------------ single ops
+int mfvit_eval_counts(const float* scores, int64_t ld, const int64_t* labels, int n, int C, uint64_t* confusion, int64_t* preds,
+                      uint64_t* u2, uint64_t* npos, mfvit_stream_t stream) {
+    if (!scores || !labels || (!confusion && !(u2 && npos))) return MFVIT_EINVAL;
+    return eval_counts(scores, ld, labels, n, C, (unsigned long long*)confusion, (unsigned long long*)u2, (unsigned long long*)npos, preds,
+                       (hipStream_t)stream);
+}
 int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                      int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream) {
     if (!x || !w || !y) return MFVIT_EINVAL;

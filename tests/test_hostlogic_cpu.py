@@ -112,3 +112,44 @@ def test_two_rank_gloo_paths():
         assert p.exitcode == 0
     for rank, ok1, ok2, ok3, ok4 in res:
         assert ok1 and ok2 and ok3 and ok4, (rank, ok1, ok2, ok3, ok4)
+
+
+def test_checkpoint_layouts_and_pretrained_load(tmp_path):
+    """the dict layouts the drivers save (MAIN_MOCO:461-467, MAIN_SS:567-575, MAIN_CA:712-720, 1002-1011) and the
+    key surgery that loads a MoCo pretraining checkpoint into a finetune backbone (MAIN_SS:326-337), on this package's modules."""
+    import vits
+    from mfvit import checkpoint as ck
+    from moco.optimizer import LARS
+    bld, m = _moco()
+    opt = LARS(m.parameters(), 0.3, weight_decay=1e-6, momentum=0.9)
+    state = ck.pretrain_checkpoint(m, opt, epoch=4, arch="vit_small")
+    assert list(state.keys()) == ["epoch", "arch", "state_dict", "optimizer"] and state["epoch"] == 5
+    # what DistributedDataParallel would have saved: every key behind 'module.'
+    state["state_dict"] = {"module." + k: v for k, v in state["state_dict"].items()}
+    path = ck.save_checkpoint(str(tmp_path), state, is_best=False, filename="checkpoint_0004.pth.tar")
+    assert os.path.basename(path) == "checkpoint_0004.pth.tar"
+    assert os.path.basename(ck.save_checkpoint(str(tmp_path), state, is_best=True)) == "model_best.pth.tar"   # MAIN_CA:1006-1009
+
+    torch.manual_seed(123)
+    ft = vits.vit_small(num_classes=3, depth=1)                                              # MAIN_SS:276 + :309-style 3-class head (depth 1 as _moco())
+    msg = ck.load_pretrained_backbone(ft, path)
+    assert set(msg.missing_keys) == {"head.weight", "head.bias"} and not msg.unexpected_keys
+    sd = ft.state_dict()
+    for k, v in m.base_encoder.state_dict().items():
+        if not k.startswith("head."):
+            assert torch.equal(sd[k], v), k
+    assert ck.sanity_check(ft.state_dict(), path)                                            # nothing but the head differs
+    with torch.no_grad():
+        ft.blocks[0].mlp.fc1.bias.add_(1.0)
+    with pytest.raises(AssertionError, match="is changed in linear classifier training"):
+        ck.sanity_check(ft.state_dict(), path)
+    assert ck.sanity_check(ft.state_dict(), path, semi_supervised=True)                      # skipped, MAIN_CA:1018-1020
+
+    opt2 = torch.optim.SGD(ft.parameters(), lr=0.1)
+    fin = ck.finetune_checkpoint(ft, opt2, epoch=0, arch="vit_small", best_metric_val=0.9, best_metric_val_test=0.8, best_metric_test=0.85)
+    assert list(fin.keys()) == ["epoch", "arch", "state_dict", "best_metric_val_test", "best_metric_val", "best_metric_test", "optimizer"]
+    fin_ca = ck.finetune_checkpoint(ft, opt2, epoch=0, arch="vit_small", best_metric_val=0.9)
+    assert list(fin_ca.keys()) == ["epoch", "arch", "state_dict", "best_metric_val", "optimizer"]
+    # the stripped dict keeps nothing of the momentum encoder / predictor / queue
+    stripped = ck.strip_moco_prefix(dict(torch.load(path, map_location="cpu")["state_dict"]))
+    assert all(not k.startswith(("module.", "head.")) for k in stripped) and "cls_token" in stripped
