@@ -132,6 +132,19 @@ int mfvit_head_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, c
 int mfvit_cross_entropy(const float* logits, const int64_t* target, float* loss_mean, float* dlogits, int64_t* preds, int B, int C,
                         mfvit_stream_t stream);
 
+/* GPU-side input pipeline (replaces the torchvision / Pillow chain of aihc_utils/image_transform.py:50-84 run by
+ * the DataLoader workers, moco/loader.py:121-137): Resize((S,S), bilinear) -> horizontal flip -> rotation (nearest, fill 0) -> crop
+ * -> ToTensor -> Normalize, fused, bit-exact against Pillow's fixed-point arithmetic.
+ *   src    : decoded uint8 HWC (3 channels, channel order as decoded) images of n samples, packed back to back, on the device
+ *   desc   : device int64 [n][16]: 0 byte offset of the image in src, 1 in_h, 2 in_w, 3 / 4 offsets (in int32 units) of the x / y
+ *            resample tables, 5 / 6 their ksize, 7 flip (0/1), 8 rotation mode (0 none, 1 affine, 2/3/4 = transpose 90/180/270),
+ *            9..14 the 16.16 fixed-point affine terms a0 a1 a2 a3 a4 a5 of libImaging's affine_fixed, 15 (crop_i << 32) | crop_j
+ *   tables : device int32: per axis S rows of [first source index, tap count, taps[ksize]] (22-bit fixed point)
+ *   out    : float32 [n][3][crop][crop]
+ * mfvit.input_pipeline builds desc / tables from image sizes and the random draws exactly as Pillow's Python / C code does. */
+int mfvit_input_transform(const uint8_t* src, const int64_t* desc, const int32_t* tables, int n, int S, int crop, const float* mean3,
+                          const float* std3, float* out, mfvit_stream_t stream);
+
 /* Epoch metrics on the device (replaces the per-batch .cpu() copies MAIN_CA:886-899 and the scikit-learn calls
  * MAIN_CA:901-911).  scores f32 [n][C] (row stride ld), labels int64 [n].  ACCUMULATES into caller-zeroed uint64 arrays:
  * confusion[t][p] (+ optional preds[n] = first-maximum argmax, as torch.max MAIN_CA:870), and per class c the pair counts of the

@@ -11,6 +11,8 @@ int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st);
 bool gemm_nt_pers_supported(int dtype, int epi, const GemmP& p, bool force = false);   // gemm_pers.hip: persistent 256x128 kernel (bf16, short K)
 int gemm_nt_pers(int epi, const GemmP& p, hipStream_t st);
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st);
+int input_transform(const unsigned char* src, const long long* desc, const int* tables, int n, int S, int crop, const float* mean,
+                    const float* stdv, float* out, hipStream_t st);   // input.hip
 int eval_counts(const float* scores, long ld, const int64_t* labels, int n, int C, unsigned long long* conf, unsigned long long* u2,
                 unsigned long long* npos, int64_t* preds, hipStream_t st);   // metrics.hip
 int gemm_tn(int dtype, const GemmP& p, hipStream_t st);

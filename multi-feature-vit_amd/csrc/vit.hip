@@ -537,6 +537,11 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
 }
 
 // ------------------------------------------------------------------------------------------------ single ops
+int mfvit_input_transform(const uint8_t* src, const int64_t* desc, const int32_t* tables, int n, int S, int crop, const float* mean3,
+                          const float* std3, float* out, mfvit_stream_t stream) {
+    if (!src || !desc || !tables || !mean3 || !std3 || !out) return MFVIT_EINVAL;   // mean3 / std3 are HOST pointers (3 floats each)
+    return input_transform(src, (const long long*)desc, tables, n, S, crop, mean3, std3, out, (hipStream_t)stream);
+}
 int mfvit_eval_counts(const float* scores, int64_t ld, const int64_t* labels, int n, int C, uint64_t* confusion, int64_t* preds,
                       uint64_t* u2, uint64_t* npos, mfvit_stream_t stream) {
     if (!scores || !labels || (!confusion && !(u2 && npos))) return MFVIT_EINVAL;

@@ -77,6 +77,7 @@ SIGNATURES = {
     "mfvit_sgd_step": (I, [P, I, F, F, F, I, P]),
     "mfvit_prenorm_xattn_forward": (I, [POINTER(FusionCfg), P, P, P, P, P, P]),
     "mfvit_prenorm_xattn_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P]),
+    "mfvit_input_transform": (I, [P, P, P, I, I, I, P, P, P, P]),
     "mfvit_eval_counts": (I, [P, L, P, I, I, P, P, P, P, P]),
     "mfvit_prof_enable": (I, [I]),
     "mfvit_set_wgrad_stream": (I, [I]),
