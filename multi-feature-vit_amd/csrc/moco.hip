@@ -146,12 +146,16 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ 
         if (v > m) { s *= __expf(m - v); m = v; }
         s += __expf(v - m);
     }
+    // lanes / waves without an element (rows narrower than the block: the n x n logits of the symmetric loss) hold
+    // (-inf, 0): their weight is 0, not exp(-inf - -inf) = NaN
     const float wm = wave_max(m);
-    s = wave_sum(s * __expf(m - wm));
+    s = wave_sum(m == -INFINITY ? 0.f : s * __expf(m - wm));
     if (lane == 0) { sm[w] = wm; ss[w] = s; }
     __syncthreads();
     const float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
-    const float S = ss[0] * __expf(sm[0] - M) + ss[1] * __expf(sm[1] - M) + ss[2] * __expf(sm[2] - M) + ss[3] * __expf(sm[3] - M);
+    float S = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) S += sm[i] == -INFINITY ? 0.f : ss[i] * __expf(sm[i] - M);
     const float lse = M + __logf(S);
     const int t = (int)target[r];
     if (threadIdx.x == 0) {

@@ -15,6 +15,8 @@ What is exercised from the reference (paths relative to /root/reference/moco_pre
         cannot influence any stored number.
   moco/builder_vit_mocov3structure_mocov2loss.py   MoCo._build_mlp, _momentum_update_key_encoder,
         _dequeue_and_enqueue (1-rank gloo group), concat_all_gather
+  moco/builder_vit.py                  MoCo.contrastive_loss, MoCo_ViT.forward (symmetric MoCo-v3 loss; 1-rank gloo group,
+        torch.Tensor.cuda mapped to the identity while it runs because builder_vit.py:93 calls .cuda() on the labels)
   moco/optimizer.py                    LARS
 The ViT backbone is absent from the reference; where a backbone is needed the oracle's own restatement
 (oracle/ref_vit.py, parity unpinned) is wrapped in an object exposing ``features3D`` / ``__call__``.
@@ -251,6 +253,60 @@ def golden_moco():
     print("moco_pieces.npz ptr", d["enq_ptr_after"])
 
 
+def golden_moco_v3():
+    """moco/builder_vit.py (the symmetric MoCo-v3 loss): MoCo.contrastive_loss and MoCo.forward of the reference on a
+    toy encoder, 1-rank gloo group.  The reference moves its labels with `.cuda()` (builder_vit.py:93): Tensor.cuda is mapped to
+    the identity while the reference code runs (torch-level shim, nothing of the reference is altered)."""
+    import torch.distributed as dist
+    import moco.builder_vit as bv
+
+    class Toy(torch.nn.Module):
+        def __init__(self, num_classes=1000, **_):
+            super().__init__()
+            self.body = torch.nn.Linear(12, 16)
+            self.head = torch.nn.Linear(16, num_classes)
+
+        def forward(self, x):
+            return self.head(self.body(x))
+
+    d = {}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        torch.manual_seed(0)
+        m = bv.MoCo_ViT(Toy, types.SimpleNamespace(arch="vit_small"), dim=256, mlp_dim=64, T=0.2).double().train()
+        d["state_keys"] = np.array(sorted(m.state_dict().keys()))
+        # (a) the loss alone
+        q = rng_tensor(501, (8, 256), dtype=torch.float64).requires_grad_(True)
+        k = rng_tensor(502, (8, 256), dtype=torch.float64)
+        loss = m.contrastive_loss(q, k)
+        loss.backward()
+        d.update(seed_q=501, seed_k=502, T=0.2, n=8)
+        put(d, "ctr_loss", loss, full=True)
+        put(d, "ctr_dq", q.grad, full=True)
+        # (b) forward on seeded weights: loss, and the momentum encoder after its update
+        with torch.no_grad():
+            for i, (name, p) in enumerate(m.named_parameters()):
+                p.copy_(rng_tensor(520 + i, p.shape, scale=0.3, dtype=torch.float64))
+        d["param_names"] = np.array([n_ for n_, _ in m.named_parameters()])
+        d["seed_param0"] = 520
+        x1 = rng_tensor(511, (8, 12), dtype=torch.float64)
+        x2 = rng_tensor(512, (8, 12), dtype=torch.float64)
+        out = m(x1, x2, 0.99)
+        d.update(seed_x1=511, seed_x2=512, m=0.99)
+        put(d, "fwd_loss", out, full=True)
+        for name, p in m.momentum_encoder.named_parameters():
+            put(d, "mom." + name, p, full=True)
+    finally:
+        torch.Tensor.cuda = real_cuda
+        dist.destroy_process_group()
+    np.savez_compressed(os.path.join(OUT, "moco_v3.npz"), **d)
+    print("moco_v3.npz loss", float(d["fwd_loss"]))
+
+
 def golden_lars():
     from moco.optimizer import LARS
     shapes = [(6, 5), (5,), (4, 3), (3, 2)]
@@ -281,4 +337,5 @@ if __name__ == "__main__":
     golden_cross_attention()
     golden_fusion()
     golden_moco()
+    golden_moco_v3()
     golden_lars()

@@ -153,3 +153,22 @@ def test_checkpoint_layouts_and_pretrained_load(tmp_path):
     # the stripped dict keeps nothing of the momentum encoder / predictor / queue
     stripped = ck.strip_moco_prefix(dict(torch.load(path, map_location="cpu")["state_dict"]))
     assert all(not k.startswith(("module.", "head.")) for k in stripped) and "cls_token" in stripped
+
+
+def test_moco_v3_builder_surface():
+    """moco/builder_vit.py drop-in (symmetric loss): constructor, module names and state-dict layout against the reference-generated
+    key list (projector / predictor keys; the toy encoder body of the generator is not part of the comparison), no queue buffers."""
+    import vits
+    import moco.builder_vit as bv
+    g = np.load(os.path.join(GOLDEN, "moco_v3.npz"), allow_pickle=False)
+    m = bv.MoCo_ViT(partial(vits.vit_small, stop_grad_conv1=True, depth=1), types.SimpleNamespace(arch="vit_small"), 256, 64, 0.2)
+    for n in ("MoCo", "MoCo_ViT", "MoCo_ResNet", "concat_all_gather"):
+        assert hasattr(bv, n)
+    mine = {k for k in m.state_dict().keys() if k.startswith("predictor.") or ".head." in k}
+    ref = {k for k in g["state_keys"] if k.startswith("predictor.") or ".head." in k}
+    assert mine == ref
+    assert not any(k.startswith("queue") for k in m.state_dict().keys())
+    for pb, pm in zip(m.base_encoder.parameters(), m.momentum_encoder.parameters()):
+        assert torch.equal(pb, pm) and not pm.requires_grad
+    with pytest.raises(NotImplementedError):
+        bv.MoCo_ResNet(None, None)

@@ -174,6 +174,83 @@ def test_moco_forward_backward_vs_oracle(predict_keys):
     assert errs["logits"] < 1e-3 and errs["loss"] < 1e-3 and errs["queue"] < 1e-3
 
 
+def test_moco_v3_symmetric_loss_vs_oracle_and_golden():
+    """moco/builder_vit.py drop-in: the loss alone against the reference-generated golden, and the whole
+    forward + backward (two views through both encoders, EMA first) against the oracle on a depth-2 ViT."""
+    import vits
+    import moco.builder_vit as bv
+    g = np.load(os.path.join(GOLDEN, "moco_v3.npz"), allow_pickle=False)
+    depth, mlp_dim, dim, T, n, mval = 2, 512, 256, float(g["T"]), 8, 0.99
+    torch.manual_seed(0)
+    m = bv.MoCo_ViT(partial(vits.vit_small, stop_grad_conv1=True, depth=depth, precision="fp32"), types.SimpleNamespace(arch="vit_small"),
+                    dim, mlp_dim, T)
+    keys = set(m.state_dict().keys())
+    assert "queue" not in keys and "queue_ptr" not in keys
+    assert {k for k in g["state_keys"] if k.startswith("predictor.")} <= keys               # same predictor layout as the reference
+    with torch.no_grad():
+        m.base_encoder.load_state_dict(ref_vit.seeded_params(801, num_classes=0, depth=depth), strict=False)
+        m.momentum_encoder.load_state_dict(ref_vit.seeded_params(802, num_classes=0, depth=depth), strict=False)
+        for i, (name, p) in enumerate(list(m.base_encoder.head.named_parameters()) + list(m.predictor.named_parameters())
+                                      + list(m.momentum_encoder.head.named_parameters())):
+            if p.ndim == 1:
+                p.copy_(1.0 + 0.1 * rng_tensor(810 + i, p.shape) if "weight" in name else 0.05 * rng_tensor(810 + i, p.shape))
+            else:
+                p.copy_(rng_tensor(810 + i, p.shape) / p.shape[1] ** 0.5)
+    m = m.to(DEV).train()
+    # (a) the loss alone on the golden's seeded q, k
+    q = rng_tensor(int(g["seed_q"]), (8, 256)).to(DEV).requires_grad_(True)
+    k = rng_tensor(int(g["seed_k"]), (8, 256)).to(DEV)
+    loss = m.contrastive_loss(q, k)
+    loss.backward()
+    assert abs(float(loss) - float(g["ctr_loss"])) < 1e-5 * abs(float(g["ctr_loss"]))
+    assert scale_err(q.grad, torch.from_numpy(g["ctr_dq"])) < 1e-4
+    # (b) forward + backward against the oracle
+    sd = {k_: v.detach().cpu().double() for k_, v in m.state_dict().items()}
+    split = lambda pre: {k_[len(pre):]: v for k_, v in sd.items() if k_.startswith(pre)}
+    clean = lambda d_: {k_: v for k_, v in d_.items() if "running" not in k_ and "num_b" not in k_}
+    base_vit = {k_: v for k_, v in split("base_encoder.").items() if not k_.startswith("head.")}
+    mom_vit = {k_: v for k_, v in split("momentum_encoder.").items() if not k_.startswith("head.")}
+    base_proj = clean({k_: v for k_, v in split("base_encoder.").items() if k_.startswith("head.")})
+    mom_proj = clean({k_: v for k_, v in split("momentum_encoder.").items() if k_.startswith("head.")})
+    pred = clean({k_: v for k_, v in sd.items() if k_.startswith("predictor.")})
+    for d_ in (base_vit, base_proj, pred):
+        for k_, v in d_.items():
+            v.requires_grad_(k_ != "pos_embed" and not k_.startswith("patch_embed"))
+    x1, x2 = rng_tensor(820, (n, 3, 224, 224)), rng_tensor(821, (n, 3, 224, 224))
+    with torch.no_grad():
+        mv = ref_moco.ema_update(base_vit, mom_vit, mval)
+        mp = ref_moco.ema_update(base_proj, mom_proj, mval)
+    ref = ref_moco.moco_v3_forward(lambda x: ref_moco.encoder_embed(base_vit, base_proj, "head.", x),
+                                   lambda x: ref_moco.encoder_embed(mv, mp, "head.", x),
+                                   lambda z: ref_moco.mlp_forward(pred, "predictor.", 2, z), x1.double(), x2.double(), T)
+    ref.backward()
+    out = m(x1.to(DEV), x2.to(DEV), mval)
+    out.backward()
+    e_loss = abs(float(out) - float(ref)) / abs(float(ref))
+    gfloor = 1e-4 * max(float(v.grad.abs().max()) for d_ in (base_vit, base_proj, pred) for v in d_.values() if v.grad is not None)
+    worst = ("", 0.0)
+    for name, p in m.named_parameters():
+        if name.startswith("base_encoder.head."):
+            rg = base_proj[name[len("base_encoder."):]].grad
+        elif name.startswith("base_encoder."):
+            rg = base_vit[name[len("base_encoder."):]].grad
+        elif name.startswith("predictor."):
+            rg = pred[name].grad
+        else:
+            assert p.grad is None, name
+            continue
+        if rg is None:
+            assert p.grad is None, name
+            continue
+        e = scale_err(p.grad, rg, gfloor)
+        worst = max(worst, (name, e), key=lambda t: t[1])
+        assert e < 2e-3, (name, e)
+    for k_, v in mv.items():
+        assert scale_err(m.momentum_encoder.state_dict()[k_], v) < 1e-5, k_
+    log(f"moco v3 symmetric loss vs oracle: loss err {e_loss:.2e}, worst grad {worst}")
+    assert e_loss < 1e-3
+
+
 def test_lars_against_reference_golden_and_adam_sgd_vs_torch():
     from moco.optimizer import LARS
     from mfvit.optim import SGD, Adam, AdamW
