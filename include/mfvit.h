@@ -136,9 +136,10 @@ int mfvit_cross_entropy(const float* logits, const int64_t* target, float* loss_
  * the DataLoader workers, moco/loader.py:121-137): Resize((S,S), bilinear) -> horizontal flip -> rotation (nearest, fill 0) -> crop
  * -> ToTensor -> Normalize, fused, bit-exact against Pillow's fixed-point arithmetic.
  *   src    : decoded uint8 HWC (3 channels, channel order as decoded) images of n samples, packed back to back, on the device
- *   desc   : device int64 [n][16]: 0 byte offset of the image in src, 1 in_h, 2 in_w, 3 / 4 offsets (in int32 units) of the x / y
+ *   desc   : device int64 [n][20]: 0 byte offset in src of the top-left pixel of the source window, 1 in_h, 2 in_w, 3 / 4 offsets (in int32 units) of the x / y
  *            resample tables, 5 / 6 their ksize, 7 flip (0/1), 8 rotation mode (0 none, 1 affine, 2/3/4 = transpose 90/180/270),
- *            9..14 the 16.16 fixed-point affine terms a0 a1 a2 a3 a4 a5 of libImaging's affine_fixed, 15 (crop_i << 32) | crop_j
+ *            9..14 the 16.16 fixed-point affine terms a0 a1 a2 a3 a4 a5 of libImaging's affine_fixed, 15 (crop_i << 32) | crop_j,
+ *            16 source row pitch in bytes (3 * image width; a RandomResizedCrop box is a window of the image), 17..19 zero
  *   tables : device int32: per axis S rows of [first source index, tap count, taps[ksize]] (22-bit fixed point)
  *   out    : float32 [n][3][crop][crop]
  * mfvit.input_pipeline builds desc / tables from image sizes and the random draws exactly as Pillow's Python / C code does. */

@@ -20,8 +20,9 @@ __device__ __forceinline__ int clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// desc[s][16]: 0 src byte offset, 1 in_h, 2 in_w, 3 x-table offset (int32 units), 4 y-table offset, 5 ksize_x, 6 ksize_y,
-//              7 flip, 8 rot mode (0 none, 1 affine, 2 / 3 / 4 = transpose 90 / 180 / 270), 9..14 a0 a1 a2 a3 a4 a5 (16.16), 15 crop_i << 32 | crop_j
+// desc[s][20]: 0 src byte offset of the (cropped) source's top-left pixel, 1 in_h, 2 in_w, 3 x-table offset (int32 units), 4 y-table offset, 5 ksize_x, 6 ksize_y,
+//              7 flip, 8 rot mode (0 none, 1 affine, 2 / 3 / 4 = transpose 90 / 180 / 270), 9..14 a0 a1 a2 a3 a4 a5 (16.16), 15 crop_i << 32 | crop_j,
+//              16 source row pitch in bytes (a RandomResizedCrop box is a window of a wider image), 17..19 unused
 // table row xx of an axis: [xmin, count, k[0..ksize)]
 __global__ __launch_bounds__(256) void input_transform_kernel(const unsigned char* __restrict__ src, const long long* __restrict__ desc,
                                                               const int* __restrict__ tables, int S, int crop, float m0, float m1, float m2,
@@ -29,7 +30,8 @@ __global__ __launch_bounds__(256) void input_transform_kernel(const unsigned cha
     const int smp = blockIdx.y;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= crop * crop) return;
-    const long long* d = desc + (long)smp * 16;
+    const long long* d = desc + (long)smp * 20;
+    const long pitch = d[16];
     const int in_h = (int)d[1], in_w = (int)d[2];
     const unsigned char* img = src + d[0];
     const int x = pix % crop, y = pix / crop;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void input_transform_kernel(const unsigned cha
         const int y0 = vres ? ty[0] : yr, ny = vres ? ty[1] : 1;
         int a0 = 1 << (PREC - 1), a1 = a0, a2 = a0;
         for (int r = 0; r < ny; ++r) {
-            const unsigned char* row = img + ((long)(y0 + r) * in_w + x0) * 3;
+            const unsigned char* row = img + (long)(y0 + r) * pitch + (long)x0 * 3;
             int h0, h1, h2;
             if (hres) {
                 int b0 = 1 << (PREC - 1), b1 = b0, b2 = b0;

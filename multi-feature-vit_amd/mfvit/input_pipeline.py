@@ -81,7 +81,17 @@ class GpuTransform:
     args.img_size -> img_size, args.crop -> crop (0 = no crop), args.rotate -> rotate (degrees; RandomRotation draws from
     [-rotate, rotate])."""
 
-    def __init__(self, img_type="CheXpert-v1.0-small", img_size=256, crop=224, rotate=10, training=True, device="cuda:0"):
+    def __init__(self, img_type="CheXpert-v1.0-small", img_size=256, crop=224, rotate=10, training=True, device="cuda:0",
+                 mocov3=False, crop_min=0.08):
+        """mocov3=True mirrors `get_transform_type_mocov3` (image_transform.py:86-124, MoCo pretraining): training =
+        RandomResizedCrop(img_size, scale=(crop_min, 1)) -> flip -> rotation (no further crop); evaluation = Resize((256, 256)) ->
+        CenterCrop(crop)."""
+        self.mocov3, self.crop_min = bool(mocov3), float(crop_min)
+        if mocov3:
+            if training:
+                crop = 0
+            else:
+                img_size = 256
         if img_type not in NORMALIZE:
             raise _lib.MfvitError(f"unknown img_type {img_type!r} (image_transform.py:72-81 knows {sorted(NORMALIZE)})")
         self.mean, self.std = NORMALIZE[img_type]
@@ -90,12 +100,44 @@ class GpuTransform:
             raise _lib.MfvitError("crop larger than the resized image")
         self.device = torch.device(device)
 
-    def sample_params(self, n, generator=None):
-        """The random draws of one batch, in torchvision's order per image: flip (torch.rand(1) < 0.5), angle
-        (uniform in [-rotate, rotate]), crop offsets (randint); evaluation: no flip, no rotation, CenterCrop offsets."""
+    @staticmethod
+    def resized_crop_box(height, width, scale, generator=None, ratio=(3.0 / 4.0, 4.0 / 3.0)):
+        """torchvision RandomResizedCrop.get_params: (i, j, h, w) of the source window (10 tries, then the central fallback)."""
+        area = height * width
+        log_ratio = torch.log(torch.tensor(ratio))
+        for _ in range(10):
+            target_area = area * torch.empty(1).uniform_(scale[0], scale[1], generator=generator).item()
+            aspect = torch.exp(torch.empty(1).uniform_(float(log_ratio[0]), float(log_ratio[1]), generator=generator)).item()
+            w = int(round(math.sqrt(target_area * aspect)))
+            h = int(round(math.sqrt(target_area / aspect)))
+            if 0 < w <= width and 0 < h <= height:
+                i = int(torch.randint(0, height - h + 1, (1,), generator=generator))
+                j = int(torch.randint(0, width - w + 1, (1,), generator=generator))
+                return i, j, h, w
+        in_ratio = float(width) / float(height)
+        if in_ratio < min(ratio):
+            w = width
+            h = int(round(w / min(ratio)))
+        elif in_ratio > max(ratio):
+            h = height
+            w = int(round(h * max(ratio)))
+        else:
+            w, h = width, height
+        return (height - h) // 2, (width - w) // 2, h, w
+
+    def sample_params(self, n, generator=None, sizes=None):
+        """The random draws of one batch, in torchvision's order per image: [mocov3: the RandomResizedCrop box, needs `sizes` =
+        [(h, w)] of the images], flip (torch.rand(1) < 0.5), angle (uniform in [-rotate, rotate]), crop offsets (randint);
+        evaluation: no flip, no rotation, CenterCrop offsets.  Tuples (flip, angle, crop_i, crop_j[, box])."""
         S, C = self.size, self.crop
         out = []
-        for _ in range(n):
+        for s in range(n):
+            if self.training and self.mocov3:
+                box = self.resized_crop_box(sizes[s][0], sizes[s][1], (self.crop_min, 1.0), generator)
+                flip = bool(torch.rand(1, generator=generator) < 0.5)
+                angle = float(torch.empty(1).uniform_(-self.rotate, self.rotate, generator=generator))
+                out.append((flip, angle, 0, 0, box))
+                continue
             if self.training:
                 flip = bool(torch.rand(1, generator=generator) < 0.5)
                 angle = float(torch.empty(1).uniform_(-self.rotate, self.rotate, generator=generator))
@@ -113,8 +155,6 @@ class GpuTransform:
         if not torch.cuda.is_available():
             raise _lib.MfvitError("GpuTransform needs the GPU (no CPU fallback)")
         n = len(images)
-        if params is None:
-            params = self.sample_params(n, generator)
         S, C = self.size, self.crop
         arrs = []
         for im in images:
@@ -122,10 +162,16 @@ class GpuTransform:
             if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
                 raise _lib.MfvitError("images must be uint8 HWC with 3 channels (Image.fromarray(cv2.imread(..)), loader.py:121-125)")
             arrs.append(np.ascontiguousarray(a))
-        desc = np.zeros((n, 16), dtype=np.int64)
+        if params is None:
+            params = self.sample_params(n, generator, [a.shape[:2] for a in arrs])
+        desc = np.zeros((n, 20), dtype=np.int64)
         tabs, tab_off, tab_pos, off = [], {}, 0, 0
-        for s, (a, (flip, angle, ci, cj)) in enumerate(zip(arrs, params)):
-            h, w = a.shape[:2]
+        for s, (a, prm) in enumerate(zip(arrs, params)):
+            flip, angle, ci, cj = prm[:4]
+            H, W = a.shape[:2]
+            bi, bj, h, w = prm[4] if len(prm) > 4 else (0, 0, H, W)      # source window (RandomResizedCrop box) or the whole image
+            if not (0 <= bi and 0 <= bj and h > 0 and w > 0 and bi + h <= H and bj + w <= W):
+                raise _lib.MfvitError("source window outside the image")
             for axis, size in ((0, w), (1, h)):
                 if size not in tab_off:
                     ks, t = axis_table(size, S)
@@ -135,7 +181,8 @@ class GpuTransform:
             mode, terms = rotation_terms(angle, S)
             if not (0 <= ci <= S - C and 0 <= cj <= S - C):
                 raise _lib.MfvitError("crop offset out of range")
-            desc[s] = [off, h, w, tab_off[w][0], tab_off[h][0], tab_off[w][1], tab_off[h][1], int(flip), mode, *terms, (ci << 32) | cj]
+            desc[s] = [off + (bi * W + bj) * 3, h, w, tab_off[w][0], tab_off[h][0], tab_off[w][1], tab_off[h][1], int(flip), mode, *terms,
+                       (ci << 32) | cj, W * 3, 0, 0, 0]
             off += a.size
         src = torch.from_numpy(np.concatenate([a.reshape(-1) for a in arrs])).to(self.device, non_blocking=True)
         dsc = torch.from_numpy(desc).to(self.device, non_blocking=True)

@@ -152,3 +152,14 @@ def transform(img, size, flip, angle, crop_ij, crop_size, mean, std):
     if crop_size:
         x = crop(x, crop_ij[0], crop_ij[1], crop_size, crop_size)
     return to_tensor_normalize(x, mean, std)
+
+
+def transform_mocov3(img, box, size, flip, angle, mean, std):
+    """Training chain of image_transform.py:86-95 (`get_transform_type_mocov3`): RandomResizedCrop = crop the drawn box (i, j, h, w),
+    resize it to (size, size) (torchvision resized_crop = crop then resize), flip, rotate; then ToTensor + Normalize."""
+    i, j, h, w = box
+    x = resize_bilinear_u8(crop(img, i, j, h, w), size, size)
+    if flip:
+        x = hflip(x)
+    x = rotate_nearest(x, angle)
+    return to_tensor_normalize(x, mean, std)

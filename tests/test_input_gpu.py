@@ -54,3 +54,30 @@ def test_eval_chain_and_sampled_params():
     got = big(imgs[:1], [(True, -4.25, 0, 0)]).cpu().numpy()
     m, s = NORMALIZE["CheXpert-v1.0-small"]
     assert np.array_equal(got[0], ref_input.transform(imgs[0], 384, True, -4.25, (0, 0), 0, m, s))
+
+
+def test_mocov3_chain_random_resized_crop():
+    """get_transform_type_mocov3 (image_transform.py:86-124): RandomResizedCrop box -> resize -> flip -> rotate, and its eval chain."""
+    from mfvit.input_pipeline import NORMALIZE, GpuTransform
+    imgs = _images(13, [(320, 390), (390, 320), (512, 512), (90, 400)])
+    tf = GpuTransform("data", img_size=224, rotate=10, training=True, mocov3=True, crop_min=0.08)
+    g = torch.Generator().manual_seed(9)
+    ps = tf.sample_params(4, g, [im.shape[:2] for im in imgs])
+    for (f, a, ci, cj, (bi, bj, h, w)), im in zip(ps, imgs):
+        assert ci == cj == 0 and 0 <= bi and 0 <= bj and bi + h <= im.shape[0] and bj + w <= im.shape[1]
+        assert 0.08 * im.shape[0] * im.shape[1] * 0.9 <= h * w <= im.shape[0] * im.shape[1]
+    got = tf(imgs, generator=torch.Generator().manual_seed(9)).cpu().numpy()
+    mean, std = NORMALIZE["data"]
+    assert got.shape == (4, 3, 224, 224)
+    for k, (im, (f, a, _, _, box)) in enumerate(zip(imgs, ps)):
+        assert np.array_equal(got[k], ref_input.transform_mocov3(im, box, 224, f, a, mean, std)), k
+    # explicit windows incl. one that touches the image border and a 1:1 window (no resample on one axis)
+    params = [(True, 5.5, 0, 0, (0, 0, 320, 390)), (False, -3.0, 0, 0, (166, 96, 224, 224)), (True, 0.0, 0, 0, (500, 500, 12, 12)),
+              (False, 9.0, 0, 0, (0, 100, 90, 300))]
+    got = tf(imgs, params).cpu().numpy()
+    for k, (im, (f, a, _, _, box)) in enumerate(zip(imgs, params)):
+        assert np.array_equal(got[k], ref_input.transform_mocov3(im, box, 224, f, a, mean, std)), k
+    ev = GpuTransform("data", img_size=224, crop=224, training=False, mocov3=True)      # Resize((256, 256)) + CenterCrop(224)
+    got = ev(imgs).cpu().numpy()
+    for k, im in enumerate(imgs):
+        assert np.array_equal(got[k], ref_input.transform(im, 256, False, 0.0, (16, 16), 224, mean, std))

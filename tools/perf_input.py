@@ -17,11 +17,11 @@ print(f"end-to-end call incl. host tables + H2D of {B*H*W*3/1e6:.1f} MB: {1e3*(t
 t0 = time.perf_counter(); out = tf(imgs, params); torch.cuda.synchronize(); t1 = time.perf_counter()
 print(f"end-to-end call, tables cached: {1e3*(t1-t0):.2f} ms = {B/(t1-t0):.0f} img/s")
 # kernel alone on resident data
-desc = np.zeros((B, 16), dtype=np.int64)
+desc = np.zeros((B, 20), dtype=np.int64)
 ksx, tx = ip.axis_table(W, S); ksy, ty = ip.axis_table(H, S)
 for s, (f, a, i, j) in enumerate(params):
     mode, terms = ip.rotation_terms(a, S)
-    desc[s] = [s * H * W * 3, H, W, 0, tx.size, ksx, ksy, int(f), mode, *terms, (i << 32) | j]
+    desc[s] = [s * H * W * 3, H, W, 0, tx.size, ksx, ksy, int(f), mode, *terms, (i << 32) | j, W * 3, 0, 0, 0]
 src = torch.from_numpy(np.concatenate([a.reshape(-1) for a in imgs])).to(dev)
 dsc = torch.from_numpy(desc).to(dev)
 tab = torch.from_numpy(np.concatenate([tx.reshape(-1), ty.reshape(-1)])).to(dev)
