@@ -631,8 +631,7 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
         attr_set = true;
     }
     // p.cpart (optional, >= splits * N * K floats): split partials go there as plain stores and are summed by a second kernel
-    static const bool use_part = [] { const char* e = getenv("MFVIT_TN_PART"); return !(e && e[0] == '0'); }();
-    if (!use_part || p.nb > 1 || p.splits < 2 || p.ldo0 % 4 || (long)tiles * p.splits > 384) p.cpart = nullptr;   // scratch holds 384 tiles
+    if (p.nb > 1 || p.splits < 2 || p.ldo0 % 4 || (long)tiles * p.splits > 384) p.cpart = nullptr;   // scratch holds 384 tiles
     ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
     const dim3 grid = xcd1d ? dim3(tiles * p.splits, 1, 1) : dim3(tiles, p.splits, p.nb > 1 ? p.nb : 1);
     if (p.orow_in)

@@ -395,7 +395,11 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
     float* gmid = (float*)(ws + W.gmid);
     float* colscr = (float*)(ws + W.colscratch);
     float* colpart = (float*)(ws + W.colpart);
-    float* tnpart = (float*)(ws + W.tnpart);
+    // split partials of the wgrad GEMMs through scratch instead of float atomics: opt-in (MFVIT_TN_PART=1).  Measured inside the
+    // four-stream step the extra reduce launch per wgrad costs more (-4 %) than the atomics it replaces (they are fire-and-forget and
+    // overlap the tail of the kernel); what it buys is a deterministic dW.
+    static const bool tn_part = [] { const char* e = getenv("MFVIT_TN_PART"); return e && e[0] == '1'; }();
+    float* tnpart = tn_part ? (float*)(ws + W.tnpart) : nullptr;
     // dY buffers by layer parity (the embed stage counts as layer -1 -> parity 1)
     auto pp = [&](size_t off, int l) { return (void*)(ws + off + (size_t)(l & 1) * W.pp_stride); };
     SideStream& ss = side_stream(st);
