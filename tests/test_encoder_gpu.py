@@ -90,6 +90,41 @@ def test_backward_all_parameters(precision, tol, stop_grad_conv1):
     log(f"backward[{precision},stop_grad_conv1={stop_grad_conv1}] worst {worst[0]} err={worst[1]:.3e}")
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_full_size_batch_is_sample_independent(precision):
+    """BASELINE configs[2] size (B = 128 at 224^2, M = 25,216 token rows - too big for the CPU oracle): a ViT has no cross-sample
+    op, so every sample of the full batch must come out exactly as it does in the small batches the oracle tests cover (the GEMM
+    tiles, attention workgroups and row kernels may not leak between rows, pad rows or tile tails).  Forward: bit-exact.  Backward:
+    the input-independent reduction order of the split-M weight gradients changes with M, so the full-batch gradient is compared
+    with the SUM of the sub-batch gradients at rounding level."""
+    m, _ = build(precision, 601, depth=2 if precision == "fp32" else 12)
+    B = 128
+    x = rng_tensor(602, (B, 3, 224, 224)).to("cuda:0")
+    with torch.no_grad():
+        full = m.features3D(x)
+        for lo, n in ((0, 4), (60, 3), (125, 3)):                   # first, middle and the tail rows of the last M-tile
+            part = m.features3D(x[lo:lo + n].contiguous())
+            assert torch.equal(full[lo:lo + n], part), (precision, lo)
+    assert torch.isfinite(full).all()
+    # gradient linearity over the batch: grad(sum over 128) == grad(first 64) + grad(last 64)
+    w = rng_tensor(603, (B, 197, 384)).to("cuda:0")
+
+    def grads(lo, hi):
+        for p_ in m.parameters():
+            p_.grad = None
+        (m.features3D(x[lo:hi].contiguous()) * w[lo:hi]).sum().backward()
+        return {k: p_.grad.detach().clone() for k, p_ in m.named_parameters() if p_.grad is not None}
+
+    g_all, g_a, g_b = grads(0, B), grads(0, 64), grads(64, B)
+    tol = 2e-2 if precision == "bf16" else 1e-4                      # bf16: dY is rounded to bf16 per call; sums differ by rounding
+    worst = 0.0
+    for k in g_all:
+        e = scale_err(g_all[k], g_a[k] + g_b[k])
+        worst = max(worst, e)
+        assert e < tol, (k, e)
+    log(f"full-size batch independence [{precision}]: forward bit-exact, gradient additivity worst {worst:.2e}")
+
+
 def test_state_dict_roundtrip_and_arena_survives_moves():
     m, p = build("fp32", 521, depth=2)
     sd = m.state_dict()
