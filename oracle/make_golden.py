@@ -292,6 +292,7 @@ def golden_moco_v3():
             for i, (name, p) in enumerate(m.named_parameters()):
                 p.copy_(rng_tensor(520 + i, p.shape, scale=0.3, dtype=torch.float64))
         d["param_names"] = np.array([n_ for n_, _ in m.named_parameters()])
+        d["param_shapes"] = np.array([",".join(map(str, p.shape)) for _, p in m.named_parameters()])
         d["seed_param0"] = 520
         x1 = rng_tensor(511, (8, 12), dtype=torch.float64)
         x2 = rng_tensor(512, (8, 12), dtype=torch.float64)
