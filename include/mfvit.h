@@ -92,6 +92,11 @@ int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const 
  * for the encoder with MFVIT_PERS=1. */
 int mfvit_linear_fwd_persistent(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                                 int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream);
+/* Experimental third implementation (bf16; N % 128 == 0, N <= 1536, K % 64 == 0, K >= 128, M >= 1024): warp-specialised
+ * persistent kernel - four producer waves own all LDS-DMA, four consumer waves the MFMAs (csrc/gemm_ws.hip).  Same results;
+ * opt-in for the encoder with MFVIT_WS=1. */
+int mfvit_linear_fwd_ws(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
+                        void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream);
 /* dW[N][K] (f32, accumulated) += dy[M][N]^T x[M][K]   (nn.Linear weight gradient).  N % 128 == 0, K % 128 == 0. */
 int mfvit_linear_wgrad(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N, int K,
                        mfvit_stream_t stream);

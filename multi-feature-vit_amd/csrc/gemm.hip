@@ -675,6 +675,7 @@ int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float
 }
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
+    if (gemm_nt_ws_supported(dtype, epi, p)) return gemm_nt_ws(epi, p, st);
     if (gemm_nt_pers_supported(dtype, epi, p)) return gemm_nt_pers(epi, p, st);
 #define MFVIT_TILE_CASE(E)                                              \
     case E:                                                             \

@@ -23,6 +23,11 @@ namespace mfvit {
 
 namespace {
 
+// staging accesses of the epilogue write packed bf16x4 and read 16-byte chunks of the same LDS bytes: both through may_alias types
+// (type-based alias analysis would otherwise let the compiler reorder the differently typed stores and loads)
+typedef uint4 __attribute__((may_alias)) stg_u4;
+typedef bf16x4 __attribute__((may_alias)) stg_b4;
+
 constexpr int PBM = 256, PBN = 128, PNS = 3;
 constexpr int PTM = 4, PTN = 2;
 constexpr int PMAXN = 1536;                              // bias vector kept in LDS
@@ -142,6 +147,13 @@ __global__ __launch_bounds__(256, BKB == 64 ? 2 : 1) void gemm_nt_pers_kernel(Ge
     __builtin_amdgcn_sched_barrier(0);
     load_frags(0, 0, fa[0], fb[0]);
 
+#ifdef MFVIT_PERS_TRACE
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_readcyclecounter();
+#define TICK(i) do { const long long t__ = __builtin_readcyclecounter(); tacc[i] += t__ - tlast; tlast = t__; } while (0)
+#else
+#define TICK(i) do { } while (0)
+#endif
     constexpr int NST = (EPI == EPI_BIAS_GELU ? 2 : 1) * PTM * 4;   // global stores per lane and epilogue
     int slot = 0, s = 0, since = 2;                                  // since = steps since the last epilogue
     int tile = cslot;
@@ -175,13 +187,17 @@ __global__ __launch_bounds__(256, BKB == 64 ? 2 : 1) void gemm_nt_pers_kernel(Ge
         // that epilogue's NST stores (issued after stage s+1, before stage s+2).  vmcnt retires in order.
         auto sync = [&]() {
             const bool young = s + 2 < S;
+            TICK(0);
             if (young && since == 0) wait_vm_le<C::LPS + NST>();
             else if (young) wait_vm_le<C::LPS>();
             else if (since == 0) wait_vm_le<NST>();
             else wait_vm_le<0>();
+            TICK(1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            TICK(2);
             if constexpr (!(dbg & 8)) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            TICK(3);
         };
         for (int kt = 0; kt < nk - 1; ++kt) {
             front();
@@ -190,8 +206,10 @@ __global__ __launch_bounds__(256, BKB == 64 ? 2 : 1) void gemm_nt_pers_kernel(Ge
             if (s + 3 < S && !(dbg & 4)) issue(slot);        // refill the slot every wave has finished reading, three steps ahead
             load_frags(nslot, 0, fa[0], fb[0]);              // first fragments of the next step, hidden behind the last MFMAs
             __builtin_amdgcn_sched_barrier(0);
+            TICK(4);
             mfmas(fa[(C::KS - 1) & 1], fb[(C::KS - 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+            TICK(5);
             slot = nslot;
             ++since;
             ++s;
@@ -199,8 +217,10 @@ __global__ __launch_bounds__(256, BKB == 64 ? 2 : 1) void gemm_nt_pers_kernel(Ge
         // ---- last step of the tile: this wave's own pieces of the free slot first serve as the epilogue's staging buffer
         front();
         sync();
+        TICK(4);
         mfmas(fa[(C::KS - 1) & 1], fb[(C::KS - 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
+        TICK(5);
         since = 0;
         {
             // acc[i][j][r] = out[m][n], m = m0 + wm 128 + 32 i + (lane & 31), n = n0 + wn 64 + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3).
@@ -219,10 +239,14 @@ __global__ __launch_bounds__(256, BKB == 64 ? 2 : 1) void gemm_nt_pers_kernel(Ge
                 const int wsw = (mrow >> 1) & 7;
                 const int nb = n0 + wn * 64 + 4 * h;
                 auto flush = [&](int i, void* out, long ldo) {   // staged 32 x 64 tile -> global, 4 x 16 B per lane
+                    // lanes exchange data through LDS inside ONE wave (hardware executes a wave's LDS instructions in order, no barrier
+                    // needed) - but the compiler reasons per thread: without this fence it forwards a lane's earlier load of the same
+                    // address past the OTHER lanes' stores (observed: the reads sunk under the writers' exec mask)
+                    asm volatile("" ::: "memory");
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
                         const int q = q4 * 64 + lane, row = q >> 3, ch = q & 7;
-                        const uint4 v = *(const uint4*)(stg + (row >> 3) * 4096 + (row & 7) * 128 + 16 * (ch ^ ((row >> 1) & 7)));
+                        const uint4 v = *(const stg_u4*)(stg + (row >> 3) * 4096 + (row & 7) * 128 + 16 * (ch ^ ((row >> 1) & 7)));
                         int m = m0 + wm * 128 + 32 * i + row;
                         m = m < p.M ? m : p.M - 1;   // rows past M replicate row M-1 exactly (clamped A loads): identical duplicate
                         *(uint4*)((bf16*)out + (long)m * ldo + n0 + wn * 64 + 8 * ch) = v;   // stores, data-independent store count
@@ -258,14 +282,14 @@ __global__ __launch_bounds__(256, BKB == 64 ? 2 : 1) void gemm_nt_pers_kernel(Ge
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) w0[e] = (bf16)v[e];
                             }
-                            *(bf16x4*)(wrow + 16 * ((4 * j + g) ^ wsw)) = w0;
+                            *(stg_b4*)(wrow + 16 * ((4 * j + g) ^ wsw)) = w0;
                         }
                     flush(i, p.out0, p.ldo0);
                     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
                         for (int j = 0; j < PTN; ++j)
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) *(bf16x4*)(wrow + 16 * ((4 * j + g) ^ wsw)) = second[j][g];
+                            for (int g = 0; g < 4; ++g) *(stg_b4*)(wrow + 16 * ((4 * j + g) ^ wsw)) = second[j][g];
                         flush(i, p.out1, p.ldo1);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // keep the four row groups apart: interleaved, their temporaries spill
@@ -275,11 +299,19 @@ __global__ __launch_bounds__(256, BKB == 64 ? 2 : 1) void gemm_nt_pers_kernel(Ge
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's staging reads are done: its pieces may be refilled
         __builtin_amdgcn_sched_barrier(0);
         const int nslot = slot == PNS - 1 ? 0 : slot + 1;
+        TICK(6);
         if (s + 3 < S && !(dbg & 4)) issue(slot);
         if (s + 1 < S) load_frags(nslot, 0, fa[0], fb[0]);
         slot = nslot;
         ++s;
+        TICK(7);
     }
+#ifdef MFVIT_PERS_TRACE
+    // per-workgroup phase totals (wave 0, lane 0) -> p.res[block][8] (cycles): 0 front MFMAs, 1 vmcnt wait, 2 lgkm wait, 3 barrier,
+    // 4 issue + fragment prefetch, 5 last MFMAs, 6 epilogue, 7 refill after epilogue
+    if (threadIdx.x == 0 && p.res)
+        for (int i = 0; i < 8; ++i) ((float*)p.res)[blockIdx.x * 8 + i] = (float)tacc[i];
+#endif
 }
 
 template <int EPI, int BKB> int launch_pers_v(const GemmP& p, hipStream_t st, int wgs_per_cu) {
@@ -297,6 +329,9 @@ template <int EPI, int BKB> int launch_pers_v(const GemmP& p, hipStream_t st, in
     GemmP q = p;
     static const int stagger = [] { const char* e = getenv("MFVIT_PERS_STAGGER"); return e ? atoi(e) : 0; }();
     q.y_f32 = wgs_per_cu > 1 ? stagger : 0;   // field reused as the stagger length (x 1024 cycles)
+#ifdef MFVIT_PERS_TRACE
+    if (EPI != EPI_BIAS_GELU) q.res = (const float*)q.out1;   // trace build: the unused second output receives [grid][8] cycle totals
+#endif
     MFVIT_LAUNCH((gemm_nt_pers_kernel<EPI, BKB>), dim3(G), dim3(256), bytes, st, q, ntm, ntn);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;

@@ -47,6 +47,7 @@ SIGNATURES = {
     "mfvit_vit_backward": (I, [POINTER(VitCfg), P, P, P, P, P, I, I, P]),
     "mfvit_linear_fwd": (I, [I, I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
     "mfvit_linear_fwd_persistent": (I, [I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
+    "mfvit_linear_fwd_ws": (I, [I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
     "mfvit_linear_wgrad": (I, [I, P, L, P, L, P, L, I, I, I, P]),
     "mfvit_linear_wgrad_ws": (I, [I, P, L, P, L, P, L, I, I, I, P, P]),
     "mfvit_linear_res_ln_fwd": (I, [I, P, L, P, L, P, P, L, P, P, I, P, P, F, P, P, I, I, P]),

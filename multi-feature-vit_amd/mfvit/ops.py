@@ -31,6 +31,10 @@ def linear_fwd(x, w, bias=None, gelu=False, persistent=False):
     y = torch.empty(M, N, device=x.device, dtype=x.dtype)
     y2 = torch.empty_like(y) if gelu else None
     epi = EPI_BIAS_GELU if gelu else (EPI_BIAS if bias is not None else EPI_NONE)
+    if persistent == "ws":
+        check(lib().mfvit_linear_fwd_ws(epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N, ptr(y2), N, M, N, K,
+                                        stream()), "mfvit_linear_fwd_ws")
+        return (y, y2) if gelu else y
     if persistent:
         check(lib().mfvit_linear_fwd_persistent(epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N, ptr(y2), N, M, N, K,
                                                 stream()), "mfvit_linear_fwd_persistent")

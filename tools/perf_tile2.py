@@ -20,3 +20,11 @@ y = torch.empty(M, 1152, device=dev, dtype=torch.bfloat16)
 timeit(lambda: ops.linear_fwd(x, w, b), "qkv", 2.0*M*1152*384)
 w2, b2 = r(1536, 384, sc=.05), r(1536, dt=torch.float32)
 timeit(lambda: ops.linear_fwd(x, w2, b2, gelu=True), "fc1+gelu", 2.0*M*1536*384)
+
+for mode in (True, "ws"):
+    timeit(lambda: ops.linear_fwd(x, w, b, persistent=mode), f"qkv persistent={mode}", 2.0*M*1152*384)
+    timeit(lambda: ops.linear_fwd(x, w2, b2, gelu=True, persistent=mode), f"fc1+gelu persistent={mode}", 2.0*M*1536*384)
+y0 = ops.linear_fwd(x, w, b); y1 = ops.linear_fwd(x, w, b, persistent="ws")
+print("ws == default:", torch.equal(y0, y1))
+a0, g0 = ops.linear_fwd(x, w2, b2, gelu=True); a1, g1 = ops.linear_fwd(x, w2, b2, gelu=True, persistent="ws")
+print("ws gelu == default:", torch.equal(a0, a1), torch.equal(g0, g1))
