@@ -706,6 +706,7 @@ int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
     return MFVIT_EINVAL;
 }
 int gemm_tn(int dtype, const GemmP& p, hipStream_t st) {
+    if (gemm_tn_glds_supported(dtype, p)) return gemm_tn_glds(p, st);   // gemm_tn2.hip: LDS-DMA ring (bf16, large M)
     return dtype == MFVIT_BF16 ? launch_tn<bf16>(p, st) : launch_tn<float>(p, st);
 }
 
