@@ -174,7 +174,19 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
     const int m0 = blockIdx.x * rpw;
     p.M = p.M < m0 + rpw ? p.M : m0 + rpw;   // everything below treats rows >= p.M as padding
     f32x16 acc[TM][TN];
-    Loop::run(p, m0, 0, lds, acc);  // ends with a barrier: the staging LDS is free from here on
+    if constexpr (sizeof(T) == 2 && BKB == 128) {
+        // 128-row variant: the stage splits evenly over the 8 waves, so the LDS-DMA ring (BK 32, 4 slots in the same 128 KB, counted
+        // vmcnt: two stages in flight) applies - OPT-IN (MFVIT_ROW_GLDS=1): fc2 + LN 71 vs 75 us on a repeated launch whose operands sit
+        // in the Infinity Cache, but 84 vs 76 us inside the training step where they come from HBM.  (Measured and dropped for the 64-row variants: a 2-slot
+        // BK 64 DMA loop and a 4-slot loop with an uneven 3/4-instruction split per wave are both 5-10 % slower than register staging.)
+        if (BM == 128 && p.splits == 78) {
+            if constexpr (BM == 128) NtLoopGlds<BM, BN, WM, WN, 4>::run(p, m0, 0, lds, acc);
+        } else {
+            Loop::run(p, m0, 0, lds, acc);
+        }
+    } else {
+        Loop::run(p, m0, 0, lds, acc);  // ends with a barrier: the staging LDS is free from here on
+    }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -582,6 +594,8 @@ static int balanced_rows(int M, int BM) {
 template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v(const GemmP& pin, hipStream_t st) {
     GemmP p = pin;
     p.rows_per_wg = balanced_rows(p.M, BM);
+    static const int row_glds = [] { const char* e = getenv("MFVIT_ROW_GLDS"); return e ? atoi(e) : 0; }();   // opt-in, see the kernel
+    p.splits = (row_glds && sizeof(T) == 2 && BKB == 128 && BM == 128) ? 78 : 0;      // field unused by the row kernels otherwise
     typedef NtLoop<T, BM, ROW_BN, BKB, WM, 4> Loop;
     if (p.N != ROW_BN || p.K % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
     constexpr int need = BM * ROW_RS * 4 + BM * 4;
