@@ -38,8 +38,8 @@ NCLS = 10
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="pairs per GPU (BASELINE configs[2])")
     ap.add_argument("--mode", choices=["T", "F"], default="T")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")

@@ -5,7 +5,7 @@ out = sys.argv[1]
 
 
 def klass(name):
-    if "gemm_tn_kernel" in name:
+    if "gemm_tn_kernel" in name or "gemm_tn_glds_kernel" in name:
         return "gemm_tn_wgrad"
     if "gemm_nt_row_kernel" in name:
         return "gemm_nt_row_res_ln" if "gemm_nt_row_kernelIDF16bLi0E" in name or "gemm_nt_row_kernelIfLi0E" in name else "gemm_nt_row_lnbwd"
