@@ -1,8 +1,8 @@
 """Data-parallel gradient exchange over RCCL (torch.distributed backend 'nccl' on ROCm) for arena-backed modules.
 
-One process per GPU.  The encoder backward runs stage by stage (mfvit_vit_backward stage_hi..stage_lo); after each
-stage the gradient slice of that stage (one ViT block = 1.77 M floats = 7.1 MB f32, contiguous in the flat gradient
-arena) is all-reduced asynchronously, so the exchange of block l overlaps the backward of blocks l-1..0.  xGMI is
+One process per GPU.  The encoder backward runs in groups of stages (mfvit_vit_backward stage_hi..stage_lo, by default 4 ViT
+blocks per group: 4 x 1.77 M floats = 28 MB f32, contiguous in the flat gradient arena); after each group its slice is
+all-reduced asynchronously, so the exchange of a group overlaps the backward of the groups below it.  xGMI is
 point-to-point (7 links x ~153 GB/s per GPU): per-block buckets keep every message large enough for the ring/direct
 algorithms while leaving 11 blocks of compute to hide each one behind.
 """
@@ -27,18 +27,27 @@ class GradSync:
         return h
 
     # ---- encoder: called from VisionTransformerMoCo._run_backward after every stage
-    def attach(self, vit):
+    def attach(self, vit, bucket_layers=None):
+        import os
+        if bucket_layers is None:
+            bucket_layers = int(os.environ.get("MFVIT_GRAD_BUCKET_LAYERS", "4"))
+        vit._grad_bucket_layers = bucket_layers
         if self.enabled:
             vit._grad_stage_hook = self._stage_hook
+        elif os.environ.get("MFVIT_FORCE_BUCKETS"):            # single-GPU measurement of what the grouped backward alone costs
+            vit._grad_stage_hook = lambda *_: None
         return vit
 
-    def _stage_hook(self, vit, stage, gflat):
-        if stage == vit.depth:          # final norm (2 x 384 floats): sent together with the embed stage
-            return
-        if stage >= 0:
-            a, n = vit.block_slice(stage)
-            self._push(self._all_reduce(gflat[a:a + n], True))
-        else:
+    def _stage_hook(self, vit, hi, lo, gflat):
+        """Called after backward stages hi .. lo (depth = final norm, depth-1 .. 0 = blocks, -1 = embedding) have been queued: the
+        blocks of the group are one contiguous slice of the flat gradient arena; everything outside the blocks (cls / pos / patch
+        embedding in front, final norm + head behind) goes with the group that contains the embedding stage."""
+        b_hi, b_lo = min(hi, vit.depth - 1), max(lo, 0)
+        if b_hi >= b_lo:
+            a, _ = vit.block_slice(b_lo)
+            e, n = vit.block_slice(b_hi)
+            self._push(self._all_reduce(gflat[a:e + n], True))
+        if lo <= -1:
             a0, _ = vit.block_slice(0)
             self._push(self._all_reduce(gflat[:a0], True))
             e, n = vit.block_slice(vit.depth - 1)

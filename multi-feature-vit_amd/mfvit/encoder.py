@@ -324,10 +324,19 @@ class VisionTransformerMoCo(nn.Module):
             check(lib().mfvit_vit_backward(cfg, ptr(self._arena), ptr(self._shadow), ptr(ws), ptr(dfeats), ptr(gflat), self.depth, -1,
                                            stream()), "mfvit_vit_backward")
         else:
-            for s in range(self.depth, -2, -1):
-                check(lib().mfvit_vit_backward(cfg, ptr(self._arena), ptr(self._shadow), ptr(ws), ptr(dfeats), ptr(gflat), s, s,
+            # stages depth (final norm), depth-1 .. 0 (blocks), -1 (embedding) run in groups of `_grad_bucket_layers` blocks: after
+            # each group its (contiguous) gradient slice can be exchanged while the next group computes.  Every library call joins
+            # its weight-gradient side stream at the end, so fewer, larger groups keep more of that overlap than one call per block.
+            gb = max(1, int(getattr(self, "_grad_bucket_layers", 4)))
+            hi = self.depth
+            while hi >= -1:
+                lo = max(hi - gb, -1) if hi == self.depth else max(hi - gb + 1, -1)
+                if lo == 0:
+                    lo = -1                                   # the embedding stage rides with the last block group
+                check(lib().mfvit_vit_backward(cfg, ptr(self._arena), ptr(self._shadow), ptr(ws), ptr(dfeats), ptr(gflat), hi, lo,
                                                stream()), "mfvit_vit_backward")
-                hook(self, s, gflat)
+                hook(self, hi, lo, gflat)
+                hi = lo - 1
         self._last_grad_arena = gflat
         grads = []
         for name, p in self.arena_named_parameters():

@@ -125,6 +125,32 @@ def test_full_size_batch_is_sample_independent(precision):
     log(f"full-size batch independence [{precision}]: forward bit-exact, gradient additivity worst {worst:.2e}")
 
 
+@pytest.mark.parametrize("bucket", [1, 4, 5])
+def test_grouped_backward_stages_match_single_call(bucket):
+    """The data-parallel path runs the encoder backward in groups of stages (one library call + one gradient bucket per group,
+    mfvit/ddp.py); every grouping must give the gradients of the single-call backward and cover every stage exactly once."""
+    m, _ = build("fp32", 611, depth=12)
+    x = rng_tensor(612, (2, 3, 224, 224)).to("cuda:0")
+    w = rng_tensor(613, (2, 197, 384)).to("cuda:0")
+
+    def grads():
+        for p_ in m.parameters():
+            p_.grad = None
+        (m.features3D(x) * w).sum().backward()
+        return {k: p_.grad.detach().clone() for k, p_ in m.named_parameters() if p_.grad is not None}
+
+    ref = grads()
+    seen = []
+    m._grad_bucket_layers = bucket
+    m._grad_stage_hook = lambda vit, hi, lo, gflat: seen.append((hi, lo))
+    got = grads()
+    del m._grad_stage_hook
+    stages = [s for hi, lo in seen for s in range(hi, lo - 1, -1)]
+    assert stages == list(range(12, -2, -1)), seen                  # final norm, blocks 11..0, embedding: each once, in order
+    for k in ref:
+        assert scale_err(got[k], ref[k]) < 1e-5, k
+
+
 def test_state_dict_roundtrip_and_arena_survives_moves():
     m, p = build("fp32", 521, depth=2)
     sd = m.state_dict()

@@ -83,10 +83,14 @@ def _worker(rank, world, port, q):
         vit = m.base_encoder
         sync.attach(vit)
         gflat = torch.full_like(vit.flat_parameters(), float(rank + 1))
-        for s in range(vit.depth, -2, -1):
-            vit._grad_stage_hook(vit, s, gflat)
+        for s in range(vit.depth, -2, -1):                    # one stage per group
+            vit._grad_stage_hook(vit, s, s, gflat)
         sync.finish()
         ok2 = bool(torch.allclose(gflat, torch.full_like(gflat, 1.5)))
+        gflat = torch.full_like(vit.flat_parameters(), float(rank + 1))
+        vit._grad_stage_hook(vit, vit.depth, -1, gflat)        # everything in one group
+        sync.finish()
+        ok2 = ok2 and bool(torch.allclose(gflat, torch.full_like(gflat, 1.5)))
         # (3) concat_all_gather order + enqueue of the gathered keys (BLD:91-105, 229-240)
         keys = torch.nn.functional.normalize(torch.full((4, 256), float(rank + 1)) + torch.arange(4).float()[:, None], dim=1)
         allk = bld.concat_all_gather(keys)
