@@ -1,4 +1,9 @@
-"""Per-op timings at the bench shapes (M = 128 x 197 token rows), bf16.  Development aid."""
+"""Per-op timings at the bench shapes (M = 128 x 197 token rows), bf16.  Development aid.
+
+CAUTION: every op is launched repeatedly on the SAME tensors, so its operands sit in the 256 MB Infinity Cache.  Variants that win
+here can lose inside the training step, where operands come from HBM (it happened: LDS-DMA rings for the row kernels, the
+persistent tile kernels).  Trust the per-class averages of bench.py's serialized pass (`roofline.serialized_pass.per_class`) or a
+rotation over more than 256 MB of operands (tools/perf_tn_cold.py) before keeping a change."""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
