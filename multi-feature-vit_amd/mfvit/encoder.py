@@ -318,7 +318,20 @@ class VisionTransformerMoCo(nn.Module):
         dfeats = dfeats.contiguous()
         if dfeats.dtype != torch.float32:
             dfeats = dfeats.float()
-        gflat = torch.zeros_like(self._arena)
+        # The flat gradient arena is reused from step to step (stable addresses: the optimizers' device tables stay valid) unless a
+        # parameter still holds a gradient - accumulation over several backward passes, or a second pass through this encoder
+        # inside one autograd run (MoCo-v3 feeds both views through the base encoder) - in which case a fresh one is allocated.
+        ga = getattr(self, "_grad_arena", None)
+        # (`_grad_arena_lent` covers the second case before autograd has accumulated the first pass's views into p.grad; it is
+        # cleared by the next forward.)
+        if (ga is not None and not getattr(self, "_grad_arena_lent", False) and ga.shape == self._arena.shape
+                and ga.device == self._arena.device and all(p.grad is None for p in self._arena_params)):
+            gflat = ga.zero_()
+        else:
+            gflat = torch.zeros_like(self._arena)
+            if not getattr(self, "_grad_arena_lent", False):
+                self._grad_arena = gflat
+        self._grad_arena_lent = True
         hook = on_stage_done or getattr(self, "_grad_stage_hook", None)
         if hook is None:
             check(lib().mfvit_vit_backward(cfg, ptr(self._arena), ptr(self._shadow), ptr(ws), ptr(dfeats), ptr(gflat), self.depth, -1,
@@ -358,6 +371,7 @@ class VisionTransformerMoCo(nn.Module):
             # all dropouts are 0, so the second result is head(first[:, 0]): computed once.  Single use: a repeated call of
             # the SAME method always recomputes.
             return c[3]
+        self._grad_arena_lent = False
         feats = _EncoderFn.apply(self, x, need, *self._arena_params)
         self._feat_cache = (x, key, caller, feats)
         return feats

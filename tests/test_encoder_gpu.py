@@ -151,6 +151,39 @@ def test_grouped_backward_stages_match_single_call(bucket):
         assert scale_err(got[k], ref[k]) < 1e-5, k
 
 
+def test_gradient_arena_reuse_is_safe():
+    """The flat gradient arena is reused from step to step (stable addresses for the optimizers' device tables).  It must NOT be
+    reused while a gradient still lives in it: accumulation over two backward passes without zero_grad, and two passes through the
+    same encoder inside ONE autograd run (what MoCo-v3 does) - both must equal the sum of the separate gradients."""
+    m, _ = build("fp32", 621, depth=2)
+    xa = rng_tensor(622, (2, 3, 224, 224)).to("cuda:0")
+    xb = rng_tensor(623, (2, 3, 224, 224)).to("cuda:0")
+    w = rng_tensor(624, (2, 197, 384)).to("cuda:0")
+
+    def zero():
+        for p_ in m.parameters():
+            p_.grad = None
+
+    def snap():
+        return {k: p_.grad.detach().clone() for k, p_ in m.named_parameters() if p_.grad is not None}
+
+    zero(); (m.features3D(xa) * w).sum().backward(); ga = snap()
+    ptr_a = m.blocks[0].mlp.fc1.weight.grad.data_ptr()
+    zero(); (m.features3D(xb) * w).sum().backward(); gb = snap()
+    assert m.blocks[0].mlp.fc1.weight.grad.data_ptr() == ptr_a            # reused: same addresses step after step
+    zero()
+    (m.features3D(xa) * w).sum().backward()
+    (m.features3D(xb) * w).sum().backward()                                # accumulates into the live gradients
+    acc = snap()
+    zero()
+    ((m.features3D(xa) * w).sum() + (m.features3D(xb) * w).sum()).backward()   # two passes in one autograd run
+    both = snap()
+    for k in ga:
+        want = ga[k] + gb[k]
+        assert scale_err(acc[k], want) < 1e-5, k
+        assert scale_err(both[k], want) < 1e-5, k
+
+
 def test_state_dict_roundtrip_and_arena_survives_moves():
     m, p = build("fp32", 521, depth=2)
     sd = m.state_dict()
