@@ -86,8 +86,17 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long rs = 3L * H * HD;
     const bf16* base = qkv + (long)b * Tn * rs + h * HD;
-    stage(base + (long)H * HD, rs, Tn, Tpad, Ks, RSB);
-    stage(base + 2L * H * HD, rs, Tn, Tpad, Vs, 64);
+    for (int q = threadIdx.x; q < Tpad * 4; q += blockDim.x) {   // K and V pieces of a row loaded together (one HBM round trip, not two)
+        const int t = q >> 2, cidx = q & 3;
+        uint4 vk = make_uint4(0, 0, 0, 0), vv = vk;
+        if (t < Tn) {
+            const bf16* rp = base + (long)t * rs + (long)H * HD + 8 * cidx;
+            vk = *(const uint4*)rp;
+            vv = *(const uint4*)(rp + (long)H * HD);
+        }
+        *(uint4*)(Ks + t * RSB + 16 * cidx) = vk;
+        *(uint4*)(Vs + t * 64 + 16 * cidx) = vv;
+    }
     __syncthreads();
     const float c = scale * 1.4426950408889634f;
     const int nt = Tpad >> 5;
@@ -177,27 +186,34 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restri
     bf16* dbase = dqkv + (long)b * Tn * rs + h * HD;
     const bf16* obase = out + (long)b * Tn * os + h * HD;
     const bf16* dobase = dout + (long)b * Tn * os + h * HD;
-    stage(base, rs, Tn, Tpad, Qs, PITCH);
-    stage(base + (long)H * HD, rs, Tn, Tpad, Ks, PITCH);
-    stage(base + 2L * H * HD, rs, Tn, Tpad, Vs, PITCH);
-    for (int q = threadIdx.x; q < Tpad * 4; q += blockDim.x) {  // dO image + D: four lanes per row, 16 B each
+    // one fused staging pass: the five loads of a row piece (Q, K, V, dO, O) are issued together - staged image by image, each image
+    // paid its own HBM round trip before the next one's loads went out (operands are cold inside the training step)
+    for (int q = threadIdx.x; q < Tpad * 4; q += blockDim.x) {  // four lanes per row, 16 B each
         const int t = q >> 2, cidx = q & 3;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        float D = 0.f;
+        uint4 vq = make_uint4(0, 0, 0, 0), vk = vq, vv = vq, vd = vq;
+        float D = 0.f, L = -1e30f;                                 // padded queries: p = exp2(-1e30 c) = 0
         if (t < Tn) {
-            v = *(const uint4*)(dobase + (long)t * os + 8 * cidx);
+            const bf16* rp = base + (long)t * rs + 8 * cidx;
+            vq = *(const uint4*)rp;
+            vk = *(const uint4*)(rp + (long)H * HD);
+            vv = *(const uint4*)(rp + 2L * H * HD);
+            vd = *(const uint4*)(dobase + (long)t * os + 8 * cidx);
             const bf16x8 o = *(const bf16x8*)(obase + (long)t * os + 8 * cidx);
+            if (cidx == 0) L = -lse[((long)b * H + h) * Tn + t] / scale;
             union { uint4 u; bf16x8 b8; } cv;
-            cv.u = v;
+            cv.u = vd;
 #pragma unroll
             for (int j = 0; j < 8; ++j) D = fmaf((float)cv.b8[j], (float)o[j], D);
         }
-        *(uint4*)(dOs + t * PITCH + 16 * cidx) = v;
+        *(uint4*)(Qs + t * PITCH + 16 * cidx) = vq;
+        *(uint4*)(Ks + t * PITCH + 16 * cidx) = vk;
+        *(uint4*)(Vs + t * PITCH + 16 * cidx) = vv;
+        *(uint4*)(dOs + t * PITCH + 16 * cidx) = vd;
         D += __shfl_xor(D, 1, 64);
         D += __shfl_xor(D, 2, 64);
         if (cidx == 0) {
             Ds[t] = -D;
-            Ls[t] = t < Tn ? -lse[((long)b * H + h) * Tn + t] / scale : -1e30f;  // padded queries: p = exp2(-1e30 c) = 0
+            Ls[t] = L;
         }
     }
     __syncthreads();
