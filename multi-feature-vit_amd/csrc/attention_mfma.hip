@@ -53,15 +53,6 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
 }
 __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 
-// copy rows [0, Tn) of one (b, which, h) slice (64 B each) into an LDS image with the given pitch; rows [Tn, Tpad) are zeroed
-__device__ __forceinline__ void stage(const bf16* base, long row_stride, int Tn, int Tpad, char* img, int pitch) {
-    for (int q = threadIdx.x; q < Tpad * 4; q += blockDim.x) {
-        const int t = q >> 2, c = q & 3;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (t < Tn) v = *(const uint4*)(base + (long)t * row_stride + 8 * c);
-        *(uint4*)(img + t * pitch + 16 * c) = v;
-    }
-}
 // store an accumulator tile X^T[d][col] (col on the lane) as rows of a [.., HD] bf16 tensor: 4 x 8-byte stores per lane
 __device__ __forceinline__ void store_tile_T(bf16* row_ptr, const f32x16& acc, float mul, int lane) {
 #pragma unroll
