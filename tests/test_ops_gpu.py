@@ -83,7 +83,8 @@ def test_linear_fwd_persistent(M, N, K, variant):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("M,N,K", [(777, 256, 384), (197 * 4, 1152, 384), (100, 384, 1536), (31, 128, 128), (197 * 64, 1152, 384)])
+@pytest.mark.parametrize("M,N,K", [(777, 256, 384), (197 * 4, 1152, 384), (100, 384, 1536), (31, 128, 128), (197 * 64, 1152, 384),
+                                   (197 * 33 + 5, 384, 1536), (4099, 128, 128), (197 * 128, 1536, 384)])   # >= 4096 rows: LDS-DMA kernel (bf16), ragged tails
 def test_linear_wgrad(dtype, M, N, K):
     from mfvit import ops
     dy, x = rnd((M, N), dtype, 4), rnd((M, K), dtype, 5)
