@@ -30,7 +30,12 @@ import torch.distributed as dist  # noqa: E402
 FUS_MOD = ("model.crossvit_2vits_2additionaloutputs_changenormlayer_location_removeextralclayer_"
            "changemodelinputlocation_std002_sum")
 GFLOP_PER_PAIR = {"T": 55.88, "F": 19.10}      # algorithmic work, each ViT counted once
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # MI355X_MICROARCH.md: dense MFMA peak per dtype
+# MI355X_MICROARCH.md: dense MFMA peak per dtype.  bf16x3 (split bf16) issues three bf16 MFMAs per algorithmic product, so the ceiling
+# for ALGORITHMIC flops in that mode is a third of the bf16 peak.
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "bf16x3": 2500.0 / 3.0, "fp32": 157.3}
+PEAK_NOTE = {"bf16": "dense bf16 MFMA", "fp16": "dense fp16 MFMA", "fp32": "dense f32 MFMA",
+             "bf16x3": "dense bf16 MFMA / 3 (split bf16: three MFMAs per algorithmic product)"}
+ARITH = {"bf16": "bf16", "fp16": "f16", "fp32": "f32", "bf16x3": "bf16x3 (split bf16 hi+lo operands, 3 MFMAs per product, f32 accumulate)"}
 PEAK_HBM_GBS = 8000.0
 NCLS = 10
 
@@ -42,7 +47,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="pairs per GPU (BASELINE configs[2])")
     ap.add_argument("--mode", choices=["T", "F"], default="T")
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16x3", "bf16", "fp16", "fp32"], default="bf16x3",
+                    help="bf16x3 (default): split-bf16 products, the mode that meets the 1e-3 logits gate on the bf16 matrix core "
+                         "(the reference's CA finetune is fp32); bf16: throughput mode; fp16: the reference's autocast arithmetic "
+                         "(MoCo pretraining, with GradScaler); fp32: exact f32 MFMA")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary lines (bf16 throughput mode, mode F) of the N=1 run")
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--workload", choices=["ca", "single", "moco"], default="ca",
                     help="ca = BASELINE configs[2] (the metric's configuration); single = configs[1]; moco = configs[3] per-GPU slice")
@@ -50,19 +59,21 @@ def parse():
     ap.add_argument("--serialize-streams", action="store_true",
                     help="run the whole benchmark on ONE stream (no second encoder stream, no wgrad side stream): the mode whose "
                          "rocprofv3 kernel durations the roofline's per-kernel numbers are checked against")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=10)
     return ap.parse_args()
 
 
-def build_models(args, dev):
+def build_models(args, dev, precision=None, mode=None):
     import importlib
     import vits_returnftrs as vits
     fus = importlib.import_module(FUS_MOD)
+    precision = precision or args.precision
+    mode = mode or args.mode
     torch.manual_seed(0)
     backs = []
     for _ in range(2):
-        m = vits.__dict__["vit_small"](precision=args.precision, img_size=args.img)      # MAIN_CA:289-290
-        if args.mode == "F":                                                             # MAIN_CA:298-305
+        m = vits.__dict__["vit_small"](precision=precision, img_size=args.img)           # MAIN_CA:289-290
+        if mode == "F":                                                                  # MAIN_CA:298-305
             for name, prm in m.named_parameters():
                 if name not in ("head.weight", "head.bias"):
                     prm.requires_grad = False
@@ -74,9 +85,35 @@ def build_models(args, dev):
     return model, backs
 
 
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _timed(fn, warmups, want, budget_s):
+    """`warmups` untimed calls, then up to `want` timed ones (at least 1; fewer only when the host is too slow for the time budget)."""
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(warmups):
+        out = fn()
+    warm = (time.perf_counter() - t0) / max(warmups, 1)
+    n = max(1, min(want, int(budget_s / max(warm, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = fn()
+    return (time.perf_counter() - t0) / n, n, out
+
+
 def cpu_baseline(args, model, backs, x, xe, target):
-    """The CPU oracle (oracle/ref_fusion.ca_step + backward) on this host's cores, bounded sample."""
-    from oracle import ref_fusion
+    """The CPU oracle on this host's cores, bounded samples: (1) the metric's own workload - the two-stream CA train step
+    (oracle/ref_fusion.ca_step + backward) on 4 pairs; (2) BASELINE configs[0] - single-stream vit_small forward + CE on 4 images
+    (MAIN_SS:711-714).  3 warm-up + up to --cpu-steps timed iterations each."""
+    from oracle import ref_fusion, ref_vit
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -100,21 +137,20 @@ def cpu_baseline(args, model, backs, x, xe, target):
                 v.grad = None
         return out.detach()
 
-    t0 = time.perf_counter()
-    out = step()  # warm-up (also the sample if the host is slow)
-    warm = time.perf_counter() - t0
-    print(f"[bench] cpu_baseline warm-up step: {warm:.2f} s on {ncpu} threads", file=sys.stderr, flush=True)
-    n = 0 if warm > 15.0 else max(1, min(args.cpu_steps, int(20.0 / max(warm, 1e-3))))
-    if n:
-        t0 = time.perf_counter()
-        for _ in range(n):
-            out = step()
-        dt = (time.perf_counter() - t0) / n
-    else:
-        dt = warm
-    return dict(value=nb / dt, unit="images/sec", cores=ncpu, kind="port",
-                sample=f"oracle (torch f32 CPU restatement) CA step mode {args.mode}: {nb} pairs x {max(n, 1)} step(s)"
-                       f"{' after 1 warm-up' if n else ' (the warm-up itself, host too slow for more)'}, {ncpu} threads"), out
+    def cfg1():
+        with torch.no_grad():
+            logits = ref_vit.head_linear(vits_p[0], ref_vit.features3d(vits_p[0], xc)[:, 0])
+            return torch.nn.functional.cross_entropy(logits, tc)
+
+    dt, n, out = _timed(step, 3, args.cpu_steps, 20.0)
+    dt1, n1, _ = _timed(cfg1, 3, args.cpu_steps, 8.0)
+    print(f"[bench] cpu_baseline: CA step {dt:.3f} s x {n}, cfg1 fwd+CE {dt1:.3f} s x {n1} on {ncpu} threads", file=sys.stderr, flush=True)
+    return dict(value=nb / dt, unit="images/sec", cores=ncpu, kind="port", cpu_model=cpu_model_name(),
+                sample=f"oracle (torch f32 CPU restatement) two-stream CA train step mode {args.mode}: {nb} pairs x {n} timed steps after 3 warm-up, "
+                       f"{ncpu} threads",
+                cfg1=dict(value=nb / dt1, unit="images/sec",
+                          sample=f"BASELINE configs[0]: single-stream vit_small forward + CE, {nb} x 3 x {args.img} x {args.img}, {n1} timed "
+                                 f"iterations after 3 warm-up, {ncpu} threads")), out
 
 
 def other_workloads(args, world, rank, dev, lib):
@@ -201,8 +237,109 @@ def other_workloads(args, world, rank, dev, lib):
         dist.destroy_process_group()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher (what MAIN_MOCO:207 does with mp.spawn(main_worker, nprocs=ngpus)): start N ranks
+    as a CHILD process group through torch.distributed.run, relay rank 0's JSON line and fail unless it reports n_gpus == N.  The
+    parent never touches the GPU (no HIP call before or after the child) and never exec()s."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"[bench] the {args.gpus}-rank child failed with exit code {proc.returncode}", file=sys.stderr)
+        sys.exit(proc.returncode or 1)
+    if line is None:
+        print("[bench] the ranks printed no result line", file=sys.stderr)
+        sys.exit(1)
+    if json.loads(line).get("n_gpus") != args.gpus:
+        print(f"[bench] asked for --gpus {args.gpus} but the ranks report n_gpus={json.loads(line).get('n_gpus')}", file=sys.stderr)
+        sys.exit(1)
+    print(line, flush=True)
+
+
+class CaRun:
+    """One two-stream CA workload instance: models, optimizer, synthetic batch, step()."""
+
+    def __init__(self, args, dev, rank, precision, mode):
+        from mfvit.ddp import GradSync
+        from mfvit.losses import cross_entropy
+        from mfvit.optim import Adam
+        self.args, self.precision, self.mode = args, precision, mode
+        self.model, self.backs = build_models(args, dev, precision, mode)
+        g = torch.Generator().manual_seed(1234 + rank)                                   # SURVEY.md 8(d) synthetic inputs
+        B = args.batch
+        self.x = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
+        self.xe = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
+        self.target = torch.randint(0, 3, (B,), generator=g).to(dev)
+        params = list(self.model.parameters())
+        for m in self.backs:
+            params += [p for p in m.parameters() if p.requires_grad]
+        self.opt = Adam(params, lr=1e-4, betas=(0.9, 0.999))                             # MAIN_CA:455-459 (multi-tensor HIP kernel)
+        self.sync = GradSync()
+        for m in self.backs:
+            self.sync.attach(m)
+        self.small = list(self.model.parameters()) + [p for m in self.backs for p in m.head.parameters()]
+        self._ce = cross_entropy
+
+    def step(self):
+        self.opt.zero_grad(set_to_none=True)
+        fused, x_c, x_e = self.model(self.backs[0], self.backs[1], self.x, self.xe)      # MAIN_CA:862
+        output = fused + x_c + x_e                                                       # MAIN_CA:868
+        loss, preds = self._ce(output, self.target)                                      # MAIN_CA:870-873
+        loss.backward()                                                                  # MAIN_CA:880
+        self.sync.reduce_grads(self.small)
+        self.sync.finish()
+        self.opt.step()                                                                  # MAIN_CA:882
+        return loss, output
+
+    def logits(self, n):
+        with torch.no_grad():
+            f_, xc_, xe_ = self.model(self.backs[0], self.backs[1], self.x, self.xe)
+        return (f_ + xc_ + xe_)[:n].float().cpu()
+
+
+def timed_region(run, steps, warmup, world, dev):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; max over ranks."""
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(max(warmup, 1)):
+        run.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = run.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t), loss
+
+
+def parity_vs_oracle(run, ref_out):
+    got = run.logits(ref_out.shape[0])
+    return dict(logits_max_rel_err=float((got - ref_out).abs().max() / ref_out.abs().max()),
+                argmax_equal=bool((got.argmax(1) == ref_out.argmax(1)).all()))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -210,131 +347,49 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL ('nccl' on ROCm) in production; MFVIT_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
         dist.init_process_group(os.environ.get("MFVIT_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} does not match WORLD_SIZE {world}: refusing to report a {world}-rank number as "
+                  f"{args.gpus} GPUs", file=sys.stderr)
+        sys.exit(2)
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from mfvit import _lib
-    from mfvit.ddp import GradSync
-    from mfvit.losses import cross_entropy
     lib = _lib.lib()
 
     if args.workload != "ca":
         return other_workloads(args, world, rank, dev, lib)
-    model, backs = build_models(args, dev)
-    g = torch.Generator().manual_seed(1234 + rank)                                       # SURVEY.md 8(d) synthetic inputs
+    run = CaRun(args, dev, rank, args.precision, args.mode)
     B = args.batch
-    x = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
-    xe = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
-    target = torch.randint(0, 3, (B,), generator=g).to(dev)
-
-    params = list(model.parameters())
-    for m in backs:
-        params += [p for p in m.parameters() if p.requires_grad]
-    from mfvit.optim import Adam
-    opt = Adam(params, lr=1e-4, betas=(0.9, 0.999))                                      # MAIN_CA:455-459 (multi-tensor HIP kernel)
-    sync = GradSync()
-    for m in backs:
-        sync.attach(m)
-    small = list(model.parameters()) + [p for m in backs for p in m.head.parameters()]
-
-    def step():
-        opt.zero_grad(set_to_none=True)
-        fused, x_c, x_e = model(backs[0], backs[1], x, xe)                               # MAIN_CA:862
-        output = fused + x_c + x_e                                                       # MAIN_CA:868
-        loss, preds = cross_entropy(output, target)                                      # MAIN_CA:870-873
-        loss.backward()                                                                  # MAIN_CA:880
-        sync.reduce_grads(small)
-        sync.finish()
-        opt.step()                                                                       # MAIN_CA:882
-        return loss, output
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     if args.serialize_streams:
-        model._two_streams = False
+        run.model._two_streams = False
         lib.mfvit_set_wgrad_stream(0)
 
-    # warm-up; the first warm-up steps time every kernel class to pick the dominant one
-    buf = (ctypes.c_double * (NCLS * 4))()
-    lib.mfvit_prof_enable((1 << NCLS) - 1)
-    for i in range(max(args.warmup, 1)):
-        step()
-    torch.cuda.synchronize()
-    lib.mfvit_prof_collect(buf, NCLS)
-    cls_ms = [buf[c * 4 + 1] for c in range(NCLS)]
-    dom = max(range(NCLS), key=lambda c: cls_ms[c])
-    lib.mfvit_prof_enable(1 << dom)
+    dt, loss = timed_region(run, args.steps, args.warmup, world, dev)
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, output = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    lib.mfvit_prof_collect(buf, NCLS)
-    lib.mfvit_prof_enable(0)
-    # attribution pass (untimed, after the timed region): same step with the two encoder streams and the wgrad side stream
-    # serialised, so that every kernel's event-timed duration is its own rather than a share of a co-scheduled GPU
+    # attribution pass (untimed, after the timed region): the same step with the two encoder streams and the wgrad side stream
+    # serialised, every kernel class timed with HIP events on its launch stream by the library (mfvit_prof_*): each kernel's
+    # duration is then its own rather than a share of a co-scheduled GPU.  The roofline kernel is the class with the largest time
+    # share IN THIS PASS.  Every rank runs it (the step contains the gradient all-reduce); rank 0 reports.
     solo = (ctypes.c_double * (NCLS * 4))()
-    solo_ms_per_step = 0.0
-    if True:   # every rank runs it (the step contains the gradient all-reduce); rank 0 reports
-        model._two_streams = False
-        lib.mfvit_set_wgrad_stream(0)
-        step()
-        torch.cuda.synchronize()
-        lib.mfvit_prof_enable((1 << NCLS) - 1)
-        t1 = time.perf_counter()
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        solo_ms_per_step = 1e3 * (time.perf_counter() - t1) / 3
-        lib.mfvit_prof_collect(solo, NCLS)
-        lib.mfvit_prof_enable(0)
-        if not args.serialize_streams:
-            lib.mfvit_set_wgrad_stream(1)
-            model._two_streams = True
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t)
+    run.model._two_streams = False
+    lib.mfvit_set_wgrad_stream(0)
+    run.step()
+    torch.cuda.synchronize()
+    lib.mfvit_prof_enable((1 << NCLS) - 1)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        run.step()
+    torch.cuda.synchronize()
+    solo_ms_per_step = 1e3 * (time.perf_counter() - t1) / 3
+    lib.mfvit_prof_collect(solo, NCLS)
+    lib.mfvit_prof_enable(0)
+    if not args.serialize_streams:
+        lib.mfvit_set_wgrad_stream(1)
+        run.model._two_streams = True
 
     if rank == 0:
-        # The dominant kernel's own duration comes from the serialized pass: HIP-event pairs around a launch on one of four
-        # co-scheduled streams also count the time that stream waits for CUs (they read 2-3x the rocprofv3 kernel duration), so the
-        # timed region's event numbers are reported beside it, not as the kernel's roofline.
-        name = lib.mfvit_prof_class_name(dom).decode()
-
-        def roof_of(launches, ms, flops, bts, per_step):
-            r = dict(launches_per_step=launches / per_step, avg_us=1e3 * ms / max(launches, 1))
-            if flops > 0:
-                ach = flops / (ms * 1e-3) / 1e12
-                r.update(bound="mfma", achieved=ach, peak=PEAK_TFLOPS[args.precision], unit="TFLOP/s", frac=ach / PEAK_TFLOPS[args.precision])
-            else:
-                ach = bts / (ms * 1e-3) / 1e9
-                r.update(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS)
-            return r
-
-        roof = dict(kernel=name)
-        roof.update(roof_of(*(solo[dom * 4 + i] for i in range(4)), 3))
-        roof["traffic"] = None
-        roof["measured"] = ("HIP events around every launch of this kernel class in a 3-step pass with the streams serialized, right "
-                            "after the timed region (same process, same tensors); agrees with the rocprofv3 kernel durations of "
-                            "`bench.py --serialize-streams` (profiles/)")
-        tr = roof_of(*(buf[dom * 4 + i] for i in range(4)), args.steps)
-        tr["note"] = "same kernel class timed inside the timed region: event pairs on co-scheduled streams include waiting for CUs"
-        roof["timed_region"] = tr
-        try:   # HBM bytes per launch of this kernel class from the committed PMC passes (profiles/README.md); null if absent
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_by_class.json")))
-            if args.batch == 128 and args.img == 224 and args.precision == "bf16" and name in tj["per_class"]:
-                roof["traffic"] = tj["per_class"][name]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = "profiles/r01_hbm_traffic_by_class.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-        except (OSError, ValueError, KeyError):
-            pass
         peak_t = PEAK_TFLOPS[args.precision]
         per = {}
         for c in range(NCLS):
@@ -346,33 +401,79 @@ def main():
                 elif by > 0:
                     e.update(gbs=round(by / (ms_c * 1e-3) / 1e9, 1), frac_of_hbm_peak=round(by / (ms_c * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
                 per[lib.mfvit_prof_class_name(c).decode()] = e
+        dom = max(range(NCLS), key=lambda c: solo[c * 4 + 1])
+        name = lib.mfvit_prof_class_name(dom).decode()
+        launches, ms, flops, bts = (solo[dom * 4 + i] for i in range(4))
+        roof = dict(kernel=name, launches_per_step=launches / 3, avg_us=1e3 * ms / max(launches, 1))
+        if flops > 0:
+            ach = flops / (ms * 1e-3) / 1e12
+            roof.update(bound="mfma", achieved=ach, peak=peak_t, unit="TFLOP/s", frac=ach / peak_t, peak_note=PEAK_NOTE[args.precision])
+        else:
+            ach = bts / (ms * 1e-3) / 1e9
+            roof.update(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS)
+        roof["traffic"] = None
+        roof["measured"] = ("HIP events (recorded by the library on the launch stream) around every launch of this kernel class in a 3-step "
+                            "pass with the streams serialized, right after the timed region (same process, same tensors); the class is the "
+                            "one with the largest time share in that pass; rocprofv3 kernel durations of `bench.py --serialize-streams` "
+                            "are under profiles/")
+        # HBM bytes per launch from the committed PMC passes: only when they were measured on THESE kernel sources at this precision
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_by_class.json")))
+            if (tj.get("source_hash") == _lib.source_hash() and tj.get("precision") == args.precision and args.batch == 128
+                    and args.img == 224 and name in tj["per_class"]):
+                roof["traffic"] = tj["per_class"][name]["hbm_bytes_per_launch"]
+                roof["traffic_source"] = ("profiles/r02_hbm_traffic_by_class.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                          f"kernel sources {tj['source_hash'][:12]})")
+            else:
+                roof["traffic_note"] = "committed PMC traffic was measured on other kernel sources / another precision: not reported"
+        except (OSError, ValueError, KeyError):
+            pass
         roof["serialized_pass"] = dict(note="3-step attribution pass after the timed region: one stream, no wgrad side stream",
                                        ms_per_step=round(solo_ms_per_step, 3), per_class=per)
-        total = sum(cls_ms) or 1.0
-        roof["warmup_time_share_by_class"] = {lib.mfvit_prof_class_name(c).decode(): round(cls_ms[c] / total, 4)
-                                              for c in range(NCLS) if cls_ms[c] > 0}
         out = dict(metric="images/sec (two-stream 224^2 vit_small MF-CA train step)", value=B * world * args.steps / dt,
                    unit="images/sec", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.precision, data="synthetic",
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=ARITH[args.precision], data="synthetic",
                    config=dict(workload=f"BASELINE configs[2]: two-stream MF-ViT CA finetune step, {B} CXR+Enh pairs/GPU at "
                                         f"{args.img}x{args.img}, 2x vit_small + cross-attention fusion + CE + backward + Adam; "
                                         f"mode {args.mode} ({'full backward through both backbones' if args.mode == 'T' else 'frozen backbones (README default)'})",
-                               global_batch=B * world, mode=args.mode, parallelism=f"dp{world}", streams="serialized" if args.serialize_streams else "two encoder streams + wgrad side streams",
+                               global_batch=B * world, mode=args.mode, precision=args.precision, parallelism=f"dp{world}",
+                               streams="serialized" if args.serialize_streams else "two encoder streams + wgrad side streams",
                                algorithmic_gflop_per_pair=GFLOP_PER_PAIR[args.mode] if args.img == 224 else None),
                    model_tflops=(GFLOP_PER_PAIR[args.mode] * B * world * args.steps / dt / 1e3) if args.img == 224 else None,
                    loss=float(loss.detach()), roofline=roof)
         print("[bench] gpu " + json.dumps(out), file=sys.stderr, flush=True)
+        ref_out = None
         if not args.no_cpu_baseline:
-            cb, ref_out = cpu_baseline(args, model, backs, x, xe, target)
+            cb, ref_out = cpu_baseline(args, run.model, run.backs, run.x, run.xe, run.target)
             out["cpu_baseline"] = cb
-            with torch.no_grad():                       # same (final) weights as the oracle copy, same first pairs
-                f_, xc_, xe_ = model(backs[0], backs[1], x, xe)
-            got = (f_ + xc_ + xe_)[:ref_out.shape[0]].float().cpu()
-            out["parity_vs_cpu_oracle"] = dict(
-                logits_max_rel_err=float((got - ref_out).abs().max() / ref_out.abs().max()),
-                argmax_equal=bool((got.argmax(1) == ref_out.argmax(1)).all()),
-                note="bench-precision logits vs the f32 CPU oracle on the same first 4 pairs and the same final weights; the "
-                     "1e-3 parity gate is asserted in precision='fp32' by tests/ (bf16 is the throughput mode)")
+            par = parity_vs_oracle(run, ref_out)      # same (final) weights as the oracle copy, same first pairs
+            par["note"] = (f"precision '{args.precision}' logits vs the f32 CPU oracle on the same first {ref_out.shape[0]} pairs and the same final "
+                           "weights (gate: 1e-3 relative, argmax equal)")
+            out["parity_vs_cpu_oracle"] = par
+        if world == 1 and not args.no_extras and not args.serialize_streams:
+            # secondary lines, same timing contract with fewer steps: the bf16 throughput mode and the reference README's frozen-
+            # backbone mode F.  They are NOT the headline (`value`).
+            also = {}
+            final_sd = ({k: v.detach().clone() for k, v in run.model.state_dict().items()},
+                        [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in run.backs])
+            del run
+            torch.cuda.empty_cache()
+            for tag, prec, mode in (("bf16_mode_" + args.mode, "bf16", args.mode), (args.precision + "_mode_F", args.precision, "F")):
+                if (prec, mode) == (args.precision, args.mode):
+                    continue
+                r2 = CaRun(args, dev, rank, prec, mode)
+                dt2, loss2 = timed_region(r2, 10, 3, 1, dev)
+                e = dict(value=B * 10 / dt2, unit="images/sec", ms_per_step=1e3 * dt2 / 10, steps=10, warmup=3, precision=prec, mode=mode,
+                         model_tflops=(GFLOP_PER_PAIR[mode] * B * 10 / dt2 / 1e3) if args.img == 224 else None)
+                if ref_out is not None and mode == args.mode:
+                    r2.model.load_state_dict(final_sd[0])            # the weights the oracle output was computed on
+                    for m, sd in zip(r2.backs, final_sd[1]):
+                        m.load_state_dict(sd)
+                    e["parity_vs_cpu_oracle"] = parity_vs_oracle(r2, ref_out)
+                also[tag] = e
+                del r2
+                torch.cuda.empty_cache()
+            out["also"] = also
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

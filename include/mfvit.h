@@ -29,6 +29,15 @@ typedef void* mfvit_stream_t; /* hipStream_t */
 
 #define MFVIT_F32 0  /* exact-f32 MFMA path (parity mode: logits within 1e-3 of the f32 CPU oracle) */
 #define MFVIT_BF16 1 /* bf16 operands, f32 accumulate / residual / statistics (throughput mode) */
+/* SPLIT bf16 ("bf16x3"): every MFMA operand is kept as hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits) and every product runs as
+ * three bf16 MFMAs (hi*hi + lo*hi + hi*lo) with f32 accumulation: f32-grade results (logits within 1e-3 of the f32 CPU path, the
+ * reference's CA finetune is fp32: MAIN_CA:862-882 has no autocast) at a third of the bf16 MFMA rate instead of the f32 MFMA rate
+ * (1/16).  Tensors of this dtype use the "I32" storage layout: a logical row-major [M][N] matrix (N % 32 == 0) is a bf16 [M][2N]
+ * array, every group of 32 logical columns stored as [hi x 32 | lo x 32]; leading dimensions are in STORAGE elements (2 x logical). */
+#define MFVIT_BF16X3 2
+/* fp16 operands (v_mfma_f32_32x32x16_f16), f32 accumulate / residual / statistics: the arithmetic of the reference's autocast
+ * pretraining (MAIN_MOCO:349,533); pair with mfvit_amp_unscale for the GradScaler semantics (MAIN_MOCO:546-548). */
+#define MFVIT_F16 3
 
 int mfvit_abi_version(void);
 const char* mfvit_build_info(void);
@@ -38,7 +47,7 @@ const char* mfvit_build_info(void);
  * call sites MAIN_SS:276,711  MAIN_CA:289-290  FUS:80,83,128-135  BLD:29-30,164,174; spec SURVEY.md Appendix A).
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct mfvit_vit_cfg {
-    int dtype;           /* MFVIT_F32 | MFVIT_BF16 : storage / MFMA operand type of activations and weight shadows */
+    int dtype;           /* MFVIT_F32 | MFVIT_BF16 | MFVIT_BF16X3 | MFVIT_F16 : storage / MFMA operand type of activations and weight shadows */
     int batch;           /* images */
     int img_h, img_w;    /* multiples of 16 */
     int dim;             /* 384 (vit_small) */
@@ -265,6 +274,10 @@ int mfvit_adam_step(const int64_t* table, int nchunks, float lr, float beta1, fl
                     mfvit_stream_t stream);
 int mfvit_sgd_step(const int64_t* table, int nchunks, float lr, float momentum, float weight_decay, int first_step,
                    mfvit_stream_t stream);
+/* torch.cuda.amp.GradScaler.unscale_ over the same chunk table (MAIN_MOCO:349,546-548: scaler.scale(loss).backward();
+ * scaler.step(optimizer); scaler.update()): every gradient element is multiplied by inv_scale and *found_inf (device float,
+ * cleared by the caller) is set to 1 when any element was inf / nan before the multiplication. */
+int mfvit_amp_unscale(const int64_t* table, int nchunks, float inv_scale, float* found_inf, mfvit_stream_t stream);
 
 #ifdef __cplusplus
 }

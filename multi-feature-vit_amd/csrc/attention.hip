@@ -252,38 +252,44 @@ static int launch_bwd(const void* qkv, const void* out, const void* dout, const 
     return MFVIT_OK;
 }
 
+// exact (VALU, thread-per-row) kernels: f32 parity path, and the fallback of the 16-bit types when a head does not fit the MFMA
+// kernels' LDS images.  Split tensors (MFVIT_BF16X3) have no exact variant: MFVIT_ENOSYS.
+#define MFVIT_EXACT_BY_DTYPE(CALL32, CALL64)                                                       \
+    switch (dtype) {                                                                               \
+        case MFVIT_F32: { typedef float TT; return HD == 32 ? CALL32 : CALL64; }                   \
+        case MFVIT_BF16: { typedef bf16 TT; return HD == 32 ? CALL32 : CALL64; }                   \
+        case MFVIT_F16: { typedef f16 TT; return HD == 32 ? CALL32 : CALL64; }                     \
+        case MFVIT_BF16X3: return MFVIT_ENOSYS;                                                    \
+        default: return MFVIT_EINVAL;                                                              \
+    }
 int attn_fwd_exact(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HD, hipStream_t st) {
-    if (HD == 32) return dtype == MFVIT_BF16 ? launch_fwd<bf16, 32>(qkv, out, lse, B, Tn, H, st) : launch_fwd<float, 32>(qkv, out, lse, B, Tn, H, st);
-    if (HD == 64) return dtype == MFVIT_BF16 ? launch_fwd<bf16, 64>(qkv, out, lse, B, Tn, H, st) : launch_fwd<float, 64>(qkv, out, lse, B, Tn, H, st);
-    return MFVIT_EINVAL;
+    if (HD != 32 && HD != 64) return MFVIT_EINVAL;
+    MFVIT_EXACT_BY_DTYPE((launch_fwd<TT, 32>(qkv, out, lse, B, Tn, H, st)), (launch_fwd<TT, 64>(qkv, out, lse, B, Tn, H, st)))
 }
 int attn_bwd_exact(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
                    int H, int HD, hipStream_t st) {
-    if (HD == 32)
-        return dtype == MFVIT_BF16 ? launch_bwd<bf16, 32>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st)
-                                   : launch_bwd<float, 32>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
-    if (HD == 64)
-        return dtype == MFVIT_BF16 ? launch_bwd<bf16, 64>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st)
-                                   : launch_bwd<float, 64>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
-    return MFVIT_EINVAL;
+    if (HD != 32 && HD != 64) return MFVIT_EINVAL;
+    MFVIT_EXACT_BY_DTYPE((launch_bwd<TT, 32>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st)),
+                         (launch_bwd<TT, 64>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st)))
 }
 
-// ---- dispatch: bf16 / head_dim 32 -> MFMA kernels (attention_mfma.hip); everything else -> exact kernels
+// ---- dispatch: 16-bit types / head_dim 32 -> MFMA kernels (attention_mfma.hip); everything else -> exact kernels
 bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward);
-int attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st);
-int attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
+int attn_fwd_mfma(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st);
+int attn_bwd_mfma(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
                   hipStream_t st);
 static bool force_exact() {
     static const bool v = [] { const char* e = getenv("MFVIT_ATTN_EXACT"); return e && e[0] == '1'; }();
     return v;
 }
 int attn_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, hipStream_t st) {
-    if (!force_exact() && attn_mfma_supported(dtype, Tn, HDim, false)) return attn_fwd_mfma(qkv, out, lse, B, Tn, H, st);
+    if (!(force_exact() && dtype != MFVIT_BF16X3) && attn_mfma_supported(dtype, Tn, HDim, false)) return attn_fwd_mfma(dtype, qkv, out, lse, B, Tn, H, st);
     return attn_fwd_exact(dtype, qkv, out, lse, B, Tn, H, HDim, st);
 }
 int attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
              int HDim, hipStream_t st) {
-    if (!force_exact() && attn_mfma_supported(dtype, Tn, HDim, true)) return attn_bwd_mfma(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+    if (!(force_exact() && dtype != MFVIT_BF16X3) && attn_mfma_supported(dtype, Tn, HDim, true))
+        return attn_bwd_mfma(dtype, qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
     return attn_bwd_exact(dtype, qkv, out, dout, lse, dqkv, dbias, B, Tn, H, HDim, st);
 }
 

@@ -23,70 +23,112 @@ namespace mfvit {
 
 namespace {
 
+// Element types: bf16, f16 (same data movement, v_mfma_f32_32x32x16_f16) and sbf16 = SPLIT bf16 (MFVIT_BF16X3): a head's row piece
+// is [hi x 32 | lo x 32] (128 B), every product of two tensors runs as three MFMAs (hi*hi + lo*hi + hi*lo) and P / dS are split
+// in registers (hi = bf16(p), lo = bf16(p - hi)) before they feed the second product - f32-grade attention on the bf16 matrix core.
 constexpr int HD = 32;
-constexpr int RSB = 80;  // LDS row pitch in bytes (64 B of data + 16): b128 row reads of 16 consecutive rows are conflict-free
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 
+template <typename T> struct AttnT {
+    static constexpr bool SP = is_split<T>::value;
+    static constexpr int EP = SP ? 2 : 1;
+    static constexpr int RB = 64 * EP;        // bytes of one head row piece
+    static constexpr int RSB = RB + 16;       // padded LDS row pitch: b128 row reads of 16 consecutive rows are conflict-free
+    typedef typename Vec8<T>::type frag_t;
+    typedef typename Vec4<T>::type vec4_t;
+    typedef typename Vec4<T>::elem E;
+    static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) { return MmaTraits_mma(a, b, c); }
+};
+__device__ __forceinline__ f32x16 MmaTraits_mma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 MmaTraits_mma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// natural-order fragment: row (rowbase + lane&31), elements d = 16 s + 8 (lane>>5) .. +8
-template <int PITCH = RSB> __device__ __forceinline__ bf16x8 row_frag(const char* img, int rowbase, int s, int lane) {
-    return *(const bf16x8*)(img + (rowbase + (lane & 31)) * PITCH + 32 * s + 16 * (lane >> 5));
+// natural-order fragment: row (rowbase + lane&31), elements d = 16 s + 8 (lane>>5) .. +8 of part `part` (0 = hi / plain, 1 = lo)
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type row_frag(const char* img, int pitch, int rowbase, int s, int lane, int part = 0) {
+    return *(const typename Vec8<T>::type*)(img + (rowbase + (lane & 31)) * pitch + 64 * part + 32 * s + 16 * (lane >> 5));
 }
 // transposed fragment in ACCUMULATOR k order: lane holds column d = lane&31; element j = row (rowbase + 16 s + 8 (j>>2) + 4 h + (j&3))
-__device__ __forceinline__ bf16x8 tr_frag(const char* img, int pitch, int rowbase, int s, int lane) {
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type tr_frag(const char* img, int pitch, int rowbase, int s, int lane, int part = 0) {
     const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
-    const char* a = img + (rowbase + 16 * s + 4 * h + q) * pitch + (16 * g1 + 4 * p) * 2;
+    const char* a = img + (rowbase + 16 * s + 4 * h + q) * pitch + 64 * part + (16 * g1 + 4 * p) * 2;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + 8 * pitch));
-    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    union { struct { s16x4 a, b; } s; typename Vec8<T>::type v; } u;
     u.s.a = lo;
     u.s.b = hi;
     return u.v;
 }
-__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
-    bf16x8 o;
+// registers 8 s .. 8 s + 7 of an accumulator as a B fragment (k step s); split: hi and lo parts
+template <typename T> __device__ __forceinline__ void pack8(const f32x16& v, int s, typename Vec8<T>::type& hi, typename Vec8<T>::type& lo) {
+    typedef typename Vec4<T>::elem E;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[8 * s + j];
-    return o;
+    for (int j = 0; j < 8; ++j) {
+        const float x = v[8 * s + j];
+        const E h = (E)x;
+        hi[j] = h;
+        if constexpr (is_split<T>::value) lo[j] = (E)(x - (float)h);
+    }
 }
-__device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+// acc += A (x) B as one MFMA (plain) or three (split: a_hi b_hi + a_lo b_hi + a_hi b_lo)
+template <typename T> __device__ __forceinline__ f32x16 mma3(typename Vec8<T>::type ah, typename Vec8<T>::type al, typename Vec8<T>::type bh,
+                                                             typename Vec8<T>::type bl, f32x16 c) {
+    if constexpr (is_split<T>::value) {
+        c = MmaTraits_mma(al, bh, c);
+        c = MmaTraits_mma(ah, bl, c);
+    }
+    return MmaTraits_mma(ah, bh, c);
+}
 
-// store an accumulator tile X^T[d][col] (col on the lane) as rows of a [.., HD] bf16 tensor: 4 x 8-byte stores per lane
-__device__ __forceinline__ void store_tile_T(bf16* row_ptr, const f32x16& acc, float mul, int lane) {
+// store an accumulator tile X^T[d][col] (col on the lane) as rows of a [.., HD] tensor of T: 4 (split: 8) x 8-byte stores per lane
+template <typename T> __device__ __forceinline__ void store_tile_T(typename Vec4<T>::elem* row_ptr, const f32x16& acc, float mul, int lane) {
+    typedef typename Vec4<T>::elem E;
+    typedef typename Vec4<T>::type V4;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        bf16x4 o;
+        V4 o, l;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (bf16)(acc[4 * g + j] * mul);
-        *(bf16x4*)(row_ptr + 8 * g + 4 * (lane >> 5)) = o;
+        for (int j = 0; j < 4; ++j) {
+            const float x = acc[4 * g + j] * mul;
+            const E h = (E)x;
+            o[j] = h;
+            if constexpr (is_split<T>::value) l[j] = (E)(x - (float)h);
+        }
+        *(V4*)(row_ptr + 8 * g + 4 * (lane >> 5)) = o;
+        if constexpr (is_split<T>::value) *(V4*)(row_ptr + 32 + 8 * g + 4 * (lane >> 5)) = l;
     }
 }
 
 constexpr int NKC = 4;  // key tiles per register-resident chunk (4 x 16 = 64 score registers -> 2 waves per SIMD)
 
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, float* __restrict__ lse,
-                                                            int Tn, int H, float scale) {
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<T>::elem* __restrict__ qkv, typename Vec4<T>::elem* __restrict__ out,
+                                                            float* __restrict__ lse, int Tn, int H, float scale) {
+    typedef AttnT<T> A;
+    typedef typename A::E E;
+    typedef typename A::frag_t frag_t;
+    constexpr int EP = A::EP, KP = A::RSB, VP = A::RB, CPR = A::RB / 16;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tpad = (Tn + 31) & ~31;
     char* Ks = lds;
-    char* Vs = lds + Tpad * RSB;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // the heads of one image share an XCD: their 64 B row pieces share L2 lines
+    char* Vs = lds + Tpad * KP;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // the heads of one image share an XCD: their row pieces share L2 lines
     const int b = bid / H, h = bid % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long rs = 3L * H * HD;
-    const bf16* base = qkv + (long)b * Tn * rs + h * HD;
-    for (int q = threadIdx.x; q < Tpad * 4; q += blockDim.x) {   // K and V pieces of a row loaded together (one HBM round trip, not two)
-        const int t = q >> 2, cidx = q & 3;
+    const long hs = (long)H * HD * EP;                  // storage elements of one of q / k / v per token
+    const long rs = 3 * hs;
+    const E* base = qkv + (long)b * Tn * rs + h * HD * EP;
+    for (int q = threadIdx.x; q < Tpad * CPR; q += blockDim.x) {   // K and V pieces of a row loaded together (one HBM round trip, not two)
+        const int t = q / CPR, cidx = q % CPR;
         uint4 vk = make_uint4(0, 0, 0, 0), vv = vk;
         if (t < Tn) {
-            const bf16* rp = base + (long)t * rs + (long)H * HD + 8 * cidx;
+            const E* rp = base + (long)t * rs + hs + 8 * cidx;
             vk = *(const uint4*)rp;
-            vv = *(const uint4*)(rp + (long)H * HD);
+            vv = *(const uint4*)(rp + hs);
         }
-        *(uint4*)(Ks + t * RSB + 16 * cidx) = vk;
-        *(uint4*)(Vs + t * 64 + 16 * cidx) = vv;
+        *(uint4*)(Ks + t * KP + 16 * cidx) = vk;
+        *(uint4*)(Vs + t * VP + 16 * cidx) = vv;
     }
     __syncthreads();
     const float c = scale * 1.4426950408889634f;
@@ -94,9 +136,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
     for (int qt = wave; qt < nt; qt += 4) {
         const int q = qt * 32 + (lane & 31);
         const int qc = q < Tn ? q : Tn - 1;
-        bf16x8 qf[2];
+        frag_t qf[2], ql[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) qf[s] = *(const bf16x8*)(base + (long)qc * rs + 16 * s + 8 * (lane >> 5));
+        for (int s = 0; s < 2; ++s) {
+            qf[s] = *(const frag_t*)(base + (long)qc * rs + 16 * s + 8 * (lane >> 5));
+            if constexpr (A::SP) ql[s] = *(const frag_t*)(base + (long)qc * rs + 32 + 16 * s + 8 * (lane >> 5));
+            else ql[s] = qf[s];
+        }
         float m2 = -INFINITY, lsum = 0.f;
         f32x16 o;
 #pragma unroll
@@ -110,7 +156,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) sc[t] = mma(row_frag(Ks, (k0 + t) * 32, s, lane), qf[s], sc[t]);
+                    for (int s = 0; s < 2; ++s)
+                        sc[t] = mma3<T>(row_frag<T>(Ks, KP, (k0 + t) * 32, s, lane, 0), row_frag<T>(Ks, KP, (k0 + t) * 32, s, lane, A::SP ? 1 : 0),
+                                        qf[s], ql[s], sc[t]);
                     if ((k0 + t + 1) * 32 > Tn) {  // last key tile: mask the zero-padded keys
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
@@ -142,25 +190,34 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
                         lsum += p;
                     }
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) o = mma(tr_frag(Vs, 64, (k0 + t) * 32, s, lane), pack8(sc[t], s), o);
+                    for (int s = 0; s < 2; ++s) {
+                        frag_t ph, pl;
+                        pack8<T>(sc[t], s, ph, pl);
+                        if constexpr (!A::SP) pl = ph;
+                        o = mma3<T>(tr_frag<T>(Vs, VP, (k0 + t) * 32, s, lane, 0), tr_frag<T>(Vs, VP, (k0 + t) * 32, s, lane, A::SP ? 1 : 0), ph, pl, o);
+                    }
                 }
         }
         lsum += __shfl_xor(lsum, 32, 64);
         if (q < Tn) {
-            store_tile_T(out + ((long)b * Tn + q) * H * HD + h * HD, o, 1.0f / lsum, lane);
+            store_tile_T<T>(out + (((long)b * Tn + q) * H * HD + h * HD) * EP, o, 1.0f / lsum, lane);
             if (lane < 32) lse[((long)b * H + h) * Tn + q] = (m2 + log2f(lsum)) * 0.6931471805599453f;
         }
     }
 }
 
 // One 8-wave workgroup per (image, head): Q, K, V, dO of the head are read from HBM exactly once into four LDS images
-// (PITCH = 80: conflict-free row reads, T <= 480; PITCH = 64 reaches T = 608 inside the 160 KB of LDS).  -lse/scale and
+// (padded pitch: conflict-free row reads; unpadded when only that fits the 160 KB of LDS).  -lse/scale and
 // -D = -rowsum(dO o O) enter the score MFMAs as accumulator initial values, so S - lse/scale and dP - D come out of the
-// matrix core and the VALU work per element is mul, exp2, mul, cvt.
-template <int PITCH>
-__global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
-                                                            const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                            bf16* __restrict__ dqkv, int Tn, int H, float scale) {
+// matrix core and the VALU work per element is mul, exp2, mul, cvt (+ the hi / lo split of P and dS for split tensors).
+template <typename T, int PITCH>
+__global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename Vec4<T>::elem* __restrict__ out,
+                                                            const typename Vec4<T>::elem* __restrict__ dout, const float* __restrict__ lse,
+                                                            typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale) {
+    typedef AttnT<T> A;
+    typedef typename A::E E;
+    typedef typename A::frag_t frag_t;
+    constexpr int EP = A::EP, CPR = A::RB / 16, LO = A::SP ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tpad = (Tn + 31) & ~31;
     char* Qs = lds;
@@ -169,32 +226,41 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restri
     char* dOs = Vs + Tpad * PITCH;
     float* Ls = (float*)(dOs + Tpad * PITCH);
     float* Ds = Ls + Tpad;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // the heads of one image share an XCD: their 64 B row pieces share L2 lines
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // the heads of one image share an XCD: their row pieces share L2 lines
     const int b = bid / H, h = bid % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long rs = 3L * H * HD, os = (long)H * HD;
-    const bf16* base = qkv + (long)b * Tn * rs + h * HD;
-    bf16* dbase = dqkv + (long)b * Tn * rs + h * HD;
-    const bf16* obase = out + (long)b * Tn * os + h * HD;
-    const bf16* dobase = dout + (long)b * Tn * os + h * HD;
+    const long hs = (long)H * HD * EP, rs = 3 * hs, os = hs;
+    const E* base = qkv + (long)b * Tn * rs + h * HD * EP;
+    E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
+    const E* obase = out + (long)b * Tn * os + h * HD * EP;
+    const E* dobase = dout + (long)b * Tn * os + h * HD * EP;
     // one fused staging pass: the five loads of a row piece (Q, K, V, dO, O) are issued together - staged image by image, each image
     // paid its own HBM round trip before the next one's loads went out (operands are cold inside the training step)
-    for (int q = threadIdx.x; q < Tpad * 4; q += blockDim.x) {  // four lanes per row, 16 B each
-        const int t = q >> 2, cidx = q & 3;
+    for (int q = threadIdx.x; q < Tpad * CPR; q += blockDim.x) {  // CPR lanes per row, 16 B each
+        const int t = q / CPR, cidx = q % CPR;
         uint4 vq = make_uint4(0, 0, 0, 0), vk = vq, vv = vq, vd = vq;
         float D = 0.f, L = -1e30f;                                 // padded queries: p = exp2(-1e30 c) = 0
         if (t < Tn) {
-            const bf16* rp = base + (long)t * rs + 8 * cidx;
+            const E* rp = base + (long)t * rs + 8 * cidx;
             vq = *(const uint4*)rp;
-            vk = *(const uint4*)(rp + (long)H * HD);
-            vv = *(const uint4*)(rp + 2L * H * HD);
+            vk = *(const uint4*)(rp + hs);
+            vv = *(const uint4*)(rp + 2 * hs);
             vd = *(const uint4*)(dobase + (long)t * os + 8 * cidx);
-            const bf16x8 o = *(const bf16x8*)(obase + (long)t * os + 8 * cidx);
             if (cidx == 0) L = -lse[((long)b * H + h) * Tn + t] / scale;
-            union { uint4 u; bf16x8 b8; } cv;
-            cv.u = vd;
+            if (cidx < 4) {   // D = sum_d dO[d] O[d]: the lane of (hi) chunk cidx covers 8 d's (split: both parts of dO and O)
+                union { uint4 u; frag_t b8; } cv;
+                cv.u = vd;
+                const frag_t o = *(const frag_t*)(obase + (long)t * os + 8 * cidx);
+                if constexpr (A::SP) {
+                    const frag_t dl = *(const frag_t*)(dobase + (long)t * os + 32 + 8 * cidx);
+                    const frag_t ol = *(const frag_t*)(obase + (long)t * os + 32 + 8 * cidx);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) D = fmaf((float)cv.b8[j], (float)o[j], D);
+                    for (int j = 0; j < 8; ++j) D = fmaf((float)cv.b8[j] + (float)dl[j], (float)o[j] + (float)ol[j], D);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) D = fmaf((float)cv.b8[j], (float)o[j], D);
+                }
+            }
         }
         *(uint4*)(Qs + t * PITCH + 16 * cidx) = vq;
         *(uint4*)(Ks + t * PITCH + 16 * cidx) = vk;
@@ -202,6 +268,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restri
         *(uint4*)(dOs + t * PITCH + 16 * cidx) = vd;
         D += __shfl_xor(D, 1, 64);
         D += __shfl_xor(D, 2, 64);
+        if constexpr (A::SP) D += __shfl_xor(D, 4, 64);
         if (cidx == 0) {
             Ds[t] = -D;
             Ls[t] = L;
@@ -212,11 +279,13 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restri
     const int nt = Tpad >> 5;
     // ---------------- phase A: dQ, wave = query tile
     for (int qt = wave; qt < nt; qt += 8) {
-        bf16x8 qf[2], dof[2];
+        frag_t qf[2], ql[2], dof[2], dol[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            qf[s] = row_frag<PITCH>(Qs, qt * 32, s, lane);
-            dof[s] = row_frag<PITCH>(dOs, qt * 32, s, lane);
+            qf[s] = row_frag<T>(Qs, PITCH, qt * 32, s, lane, 0);
+            ql[s] = row_frag<T>(Qs, PITCH, qt * 32, s, lane, LO);
+            dof[s] = row_frag<T>(dOs, PITCH, qt * 32, s, lane, 0);
+            dol[s] = row_frag<T>(dOs, PITCH, qt * 32, s, lane, LO);
         }
         const float L = Ls[qt * 32 + (lane & 31)], Dq = Ds[qt * 32 + (lane & 31)];  // -lse/scale, -D
         f32x16 dq;
@@ -228,25 +297,32 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restri
             for (int r = 0; r < 16; ++r) { st[r] = L; dp[r] = Dq; }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                st = mma(row_frag<PITCH>(Ks, kt * 32, s, lane), qf[s], st);
-                dp = mma(row_frag<PITCH>(Vs, kt * 32, s, lane), dof[s], dp);
+                st = mma3<T>(row_frag<T>(Ks, PITCH, kt * 32, s, lane, 0), row_frag<T>(Ks, PITCH, kt * 32, s, lane, LO), qf[s], ql[s], st);
+                dp = mma3<T>(row_frag<T>(Vs, PITCH, kt * 32, s, lane, 0), row_frag<T>(Vs, PITCH, kt * 32, s, lane, LO), dof[s], dol[s], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)  // dS^T / scale (padded keys: K rows are zero, so their dQ contribution vanishes)
                 st[r] = __builtin_amdgcn_exp2f(st[r] * c) * dp[r];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) dq = mma(tr_frag(Ks, PITCH, kt * 32, s, lane), pack8(st, s), dq);
+            for (int s = 0; s < 2; ++s) {
+                frag_t sh, sl;
+                pack8<T>(st, s, sh, sl);
+                if constexpr (!A::SP) sl = sh;
+                dq = mma3<T>(tr_frag<T>(Ks, PITCH, kt * 32, s, lane, 0), tr_frag<T>(Ks, PITCH, kt * 32, s, lane, LO), sh, sl, dq);
+            }
         }
         const int q = qt * 32 + (lane & 31);
-        if (q < Tn) store_tile_T(dbase + (long)q * rs, dq, scale, lane);
+        if (q < Tn) store_tile_T<T>(dbase + (long)q * rs, dq, scale, lane);
     }
     // ---------------- phase B: dK, dV, wave = key tile
     for (int kt = wave; kt < nt; kt += 8) {
-        bf16x8 kf[2], vf[2];
+        frag_t kf[2], kl[2], vf[2], vl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            kf[s] = row_frag<PITCH>(Ks, kt * 32, s, lane);
-            vf[s] = row_frag<PITCH>(Vs, kt * 32, s, lane);
+            kf[s] = row_frag<T>(Ks, PITCH, kt * 32, s, lane, 0);
+            kl[s] = row_frag<T>(Ks, PITCH, kt * 32, s, lane, LO);
+            vf[s] = row_frag<T>(Vs, PITCH, kt * 32, s, lane, 0);
+            vl[s] = row_frag<T>(Vs, PITCH, kt * 32, s, lane, LO);
         }
         f32x16 dk, dv;
 #pragma unroll
@@ -263,8 +339,8 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restri
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                sm = mma(row_frag<PITCH>(Qs, qt * 32, s, lane), kf[s], sm);   // S[q][key] - lse[q]/scale
-                dp = mma(row_frag<PITCH>(dOs, qt * 32, s, lane), vf[s], dp);  // dP[q][key] - D[q]
+                sm = mma3<T>(row_frag<T>(Qs, PITCH, qt * 32, s, lane, 0), row_frag<T>(Qs, PITCH, qt * 32, s, lane, LO), kf[s], kl[s], sm);   // S[q][key] - lse[q]/scale
+                dp = mma3<T>(row_frag<T>(dOs, PITCH, qt * 32, s, lane, 0), row_frag<T>(dOs, PITCH, qt * 32, s, lane, LO), vf[s], vl[s], dp);  // dP[q][key] - D[q]
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -273,82 +349,111 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const bf16* __restri
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                dv = mma(tr_frag(dOs, PITCH, qt * 32, s, lane), pack8(sm, s), dv);
-                dk = mma(tr_frag(Qs, PITCH, qt * 32, s, lane), pack8(dp, s), dk);
+                frag_t ph, pl, sh, sl;
+                pack8<T>(sm, s, ph, pl);
+                pack8<T>(dp, s, sh, sl);
+                if constexpr (!A::SP) { pl = ph; sl = sh; }
+                dv = mma3<T>(tr_frag<T>(dOs, PITCH, qt * 32, s, lane, 0), tr_frag<T>(dOs, PITCH, qt * 32, s, lane, LO), ph, pl, dv);
+                dk = mma3<T>(tr_frag<T>(Qs, PITCH, qt * 32, s, lane, 0), tr_frag<T>(Qs, PITCH, qt * 32, s, lane, LO), sh, sl, dk);
             }
         }
         const int k = kt * 32 + (lane & 31);
         if (k < Tn) {
-            store_tile_T(dbase + (long)k * rs + (long)H * HD, dk, scale, lane);
-            store_tile_T(dbase + (long)k * rs + 2L * H * HD, dv, 1.0f, lane);
+            store_tile_T<T>(dbase + (long)k * rs + hs, dk, scale, lane);
+            store_tile_T<T>(dbase + (long)k * rs + 2 * hs, dv, 1.0f, lane);
         }
     }
 }
 
-// column sums of a bf16 [M][N] matrix into f32 out[N] (atomicAdd); N % 8 == 0.  Used for d qkv.bias.
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ x, long ld, float* __restrict__ out, int M, int N) {
+// column sums of a [M][N] matrix of T (N logical columns, N % 8 == 0) into f32 out[N] (atomicAdd).  Used for d qkv.bias.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_t_kernel(const typename Vec4<T>::elem* __restrict__ x, long ld, float* __restrict__ out, int M, int N) {
+    typedef typename Vec8<T>::type V8;
     const int r0 = blockIdx.x * 64, r1 = min(M, r0 + 64);
     for (int cch = threadIdx.x; cch < N / 8; cch += 256) {
+        const int col = is_split<T>::value ? split_col(8 * cch) : 8 * cch;
         float a[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = 0.f;
         for (int r = r0; r < r1; ++r) {
-            const bf16x8 v = *(const bf16x8*)(x + (long)r * ld + 8 * cch);
+            const V8 v = *(const V8*)(x + (long)r * ld + col);
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+            if constexpr (is_split<T>::value) {
+                const V8 l = *(const V8*)(x + (long)r * ld + col + 32);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += (float)l[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) atomicAdd(out + 8 * cch + j, a[j]);
     }
 }
 
-}  // namespace
-
-bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward) {
-    if (dtype != MFVIT_BF16 || HDim != HD || Tn < 1) return false;
+template <typename T> int launch_fwd_t(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
+    typedef typename Vec4<T>::elem E;
     const int Tpad = (Tn + 31) & ~31;
-    const int bytes = backward ? 4 * Tpad * 64 + 2 * Tpad * 4 : Tpad * RSB + Tpad * 64;
-    return bytes <= 160 * 1024;
-}
-
-int attn_fwd_mfma(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
-    const int Tpad = (Tn + 31) & ~31;
-    const int bytes = Tpad * RSB + Tpad * 64;
+    const int bytes = Tpad * (AttnT<T>::RSB + AttnT<T>::RB);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
-    MFVIT_LAUNCH(attn_fwd_mfma_kernel, dim3(B * H), dim3(256), bytes, st, (const bf16*)qkv, (bf16*)out, lse, Tn, H,
-                       1.0f / sqrtf((float)HD));
+    MFVIT_LAUNCH((attn_fwd_mfma_kernel<T>), dim3(B * H), dim3(256), bytes, st, (const E*)qkv, (E*)out, lse, Tn, H, 1.0f / sqrtf((float)HD));
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
-int attn_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
-                  hipStream_t st) {
+template <typename T> int launch_bwd_t(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
+                                       int H, hipStream_t st) {
+    typedef typename Vec4<T>::elem E;
+    constexpr int RSB = AttnT<T>::RSB, RB = AttnT<T>::RB;
     const int Tpad = (Tn + 31) & ~31;
     const bool wide = 4 * Tpad * RSB + 2 * Tpad * 4 <= 160 * 1024;
-    const int bytes = 4 * Tpad * (wide ? RSB : 64) + 2 * Tpad * 4;
+    const int bytes = 4 * Tpad * (wide ? RSB : RB) + 2 * Tpad * 4;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<RSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     {
         ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
         if (wide)
-            MFVIT_LAUNCH(attn_bwd_mfma_kernel<RSB>, dim3(B * H), dim3(512), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
-                         lse, (bf16*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
+            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RSB>), dim3(B * H), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
+                         (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
         else
-            MFVIT_LAUNCH(attn_bwd_mfma_kernel<64>, dim3(B * H), dim3(512), bytes, st, (const bf16*)qkv, (const bf16*)out, (const bf16*)dout,
-                         lse, (bf16*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
+            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RB>), dim3(B * H), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
+                         (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
         MFVIT_CHECK_LAUNCH();
     }
     if (dbias) {
         const int M = B * Tn, N = 3 * H * HD;
-        MFVIT_LAUNCH(colsum_bf16_kernel, dim3((M + 63) / 64), dim3(256), 0, st, (const bf16*)dqkv, (long)N, dbias, M, N);
+        MFVIT_LAUNCH((colsum_t_kernel<T>), dim3((M + 63) / 64), dim3(256), 0, st, (const E*)dqkv, (long)N * AttnT<T>::EP, dbias, M, N);
         MFVIT_CHECK_LAUNCH();
     }
     return MFVIT_OK;
+}
+
+}  // namespace
+
+bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward) {
+    if ((dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || HDim != HD || Tn < 1) return false;
+    const int Tpad = (Tn + 31) & ~31;
+    const int rb = dtype == MFVIT_BF16X3 ? 128 : 64;
+    const int bytes = backward ? 4 * Tpad * rb + 2 * Tpad * 4 : Tpad * (rb + 16) + Tpad * rb;
+    return bytes <= 160 * 1024;
+}
+
+int attn_fwd_mfma(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
+    if (dtype == MFVIT_BF16) return launch_fwd_t<bf16>(qkv, out, lse, B, Tn, H, st);
+    if (dtype == MFVIT_BF16X3) return launch_fwd_t<sbf16>(qkv, out, lse, B, Tn, H, st);
+    if (dtype == MFVIT_F16) return launch_fwd_t<f16>(qkv, out, lse, B, Tn, H, st);
+    return MFVIT_EINVAL;
+}
+int attn_bwd_mfma(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
+                  hipStream_t st) {
+    if (dtype == MFVIT_BF16) return launch_bwd_t<bf16>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+    if (dtype == MFVIT_BF16X3) return launch_bwd_t<sbf16>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+    if (dtype == MFVIT_F16) return launch_bwd_t<f16>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+    return MFVIT_EINVAL;
 }
 
 }  // namespace mfvit

@@ -16,16 +16,65 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
-// error codes (MFVIT_OK / MFVIT_E*) and dtype tags (MFVIT_F32 / MFVIT_BF16) come from the public header
+// error codes (MFVIT_OK / MFVIT_E*) and dtype tags (MFVIT_F32 / MFVIT_BF16 / MFVIT_BF16X3 / MFVIT_F16) come from the public header
 
 constexpr int WAVE = 64;
 
+// Element of a SPLIT-bf16 tensor (dtype MFVIT_BF16X3): a logical f32 value x is kept as hi = bf16(x), lo = bf16(x - hi), i.e. 16
+// mantissa bits, and a product of two such tensors runs as three bf16 MFMAs (hi*hi + lo*hi + hi*lo, f32 accumulate; the dropped
+// lo*lo term is 2^-16 relative).  Storage layout "I32": a logical row-major [M][N] matrix (N % 32 == 0) is a bf16 [M][2N] array in
+// which every group of 32 logical columns occupies 64 consecutive elements, [hi x 32 | lo x 32]; logical (m, n) has its hi part at
+// column 64 (n / 32) + n % 32 and its lo part 32 elements further.  A 128-byte LDS row of a K-contiguous tile therefore holds one
+// 32-wide k group of both parts, and a head_dim-32 attention head's row piece is one such group.  Leading dimensions of split
+// tensors are given in STORAGE elements (twice the logical width).
+struct sbf16 { bf16 v; };
+template <typename T> struct is_split { static constexpr bool value = false; };
+template <> struct is_split<sbf16> { static constexpr bool value = true; };
+// storage elements per logical element (1, or 2 for split tensors)
+template <typename T> struct elems_per { static constexpr int value = is_split<T>::value ? 2 : 1; };
+// storage column of the hi part of logical column n (lo part: + 32)
+__device__ __host__ __forceinline__ constexpr int split_col(int n) { return ((n >> 5) << 6) + (n & 31); }
+__device__ __forceinline__ void split2(float x, bf16& hi, bf16& lo) {
+    hi = (bf16)x;
+    lo = (bf16)(x - (float)hi);
+}
+// 8 x 16-bit MFMA operand fragment of element type T
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> { typedef bf16x8 type; };
+template <> struct Vec8<sbf16> { typedef bf16x8 type; };
+template <> struct Vec8<f16> { typedef f16x8 type; };
+template <typename T> struct Vec4;
+template <> struct Vec4<bf16> { typedef bf16x4 type; typedef bf16 elem; };
+template <> struct Vec4<sbf16> { typedef bf16x4 type; typedef bf16 elem; };
+template <> struct Vec4<f16> { typedef f16x4 type; typedef f16 elem; };
+
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
+__device__ __forceinline__ float to_f32(f16 x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf16)x; }  // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+template <> __device__ __forceinline__ f16 from_f32<f16>(float x) { return (f16)x; }     // v_cvt_f16_f32 (RNE; overflow -> inf)
+
+// Typed element access for tensors of element type T at a LOGICAL column (row pointer given in storage elements):
+// plain types store one value; split tensors store the hi / lo pair at the I32 positions.
+template <typename T> __device__ __forceinline__ void store_elem(T* row, int n, float v) { row[n] = from_f32<T>(v); }
+template <> __device__ __forceinline__ void store_elem<sbf16>(sbf16* row, int n, float v) {
+    bf16 hi, lo;
+    split2(v, hi, lo);
+    bf16* r = (bf16*)row + split_col(n);
+    r[0] = hi;
+    r[32] = lo;
+}
+template <typename T> __device__ __forceinline__ float load_elem(const T* row, int n) { return to_f32(row[n]); }
+template <> __device__ __forceinline__ float load_elem<sbf16>(const sbf16* row, int n) {
+    const bf16* r = (const bf16*)row + split_col(n);
+    return (float)r[0] + (float)r[32];
+}
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // d/dx [ x * Phi(x) ] = Phi(x) + x * phi(x)

@@ -22,12 +22,20 @@ __global__ void im2col16_kernel(const float* __restrict__ img, T* __restrict__ P
         const int b = (int)r;
         const float* s = img + (((long)b * 3 + c) * Hh + ph * 16 + py) * Ww + pw * 16 + half * 8;
         const float4 v0 = *(const float4*)s, v1 = *(const float4*)(s + 4);
-        T* d = P + ((long)(b * gh + ph) * gw + pw) * 768 + c * 256 + py * 16 + half * 8;
+        const int k = c * 256 + py * 16 + half * 8;             // logical column (a multiple of 8: inside one 32-group)
+        T* d = P + ((long)(b * gh + ph) * gw + pw) * 768 * elems_per<T>::value + (is_split<T>::value ? split_col(k) : k);
         if constexpr (sizeof(T) == 2) {
-            bf16x8 o;
-            o[0] = (bf16)v0.x; o[1] = (bf16)v0.y; o[2] = (bf16)v0.z; o[3] = (bf16)v0.w;
-            o[4] = (bf16)v1.x; o[5] = (bf16)v1.y; o[6] = (bf16)v1.z; o[7] = (bf16)v1.w;
-            *(bf16x8*)d = o;
+            typedef typename Vec4<T>::elem E;
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            typename Vec8<T>::type o, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const E h = (E)f[j];
+                o[j] = h;
+                if constexpr (is_split<T>::value) l[j] = (E)(f[j] - (float)h);
+            }
+            *(typename Vec8<T>::type*)d = o;
+            if constexpr (is_split<T>::value) *(typename Vec8<T>::type*)((E*)d + 32) = l;
         } else {
             *(float4*)d = v0;
             *(float4*)(d + 4) = v1;
@@ -40,8 +48,14 @@ int im2col16(int dtype, const float* img, void* P, int B, int H, int W, hipStrea
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (dtype == MFVIT_BF16)
         MFVIT_LAUNCH(im2col16_kernel<bf16>, dim3(blocks), dim3(256), 0, st, img, (bf16*)P, B, H, W);
-    else
+    else if (dtype == MFVIT_BF16X3)
+        MFVIT_LAUNCH(im2col16_kernel<sbf16>, dim3(blocks), dim3(256), 0, st, img, (sbf16*)P, B, H, W);
+    else if (dtype == MFVIT_F16)
+        MFVIT_LAUNCH(im2col16_kernel<f16>, dim3(blocks), dim3(256), 0, st, img, (f16*)P, B, H, W);
+    else if (dtype == MFVIT_F32)
         MFVIT_LAUNCH(im2col16_kernel<float>, dim3(blocks), dim3(256), 0, st, img, (float*)P, B, H, W);
+    else
+        return MFVIT_EINVAL;
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -88,7 +102,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
         const float o = (v[i] - mu) * rs * gamma[n] + beta[n];
         if (y) {
             if (y_f32) ((float*)y)[g * ldy + n] = o;
-            else ((T*)y)[g * ldy + n] = from_f32<T>(o);
+            else store_elem<T>((T*)y + g * ldy, n, o);
         }
     }
 }
@@ -100,9 +114,18 @@ int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long
 #define MFVIT_LN(TT, NPL)                                                                                                        \
     MFVIT_LAUNCH((ln_rows_kernel<TT, NPL>), grid, blk, 0, st, in0, ld0, in1, ld1, mod1, xout, ldx, y, ldy, y_f32, gamma, beta, eps, \
                        mean, rstd, rows, row_stride, row_off, in0_bcast)
-    if (N == 384) { if (dtype == MFVIT_BF16) MFVIT_LN(bf16, 6); else MFVIT_LN(float, 6); }
-    else if (N == 768) { if (dtype == MFVIT_BF16) MFVIT_LN(bf16, 12); else MFVIT_LN(float, 12); }
+#define MFVIT_LN_N(NPL)                                  \
+    switch (dtype) {                                     \
+        case MFVIT_BF16: MFVIT_LN(bf16, NPL); break;     \
+        case MFVIT_BF16X3: MFVIT_LN(sbf16, NPL); break;  \
+        case MFVIT_F16: MFVIT_LN(f16, NPL); break;       \
+        case MFVIT_F32: MFVIT_LN(float, NPL); break;     \
+        default: return MFVIT_EINVAL;                    \
+    }
+    if (N == 384) { MFVIT_LN_N(6) }
+    else if (N == 768) { MFVIT_LN_N(12) }
     else return MFVIT_EINVAL;
+#undef MFVIT_LN_N
 #undef MFVIT_LN
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -147,7 +170,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
             float o = rs * (d[i] * gm[i] - c1 - h[i] * c2);
             if (dres) o += dres[g * ldres + n];
             if (dx) dx[g * lddx + n] = o;
-            if (dxT) dxT[g * lddxT + n] = from_f32<T>(o);
+            if (dxT) store_elem<T>(dxT + g * lddxT, n, o);
             ax[i] += o;
         }
     }
@@ -183,9 +206,18 @@ int ln_bwd_rows(int dtype, int N, const float* dy, long lddy, const float* x, lo
 #define MFVIT_LNB(TT, NPL)                                                                                                         \
     MFVIT_LAUNCH((ln_bwd_rows_kernel<TT, NPL>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres, ldres, dx, \
                        lddx, (TT*)dxT, lddxT, dgamma, dbeta, dcol, cpart, rows, row_stride, row_off)
-    if (N == 384) { if (dtype == MFVIT_BF16) MFVIT_LNB(bf16, 6); else MFVIT_LNB(float, 6); }
-    else if (N == 768) { if (dtype == MFVIT_BF16) MFVIT_LNB(bf16, 12); else MFVIT_LNB(float, 12); }
+#define MFVIT_LNB_N(NPL)                                  \
+    switch (dtype) {                                      \
+        case MFVIT_BF16: MFVIT_LNB(bf16, NPL); break;     \
+        case MFVIT_BF16X3: MFVIT_LNB(sbf16, NPL); break;  \
+        case MFVIT_F16: MFVIT_LNB(f16, NPL); break;       \
+        case MFVIT_F32: MFVIT_LNB(float, NPL); break;     \
+        default: return MFVIT_EINVAL;                     \
+    }
+    if (N == 384) { MFVIT_LNB_N(6) }
+    else if (N == 768) { MFVIT_LNB_N(12) }
     else return MFVIT_EINVAL;
+#undef MFVIT_LNB_N
 #undef MFVIT_LNB
     MFVIT_CHECK_LAUNCH();
     if (cpart) return colpart_reduce(cpart, blocks, N, 3, dgamma, dbeta, dcol, st);
@@ -208,7 +240,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         float v = 0.f;
         if (r0 + r < R && c0 + c < C) {
             v = src[(long)(r0 + r) * C + c0 + c];
-            if (dst) dst[(long)(r0 + r) * C + c0 + c] = from_f32<T>(v);
+            if (dst) store_elem<T>(dst + (long)(r0 + r) * C * elems_per<T>::value, c0 + c, v);
         }
         tile[r][c] = v;
     }
@@ -216,7 +248,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     if (dstT) {
         for (int q = threadIdx.x; q < 64 * 64; q += 256) {
             const int c = q >> 6, r = q & 63;
-            if (r0 + r < R && c0 + c < C) dstT[(long)(c0 + c) * R + r0 + r] = from_f32<T>(tile[r][c]);
+            if (r0 + r < R && c0 + c < C) store_elem<T>(dstT + (long)(c0 + c) * R * elems_per<T>::value, r0 + r, tile[r][c]);
         }
     }
 }
@@ -226,8 +258,15 @@ int cast_transpose_batched(int dtype, const float* src, void* dst, void* dstT, i
     const dim3 grid((C + 63) / 64, (R + 63) / 64, nb);
     if (dtype == MFVIT_BF16)
         MFVIT_LAUNCH(cast_transpose_kernel<bf16>, grid, dim3(256), 0, st, src, (bf16*)dst, (bf16*)dstT, R, C, s_src, s_dst, s_dstT);
-    else
+    else if (dtype == MFVIT_BF16X3) {   // split layout: both R and C are column counts of one of the outputs -> multiples of 32
+        if ((dst && C % 32) || (dstT && R % 32)) return MFVIT_EINVAL;
+        MFVIT_LAUNCH(cast_transpose_kernel<sbf16>, grid, dim3(256), 0, st, src, (sbf16*)dst, (sbf16*)dstT, R, C, s_src, s_dst, s_dstT);
+    } else if (dtype == MFVIT_F16)
+        MFVIT_LAUNCH(cast_transpose_kernel<f16>, grid, dim3(256), 0, st, src, (f16*)dst, (f16*)dstT, R, C, s_src, s_dst, s_dstT);
+    else if (dtype == MFVIT_F32)
         MFVIT_LAUNCH(cast_transpose_kernel<float>, grid, dim3(256), 0, st, src, (float*)dst, (float*)dstT, R, C, s_src, s_dst, s_dstT);
+    else
+        return MFVIT_EINVAL;
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

@@ -31,6 +31,14 @@ template <> struct MmaTraits<bf16> {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
 };
+template <> struct MmaTraits<sbf16> : MmaTraits<bf16> {};   // split tensors: the same MFMA on the hi / lo parts
+template <> struct MmaTraits<f16> {
+    typedef f16x8 frag_t;
+    static constexpr int KSTEP = 16;
+    static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
 template <> struct MmaTraits<float> {
     typedef float frag_t;
     static constexpr int KSTEP = 2;
@@ -43,7 +51,7 @@ template <> struct MmaTraits<float> {
 // K-contiguous tile image: R rows, BKB bytes of k per row (64 or 128).
 template <typename T, int R, int BKB> struct KTile;
 
-template <int R, int BKB> struct KTile<bf16, R, BKB> {
+template <typename T, int R, int BKB> struct KTile16 {
     static constexpr int CPR = BKB / 16;            // 16-B chunks per row
     static constexpr int RPW = 16 / CPR;            // rows per 256-B bank row
     static constexpr int BYTES = R * BKB;
@@ -51,10 +59,14 @@ template <int R, int BKB> struct KTile<bf16, R, BKB> {
     static __device__ __forceinline__ int off(int row, int c) { return row * BKB + 16 * (c ^ ((row / RPW) % CPR)); }
     static __device__ __forceinline__ void put(char* t, int row, int c, uint4 v) { *(uint4*)(t + off(row, c)) = v; }
     // fragment for MFMA step s: lane holds row (rowbase + lane&31), k = 16 s + 8 (lane>>5) .. +8
-    static __device__ __forceinline__ bf16x8 frag(const char* t, int rowbase, int s, int lane) {
-        return *(const bf16x8*)(t + off(rowbase + (lane & 31), 2 * s + (lane >> 5)));
+    static __device__ __forceinline__ typename Vec8<T>::type frag(const char* t, int rowbase, int s, int lane) {
+        return *(const typename Vec8<T>::type*)(t + off(rowbase + (lane & 31), 2 * s + (lane >> 5)));
     }
 };
+template <int R, int BKB> struct KTile<bf16, R, BKB> : KTile16<bf16, R, BKB> {};
+template <int R, int BKB> struct KTile<f16, R, BKB> : KTile16<f16, R, BKB> {};
+// split tensors: with BKB = 128 a row holds one 32-wide k group, [hi x 32 | lo x 32] = MFMA steps 0, 1 (hi) and 2, 3 (lo)
+template <int R, int BKB> struct KTile<sbf16, R, BKB> : KTile16<sbf16, R, BKB> {};
 
 template <int R, int BKB> struct KTile<float, R, BKB> {
     static constexpr int CPR = BKB / 16;
@@ -110,25 +122,28 @@ template <typename T, int R, int BKB, int NT> struct KStage {
 // K-strided tile image (wgrad operands): KR reduction rows x R "row" elements, global layout [m][row].
 template <typename T, int R, int KR> struct STile;
 
-template <int R, int KR> struct STile<bf16, R, KR> {
+template <typename T, int R, int KR> struct STile16 {
     static constexpr int LD = R + 32;               // 320-B pitch for R = 128: the 4 rows of a tr-read block land
     static constexpr int BYTES = KR * LD * 2;       // in 4 disjoint 64-B windows of the 256-B bank row
     static constexpr int KSTEPS = KR / 16;
     // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(row) block; lane 4q+p supplies &img[k0+q][row0+4p],
     // lane i receives column i, element q = row k0+q.  Two of them give k = 8h .. 8h+7 for row (lane&31).
-    static __device__ __forceinline__ bf16x8 frag(const char* t, int rowbase, int s, int lane) {
+    static __device__ __forceinline__ typename Vec8<T>::type frag(const char* t, int rowbase, int s, int lane) {
         const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
         const int k0 = 16 * s + 8 * h + q;
         const int col = rowbase + 16 * g1 + 4 * p;
         typedef __attribute__((address_space(3))) s16x4* lptr;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(t + ((k0)*LD + col) * 2));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(t + ((k0 + 4) * LD + col) * 2));
-        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        union { struct { s16x4 a, b; } s; typename Vec8<T>::type v; } u;
         u.s.a = lo;
         u.s.b = hi;
         return u.v;
     }
 };
+template <int R, int KR> struct STile<bf16, R, KR> : STile16<bf16, R, KR> {};
+template <int R, int KR> struct STile<f16, R, KR> : STile16<f16, R, KR> {};
+template <int R, int KR> struct STile<sbf16, R, KR> : STile16<sbf16, R, KR> {};
 template <int R, int KR> struct STile<float, R, KR> {
     static constexpr int LD = R + 4;
     static constexpr int BYTES = KR * LD * 4;
@@ -243,7 +258,9 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const int nk = p.K / BK;
+        constexpr bool SPLIT = is_split<T>::value;
+        static_assert(!SPLIT || BKB == 128, "a split K tile is one 32-wide k group: [hi x 32 | lo x 32] = 128 bytes per row");
+        const int nk = p.K * elems_per<T>::value / BK;      // K tiles over the STORAGE width
         sa.load(A, p.lda, m0, p.M, 0, tid);
         sb.load(W, p.ldw, n0, p.N, 0, tid);
         sa.store(lds, tid);
@@ -256,6 +273,59 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
             if (kt + 1 < nk) {
                 sa.load(A, p.lda, m0, p.M, (kt + 1) * BK, tid);
                 sb.load(W, p.ldw, n0, p.N, (kt + 1) * BK, tid);
+            }
+            if constexpr (SPLIT) {
+                // split product: per 16-wide k step  acc += a_hi b_hi + a_lo b_hi + a_hi b_lo  (3 MFMAs from 4 fragments; the
+                // fragments of step 1 are read while the 12 - 18 MFMAs of step 0 run).  MFMA steps 0, 1 of the row are the hi
+                // parts, 2, 3 the lo parts (KTile<sbf16>).
+                typename MmaTraits<T>::frag_t ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[0][i] = TA::frag(ta, (wm * TM + i) * 32, 0, lane);
+                    al[0][i] = TA::frag(ta, (wm * TM + i) * 32, 2, lane);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[0][j] = TB::frag(tb, (wn * TN + j) * 32, 0, lane);
+                    bl[0][j] = TB::frag(tb, (wn * TN + j) * 32, 2, lane);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    if (s == 0) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            ah[1][i] = TA::frag(ta, (wm * TM + i) * 32, 1, lane);
+                            al[1][i] = TA::frag(ta, (wm * TM + i) * 32, 3, lane);
+                        }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            bh[1][j] = TB::frag(tb, (wn * TN + j) * 32, 1, lane);
+                            bl[1][j] = TB::frag(tb, (wn * TN + j) * 32, 3, lane);
+                        }
+                    }
+                    if (PIPE) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(al[s][i], bh[s][j], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[s][i], bl[s][j], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[s][i], bh[s][j], acc[i][j]);
+                    if (PIPE) __builtin_amdgcn_sched_barrier(0);
+                }
+                if (kt + 1 < nk) {
+                    char* na = lds + (cur ^ 1) * STAGE_BYTES;
+                    sa.store(na, tid);
+                    sb.store(na + TA::BYTES, tid);
+                }
+                __syncthreads();
+                cur ^= 1;
+                continue;
             }
             // fragments double-buffered by hand: the LDS reads of sub-step s+1 are issued before the MFMAs of sub-step s (left to
             // itself the compiler waits right behind each read, which at 1-2 waves per SIMD exposes the LDS latency every sub-step)

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
     const int bid = xcd_remap(blockIdx.x, ntn * ntm);
     const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
     f32x16 acc[Loop::TM][Loop::TN];
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, bf16>::value) {
         if (p.y_f32 == 99) NtLoopGlds<BM, BN, WM, WN, 4>::run(p, m0, n0, lds, acc);   // LDS-DMA main loop (bf16)
         else Loop::run(p, m0, n0, lds, acc);
     } else {
@@ -45,13 +45,14 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
     // Rows >= M replicate row M-1 exactly (the A loads are clamped), so they are stored as identical duplicates: no branches.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    constexpr int PITCH = BN * (int)sizeof(T) + 16;
-    constexpr int CPRO = BN * (int)sizeof(T) / 16;      // 16-byte chunks per tile row
+    constexpr int EP = elems_per<T>::value;             // storage elements per logical element (2 for split tensors)
+    constexpr int ROWB = BN * (int)sizeof(T) * EP;      // bytes of one tile row in the output tensor
+    constexpr int PITCH = ROWB + 16;
+    constexpr int CPRO = ROWB / 16;                     // 16-byte chunks per tile row
     constexpr int NCHO = BM * CPRO / 256;
     char* tile = lds;                                   // the staging buffers are free after the main loop's last barrier
-    auto elem = [&](int i, int j, int r) -> T* {
-        return (T*)(tile + ((wm * Loop::TM + i) * 32 + acc_row(r, lane)) * PITCH) + (wn * Loop::TN + j) * 32 + (lane & 31);
-    };
+    auto erow = [&](int i, int r) -> T* { return (T*)(tile + ((wm * Loop::TM + i) * 32 + acc_row(r, lane)) * PITCH); };
+    auto ecol = [&](int j) -> int { return (wn * Loop::TN + j) * 32 + (lane & 31); };   // LOGICAL column inside the tile
     auto store_tile = [&](void* out, long ldo) {
         __syncthreads();
 #pragma unroll
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
             const int q = tid + i * 256, row = q / CPRO, c = q % CPRO;
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;
-            *(uint4*)((char*)out + ((long)m * ldo + n0) * sizeof(T) + 16 * c) = *(const uint4*)(tile + row * PITCH + 16 * c);
+            *(uint4*)((char*)out + ((long)m * ldo + n0 * EP) * sizeof(T) + 16 * c) = *(const uint4*)(tile + row * PITCH + 16 * c);
         }
     };
     if (EPI == EPI_GELU_BWD) {   // aux = gelu'(pre-activation) saved by the forward: load its tile with 16-byte reads
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
             const int q = tid + i * 256, row = q / CPRO, c = q % CPRO;
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;
-            *(uint4*)(tile + row * PITCH + 16 * c) = *(const uint4*)((const char*)p.aux + ((long)m * p.ldaux + n0) * sizeof(T) + 16 * c);
+            *(uint4*)(tile + row * PITCH + 16 * c) = *(const uint4*)((const char*)p.aux + ((long)m * p.ldaux + n0 * EP) * sizeof(T) + 16 * c);
         }
         __syncthreads();
     }
@@ -87,17 +88,17 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[i][j][r] + bj[j];
-                T* e = elem(i, j, r);
+                T* e = erow(i, r);
                 if (EPI == EPI_BIAS_GELU) {
                     acc[i][j][r] = v;                                   // kept for the second output
-                    *e = from_f32<T>(gelu_grad_t<T>(v));                // out0 = gelu'(pre): all the backward needs
+                    store_elem<T>(e, ecol(j), gelu_grad_t<T>(v));       // out0 = gelu'(pre): all the backward needs
                 } else if (EPI == EPI_GELU_BWD) {
-                    v *= to_f32(*e);
-                    *e = from_f32<T>(v);
+                    v *= load_elem<T>(e, ecol(j));
+                    store_elem<T>(e, ecol(j), v);
                     const bool ok = m0 + (wm * Loop::TM + i) * 32 + acc_row(r, lane) < p.M;
                     csum += ok ? v : 0.f;
                 } else {
-                    *e = from_f32<T>(v);
+                    store_elem<T>(e, ecol(j), v);
                 }
             }
         if (EPI == EPI_GELU_BWD && p.cs0) {
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
 #pragma unroll
             for (int i = 0; i < Loop::TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) *elem(i, j, r) = from_f32<T>(gelu_t<T>(acc[i][j][r]));
+                for (int r = 0; r < 16; ++r) store_elem<T>(erow(i, r), ecol(j), gelu_t<T>(acc[i][j][r]));
         store_tile(p.out1, p.ldo1);
     }
 }
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
     const int m0 = blockIdx.x * rpw;
     p.M = p.M < m0 + rpw ? p.M : m0 + rpw;   // everything below treats rows >= p.M as padding
     f32x16 acc[TM][TN];
-    if constexpr (sizeof(T) == 2 && BKB == 128) {
+    if constexpr (std::is_same<T, bf16>::value && BKB == 128) {
         // 128-row variant: the stage splits evenly over the 8 waves, so the LDS-DMA ring (BK 32, 4 slots in the same 128 KB, counted
         // vmcnt: two stages in flight) applies - OPT-IN (MFVIT_ROW_GLDS=1): fc2 + LN 71 vs 75 us on a repeated launch whose operands sit
         // in the Infinity Cache, but 84 vs 76 us inside the training step where they come from HBM.  (Measured and dropped for the 64-row variants: a 2-slot
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
                 } else {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        ((T*)p.out1)[(long)orow * p.ldo1 + ncol[j]] = from_f32<T>((acc[i][j][r] - mu[i][r]) * rs * gj[j] + btj[j]);
+                        store_elem<T>((T*)p.out1 + (long)orow * p.ldo1, ncol[j], (acc[i][j][r] - mu[i][r]) * rs * gj[j] + btj[j]);
                 }
             }
     } else {  // REPI_LNBWD_RES: acc = dL/dy (y = LN output); aux = saved LN input x (f32)
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
                 for (int j = 0; j < TN; ++j) dxo[(long)m * p.ldo0 + ncol[j]] = acc[i][j][r];
                 if (dxt) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) dxt[(long)m * p.ldo1 + ncol[j]] = from_f32<T>(acc[i][j][r]);
+                    for (int j = 0; j < TN; ++j) store_elem<T>(dxt + (long)m * p.ldo1, ncol[j], acc[i][j][r]);
                 }
             }
         if (p.cpart) __syncthreads();                  // red / tot are free again; reuse as [WM][3][BN] scratch
@@ -393,13 +394,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     apply_batch<T>(p, 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntk = p.K / BK2;
+    // split tensors (sbf16): the tile grid runs over the STORAGE columns of dY [m][2N] and X [m][2K].  A wave's 64 x 64 storage
+    // sub-tile is [hi x 32 | lo x 32] of 32 logical n against the same of 32 logical k, so its four accumulators are the hi*hi,
+    // hi*lo, lo*hi (and lo*lo, skipped) blocks of ONE 32 x 32 logical tile: they are summed in the epilogue.
+    constexpr bool SPLIT = is_split<T>::value;
+    constexpr int EP = elems_per<T>::value;
+    const int ntk = p.K * EP / BK2;
     // XCD-aware placement (speed only): blocks are dealt round-robin over the 8 XCDs, each with a private L2.  All tiles of
     // one m-split read the same dY / X rows, so a split's tiles are kept on ONE XCD (split = xcd + 8 * ...): the operands are
     // then fetched into that L2 once and re-read from it by the other tiles instead of 3-12 times from HBM / Infinity Cache.
     int tile = blockIdx.x, split = blockIdx.y;
     if (gridDim.y == 1 && p.splits > 1) {          // 1-D launch: each XCD gets a contiguous run of the split-major block order
-        const int tiles = ntk * (p.N / BN);
+        const int tiles = ntk * (p.N * EP / BN);
         const int lin = xcd_remap(blockIdx.x, gridDim.x);
         split = lin / tiles;
         tile = lin % tiles;
@@ -427,8 +433,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     f32x16 bacc[2];
     typename MmaTraits<T>::frag_t ones;
     if constexpr (sizeof(T) == 2) {
+        typedef typename Vec4<T>::elem E16;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+        for (int j = 0; j < 8; ++j) ones[j] = (E16)1.0f;
     } else {
         ones = 1.0f;
     }
@@ -478,7 +485,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][i], b[s & 1][j], acc[i][j]);
+                    for (int j = 0; j < 2; ++j)
+                        if (!(SPLIT && i == 1 && j == 1)) acc[i][j] = MmaTraits<T>::mma(a[s & 1][i], b[s & 1][j], acc[i][j]);
                 if constexpr (CS) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) bacc[i] = MmaTraits<T>::mma(a[s & 1][i], ones, bacc[i]);
@@ -496,38 +504,47 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     };
     if (do_cs) main_loop(std::true_type{});
     else main_loop(std::false_type{});
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[0][0][r] += acc[0][1][r] + acc[1][0][r];
+            bacc[0][r] += bacc[1][r];
+        }
+    }
+    constexpr int NI = SPLIT ? 1 : 2;                  // accumulator tiles left per wave after the merge
+    const int nw = SPLIT ? n0 / 2 + wm * 32 : n0 + wm * 64, kw = SPLIT ? k0 / 2 + wn * 32 : k0 + wn * 64;   // LOGICAL tile origin of this wave
     if (p.cpart) {
         // split partials as PLAIN stores into scratch [split][N][K] (summed into out0 by tn_reduce_kernel): float atomics run at
         // ~1.3 TB/s chip-wide and one 256-B wave-instruction per ~50 ns per CU, i.e. ~13 us for the 256 of a 128x128 tile
         float* part = p.cpart + (long)split * p.N * p.K;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + (wm * 2 + i) * 32 + acc_row(r, lane);
-                    const int k = k0 + (wn * 2 + j) * 32 + (lane & 31);
+                    const int n = nw + i * 32 + acc_row(r, lane);
+                    const int k = kw + j * 32 + (lane & 31);
                     part[(long)n * p.K + k] = acc[i][j][r];
                 }
     } else {
         float* out = (float*)p.out0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int n = n0 + (wm * 2 + i) * 32 + acc_row(r, lane);
-                    const int k = k0 + (wn * 2 + j) * 32 + (lane & 31);
+                    const int n = nw + i * 32 + acc_row(r, lane);
+                    const int k = kw + j * 32 + (lane & 31);
                     atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
                 }
     }
     if (do_cs && (lane & 31) == 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + n0 + (wm * 2 + i) * 32 + acc_row(r, lane), bacc[i][r]);
+            for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + nw + i * 32 + acc_row(r, lane), bacc[i][r]);
     }
 }
 
@@ -554,11 +571,12 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStream_t st) {
     typedef NtLoop<T, 128, 128, 128, 2, 2> Loop;
     GemmP p = pin;
-    if (p.N % 128 || p.K % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
+    constexpr int EP = elems_per<T>::value;
+    if (p.N % 128 || p.K * EP % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
     static const int use_glds = [] { const char* e = getenv("MFVIT_GLDS"); return e ? atoi(e) : 0; }();
-    if (sizeof(T) == 2 && use_glds) p.y_f32 = 99;
+    if (std::is_same<T, bf16>::value && use_glds) p.y_f32 = 99;
     const int nwg = (p.N / 128) * ((p.M + 127) / 128);
-    constexpr int epi_bytes = 128 * (128 * (int)sizeof(T) + 16);
+    constexpr int epi_bytes = 128 * (128 * (int)sizeof(T) * EP + 16);
     constexpr int lds_bytes = Loop::LDS_BYTES > epi_bytes ? Loop::LDS_BYTES : epi_bytes;
     static bool attr_set = false;
     if (!attr_set) {
@@ -595,9 +613,9 @@ template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v
     GemmP p = pin;
     p.rows_per_wg = balanced_rows(p.M, BM);
     static const int row_glds = [] { const char* e = getenv("MFVIT_ROW_GLDS"); return e ? atoi(e) : 0; }();   // opt-in, see the kernel
-    p.splits = (row_glds && sizeof(T) == 2 && BKB == 128 && BM == 128) ? 78 : 0;      // field unused by the row kernels otherwise
+    p.splits = (row_glds && std::is_same<T, bf16>::value && BKB == 128 && BM == 128) ? 78 : 0;      // field unused by the row kernels otherwise
     typedef NtLoop<T, BM, ROW_BN, BKB, WM, 4> Loop;
-    if (p.N != ROW_BN || p.K % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
+    if (p.N != ROW_BN || p.K * elems_per<T>::value % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
     constexpr int need = BM * ROW_RS * 4 + BM * 4;
     constexpr int need2 = WM * 3 * ROW_BN * 4;
     constexpr int bytes0 = Loop::LDS_BYTES > need ? Loop::LDS_BYTES : need;
@@ -614,9 +632,11 @@ template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v
 }
 template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_t st) {
     const int v = row_variant();
-    if (v == 0 || p.K % (128 / (int)sizeof(T))) return launch_row_v<T, REPI, 1, 64, 64>(p, st);
+    if constexpr (!is_split<T>::value) {   // (a split K tile is a whole [hi | lo] group: 128-byte rows only)
+        if (v == 0 || p.K % (128 / (int)sizeof(T))) return launch_row_v<T, REPI, 1, 64, 64>(p, st);
+        if (v == 3) return launch_row_v<T, REPI, 2, 64, 64>(p, st);
+    }
     if (v == 1) return launch_row_v<T, REPI, 1, 128, 64>(p, st);
-    if (v == 3) return launch_row_v<T, REPI, 2, 64, 64>(p, st);
     if constexpr (REPI == REPI_RES_LN) {
         // 128-row variant: every workgroup streams the whole W[384][K] from L2, so doubling the rows per workgroup halves that
         // traffic (the row kernels' main loop is bound by it); worth it once K is large enough to amortise the 77 % grid fill
@@ -625,9 +645,10 @@ template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_
     return launch_row_v<T, REPI, 2, 128, 64>(p, st);
 }
 template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
-    if (p.N % 128 || p.K % 128 || p.M <= 0) return MFVIT_EINVAL;
+    constexpr int EP = elems_per<T>::value;
+    if (p.N * EP % 128 || p.K * EP % 128 || p.M <= 0) return MFVIT_EINVAL;
     constexpr int KR = 128 / (int)sizeof(T);
-    const int tiles = (p.N / 128) * (p.K / 128);
+    const int tiles = (p.N * EP / 128) * (p.K * EP / 128);
     if (p.splits <= 0) {
         static const int target = [] { const char* e = getenv("MFVIT_TN_TARGET"); return e ? atoi(e) : 384; }();
         // Fill the chip evenly: two workgroups fit a CU (2 x 80 KB of LDS), so aim just BELOW a multiple of 256 blocks - 288
@@ -688,30 +709,39 @@ int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float
     return MFVIT_OK;
 }
 
+// dtype -> element type dispatch (MFVIT_F32 float | MFVIT_BF16 bf16 | MFVIT_BF16X3 sbf16 (split) | MFVIT_F16 f16)
+#define MFVIT_BY_DTYPE(dtype, CALL)                       \
+    switch (dtype) {                                      \
+        case MFVIT_F32: { typedef float TT; return CALL; }    \
+        case MFVIT_BF16: { typedef bf16 TT; return CALL; }    \
+        case MFVIT_BF16X3: { typedef sbf16 TT; return CALL; } \
+        case MFVIT_F16: { typedef f16 TT; return CALL; }      \
+        default: return MFVIT_EINVAL;                     \
+    }
+template <int EPI> static int tile_by_dtype(int dtype, const GemmP& p, hipStream_t st) { MFVIT_BY_DTYPE(dtype, (launch_tile<TT, EPI>(p, st))) }
+template <int REPI> static int row_by_dtype(int dtype, const GemmP& p, hipStream_t st) { MFVIT_BY_DTYPE(dtype, (launch_row<TT, REPI>(p, st))) }
+static int tn_by_dtype(int dtype, const GemmP& p, hipStream_t st) { MFVIT_BY_DTYPE(dtype, (launch_tn<TT>(p, st))) }
+
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
     if (gemm_nt_ws_supported(dtype, epi, p)) return gemm_nt_ws(epi, p, st);
     if (gemm_nt_pers_supported(dtype, epi, p)) return gemm_nt_pers(epi, p, st);
-#define MFVIT_TILE_CASE(E)                                              \
-    case E:                                                             \
-        return dtype == MFVIT_BF16 ? launch_tile<bf16, E>(p, st) : launch_tile<float, E>(p, st);
     if (epi == EPI_GELU_BWD && p.cpart && p.cs0) {
-        const int rc = dtype == MFVIT_BF16 ? launch_tile<bf16, EPI_GELU_BWD>(p, st) : launch_tile<float, EPI_GELU_BWD>(p, st);
+        const int rc = tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
         if (rc != MFVIT_OK) return rc;
         return colpart_reduce(p.cpart, (p.M + 127) / 128, p.N, 1, p.cs0, nullptr, nullptr, st);
     }
     switch (epi) {
-        MFVIT_TILE_CASE(EPI_BIAS)
-        MFVIT_TILE_CASE(EPI_BIAS_GELU)
-        MFVIT_TILE_CASE(EPI_GELU_BWD)
-        MFVIT_TILE_CASE(EPI_NONE)
+        case EPI_BIAS: return tile_by_dtype<EPI_BIAS>(dtype, p, st);
+        case EPI_BIAS_GELU: return tile_by_dtype<EPI_BIAS_GELU>(dtype, p, st);
+        case EPI_GELU_BWD: return tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
+        case EPI_NONE: return tile_by_dtype<EPI_NONE>(dtype, p, st);
     }
-#undef MFVIT_TILE_CASE
     return MFVIT_EINVAL;
 }
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
-    if (repi == REPI_RES_LN) return dtype == MFVIT_BF16 ? launch_row<bf16, REPI_RES_LN>(p, st) : launch_row<float, REPI_RES_LN>(p, st);
+    if (repi == REPI_RES_LN) return row_by_dtype<REPI_RES_LN>(dtype, p, st);
     if (repi == REPI_LNBWD_RES) {
-        const int rc = dtype == MFVIT_BF16 ? launch_row<bf16, REPI_LNBWD_RES>(p, st) : launch_row<float, REPI_LNBWD_RES>(p, st);
+        const int rc = row_by_dtype<REPI_LNBWD_RES>(dtype, p, st);
         if (rc != MFVIT_OK || !p.cpart) return rc;
         GemmP q = p;
         q.rows_per_wg = balanced_rows(p.M, 64);     // the LN-backward variants all use 64-row tiles (see launch_row)
@@ -720,8 +750,8 @@ int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
     return MFVIT_EINVAL;
 }
 int gemm_tn(int dtype, const GemmP& p, hipStream_t st) {
-    if (gemm_tn_glds_supported(dtype, p)) return gemm_tn_glds(p, st);   // gemm_tn2.hip: LDS-DMA ring (bf16, large M)
-    return dtype == MFVIT_BF16 ? launch_tn<bf16>(p, st) : launch_tn<float>(p, st);
+    if (gemm_tn_glds_supported(dtype, p)) return gemm_tn_glds(dtype, p, st);   // gemm_tn2.hip: LDS-DMA ring (16-bit types, large M)
+    return tn_by_dtype(dtype, p, st);
 }
 
 }  // namespace mfvit

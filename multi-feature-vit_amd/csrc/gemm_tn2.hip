@@ -37,7 +37,7 @@ __device__ __forceinline__ void t2_glds16(const void* gsrc, unsigned lds_off) {
 }
 
 // transposed fragment of the swizzled image: lane holds column (rowbase + lane & 31), elements k = 16 s + 8 (lane >> 5) .. +8
-__device__ __forceinline__ bf16x8 t2_frag(const char* t, int rowbase, int s, int lane) {
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type t2_frag(const char* t, int rowbase, int s, int lane) {
     const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
     const int k0 = 16 * s + 8 * h + q;                       // (k0 & 3) == q, also for k0 + 4
     const int col = rowbase + 16 * g1 + 4 * pp;
@@ -45,19 +45,25 @@ __device__ __forceinline__ bf16x8 t2_frag(const char* t, int rowbase, int s, int
     typedef __attribute__((address_space(3))) s16x4* lptr;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)a);
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 4 * 256));
-    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    union { struct { s16x4 a, b; } s; typename Vec8<T>::type v; } u;
     u.s.a = lo;
     u.s.b = hi;
     return u.v;
 }
 
-template <bool CS>
+// T = bf16 | f16 | sbf16.  Split tensors (sbf16): the tile grid runs over the STORAGE columns; a wave's four accumulators are the
+// hi*hi, hi*lo, lo*hi (lo*lo skipped) blocks of one 32 x 32 logical tile and are summed in the epilogue (see gemm_tn_kernel).
+template <typename T, bool CS>
 __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
+    constexpr bool SPLIT = is_split<T>::value;
+    constexpr int EP = elems_per<T>::value;
+    typedef typename Vec8<T>::type frag_t;
+    typedef typename Vec4<T>::elem E16;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntk = p.K / T2_BK;
-    const int tiles = ntk * (p.N / T2_BN);
+    const int ntk = p.K * EP / T2_BK;
+    const int tiles = ntk * (p.N * EP / T2_BN);
     const int lin = xcd_remap(blockIdx.x, gridDim.x);        // each XCD gets a contiguous run of the split-major block order
     const int split = lin / tiles, tile = lin % tiles;
     const int n0 = (tile / ntk) * T2_BN, k0 = (tile % ntk) * T2_BK;
@@ -67,8 +73,8 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
     const int mend = min(p.M, mbeg + chunk);
     if (mbeg >= mend) return;
     const int nst = (mend - mbeg + T2_KR - 1) / T2_KR;
-    const bf16* A = (const bf16*)p.A;
-    const bf16* X = (const bf16*)p.W;
+    const E16* A = (const E16*)p.A;
+    const E16* X = (const E16*)p.W;
 
     // LDS-DMA g = wave + 4 i (i = 0..3) of an operand fills rows 4 g .. 4 g + 3: lane -> row 4 g + (lane >> 4), chunk position
     // lane & 15, which receives source chunk (lane & 15) ^ (4 * (row & 3)) = (lane & 15) ^ (4 * (lane >> 4))
@@ -102,9 +108,9 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
     }
-    bf16x8 ones;
+    frag_t ones;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (bf16)1.0f;
+    for (int j = 0; j < 8; ++j) ones[j] = (E16)1.0f;
     const bool do_cs = CS && k0 == 0 && wn == 0;             // column sums of A (= bias gradient): k-tile 0, wn 0 waves
 
     // the bias-column-sum MFMAs are selected ONCE per wave (template flag), not per k-step: a branch inside the hot loop splits it
@@ -128,27 +134,27 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
                     *(uint4*)(ta + (valid + (q >> 4)) * 256 + (q & 15) * 16) = make_uint4(0, 0, 0, 0);
                 __syncthreads();
             }
-            bf16x8 a[2][2], b[2][2];
+            frag_t a[2][2], b[2][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[0][i] = t2_frag(ta, (wm * 2 + i) * 32, 0, lane);
+            for (int i = 0; i < 2; ++i) a[0][i] = t2_frag<T>(ta, (wm * 2 + i) * 32, 0, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[0][j] = t2_frag(tb, (wn * 2 + j) * 32, 0, lane);
+            for (int j = 0; j < 2; ++j) b[0][j] = t2_frag<T>(tb, (wn * 2 + j) * 32, 0, lane);
 #pragma unroll
             for (int s = 0; s < T2_KR / 16; ++s) {
                 if (s + 1 < T2_KR / 16) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) a[(s + 1) & 1][i] = t2_frag(ta, (wm * 2 + i) * 32, s + 1, lane);
+                    for (int i = 0; i < 2; ++i) a[(s + 1) & 1][i] = t2_frag<T>(ta, (wm * 2 + i) * 32, s + 1, lane);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) b[(s + 1) & 1][j] = t2_frag(tb, (wn * 2 + j) * 32, s + 1, lane);
+                    for (int j = 0; j < 2; ++j) b[(s + 1) & 1][j] = t2_frag<T>(tb, (wn * 2 + j) * 32, s + 1, lane);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+                        if (!(SPLIT && i == 1 && j == 1)) acc[i][j] = MmaTraits<T>::mma(a[s & 1][i], b[s & 1][j], acc[i][j]);
                 if constexpr (WITH_CS) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s & 1][i], ones, bacc[i], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i) bacc[i] = MmaTraits<T>::mma(a[s & 1][i], ones, bacc[i]);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done before it reaches the next barrier
@@ -157,59 +163,90 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
     };
     if (do_cs) main_loop(std::true_type{});
     else main_loop(std::false_type{});
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[0][0][r] += acc[0][1][r] + acc[1][0][r];
+            bacc[0][r] += bacc[1][r];
+        }
+    }
+    constexpr int NI = SPLIT ? 1 : 2;
+    const int nw = SPLIT ? n0 / 2 + wm * 32 : n0 + wm * 64, kw = SPLIT ? k0 / 2 + wn * 32 : k0 + wn * 64;   // LOGICAL origin of this wave's tile
     float* out = (float*)p.out0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + (wm * 2 + i) * 32 + acc_row(r, lane);
-                const int k = k0 + (wn * 2 + j) * 32 + (lane & 31);
+                const int n = nw + i * 32 + acc_row(r, lane);
+                const int k = kw + j * 32 + (lane & 31);
                 atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
             }
     if (CS) {
         if (do_cs && (lane & 31) == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + n0 + (wm * 2 + i) * 32 + acc_row(r, lane), bacc[i][r]);
+                for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + nw + i * 32 + acc_row(r, lane), bacc[i][r]);
         }
     }
 }
 
 }  // namespace
 
+static int t2_ep(int dtype) { return dtype == MFVIT_BF16X3 ? 2 : 1; }
 bool gemm_tn_glds_supported(int dtype, const GemmP& p) {
     static const int on = [] { const char* e = getenv("MFVIT_TN_GLDS"); return e ? atoi(e) : 1; }();
-    if (!on || dtype != MFVIT_BF16 || p.nb > 1 || p.orow_in || p.cpart) return false;
-    if (p.N % T2_BN || p.K % T2_BK || p.M < 4096) return false;
+    if (!on || (dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || p.nb > 1 || p.orow_in || p.cpart) return false;
+    const int ep = t2_ep(dtype);
+    if (p.N * ep % T2_BN || p.K * ep % T2_BK || p.M < 4096) return false;
     if (p.lda % 8 || p.ldw % 8) return false;
     return true;
 }
 
-int gemm_tn_glds(GemmP p, hipStream_t st) {
-    const int tiles = (p.N / T2_BN) * (p.K / T2_BK);
+template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
+    constexpr int EP = elems_per<T>::value;
+    const int tiles = (p.N * EP / T2_BN) * (p.K * EP / T2_BK);
     if (p.splits <= 0) {
         static const int target = [] { const char* e = getenv("MFVIT_TN2_TARGET"); return e ? atoi(e) : 256; }();
-        int s = target / tiles;                              // one workgroup per CU (96 KB of LDS): tiles x splits <= 256
+        // one workgroup per CU (96 KB of LDS): tiles x splits <= 256 when the tiles allow it; more tiles than CUs (split tensors:
+        // 4 x the storage tiles) run in whole rounds of one split each
+        int s = target / tiles;
         const int maxs = (p.M + 4 * T2_KR - 1) / (4 * T2_KR);
+        if (EP == 2 && 2 * tiles > target) {
+            // more than half a round of tiles: the smallest split count (<= 8) whose grid fills >= 90 % of its rounds of 256 CUs
+            double best = 0.0;
+            for (int c = 1; c <= 8 && c <= maxs; ++c) {
+                const int g = tiles * c, rounds = (g + target - 1) / target;
+                const double eff = (double)g / ((double)rounds * target);
+                if (eff > best + 1e-9) { best = eff; s = c; }
+                if (eff >= 0.9) break;
+            }
+        }
         p.splits = s < 1 ? 1 : (s > maxs ? maxs : s);
     }
     constexpr int bytes = T2_NS * T2_STAGE;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr = true;
     }
     ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * p.N * p.K, 0, st);
     if (p.cs0)
-        MFVIT_LAUNCH(gemm_tn_glds_kernel<true>, dim3(tiles * p.splits), dim3(256), bytes, st, p);
+        MFVIT_LAUNCH((gemm_tn_glds_kernel<T, true>), dim3(tiles * p.splits), dim3(256), bytes, st, p);
     else
-        MFVIT_LAUNCH(gemm_tn_glds_kernel<false>, dim3(tiles * p.splits), dim3(256), bytes, st, p);
+        MFVIT_LAUNCH((gemm_tn_glds_kernel<T, false>), dim3(tiles * p.splits), dim3(256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
+}
+
+int gemm_tn_glds(int dtype, GemmP p, hipStream_t st) {
+    if (dtype == MFVIT_BF16) return launch_t2<bf16>(p, st);
+    if (dtype == MFVIT_BF16X3) return launch_t2<sbf16>(p, st);
+    if (dtype == MFVIT_F16) return launch_t2<f16>(p, st);
+    return MFVIT_EINVAL;
 }
 
 }  // namespace mfvit

@@ -19,7 +19,7 @@ int eval_counts(const float* scores, long ld, const int64_t* labels, int n, int 
                 unsigned long long* npos, int64_t* preds, hipStream_t st);   // metrics.hip
 int gemm_tn(int dtype, const GemmP& p, hipStream_t st);
 bool gemm_tn_glds_supported(int dtype, const GemmP& p);   // gemm_tn2.hip
-int gemm_tn_glds(GemmP p, hipStream_t st);
+int gemm_tn_glds(int dtype, GemmP p, hipStream_t st);
 int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float* d1, float* d2, hipStream_t st);
 
 int attn_fwd_exact(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HD, hipStream_t st);

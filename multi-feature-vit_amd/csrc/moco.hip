@@ -193,7 +193,9 @@ int mfvit_bn_stats(int dtype, const void* x, int n, int C, float* mean, float* m
     if (!x || !mean || !m2 || n <= 0 || C <= 0) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_stats_kernel<bf16>, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16*)x, n, C, mean, m2);
-    else MFVIT_LAUNCH(bn_stats_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)x, n, C, mean, m2);
+    else if (dtype == MFVIT_F16) MFVIT_LAUNCH(bn_stats_kernel<f16>, dim3((C + 255) / 256), dim3(256), 0, st, (const f16*)x, n, C, mean, m2);
+    else if (dtype == MFVIT_F32) MFVIT_LAUNCH(bn_stats_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)x, n, C, mean, m2);
+    else return MFVIT_EINVAL;
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -212,7 +214,9 @@ int mfvit_bn_apply(int dtype, const void* x, const float* mean, const float* inv
     const dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, mean, invstd, gamma, beta, relu, (bf16*)y, total, C);
-    else MFVIT_LAUNCH(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, mean, invstd, gamma, beta, relu, (float*)y, total, C);
+    else if (dtype == MFVIT_F16) MFVIT_LAUNCH(bn_apply_kernel<f16>, grid, dim3(256), 0, st, (const f16*)x, mean, invstd, gamma, beta, relu, (f16*)y, total, C);
+    else if (dtype == MFVIT_F32) MFVIT_LAUNCH(bn_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)x, mean, invstd, gamma, beta, relu, (float*)y, total, C);
+    else return MFVIT_EINVAL;
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -221,7 +225,9 @@ int mfvit_bn_bwd_sums(int dtype, const void* dy, const void* x, const void* y, c
     if (!dy || !x || !mean || !invstd || !s1 || !s2 || (relu && !y)) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_bwd_sums_kernel<bf16>, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, relu, n, C, s1, s2);
-    else MFVIT_LAUNCH(bn_bwd_sums_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, relu, n, C, s1, s2);
+    else if (dtype == MFVIT_F16) MFVIT_LAUNCH(bn_bwd_sums_kernel<f16>, dim3((C + 255) / 256), dim3(256), 0, st, (const f16*)dy, (const f16*)x, (const f16*)y, mean, invstd, relu, n, C, s1, s2);
+    else if (dtype == MFVIT_F32) MFVIT_LAUNCH(bn_bwd_sums_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, relu, n, C, s1, s2);
+    else return MFVIT_EINVAL;
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -232,7 +238,9 @@ int mfvit_bn_bwd_apply(int dtype, const void* dy, const void* x, const void* y, 
     const dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_bwd_apply_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, gamma, relu, S1, S2, inv_count, (bf16*)dx, total, C);
-    else MFVIT_LAUNCH(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, gamma, relu, S1, S2, inv_count, (float*)dx, total, C);
+    else if (dtype == MFVIT_F16) MFVIT_LAUNCH(bn_bwd_apply_kernel<f16>, grid, dim3(256), 0, st, (const f16*)dy, (const f16*)x, (const f16*)y, mean, invstd, gamma, relu, S1, S2, inv_count, (f16*)dx, total, C);
+    else if (dtype == MFVIT_F32) MFVIT_LAUNCH(bn_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, gamma, relu, S1, S2, inv_count, (float*)dx, total, C);
+    else return MFVIT_EINVAL;
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

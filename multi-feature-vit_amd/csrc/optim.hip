@@ -88,6 +88,21 @@ __global__ __launch_bounds__(256) void sgd_kernel(const long* __restrict__ tab, 
     }
 }
 
+// GradScaler.unscale_ (MAIN_MOCO:546-548 -> torch.cuda.amp.GradScaler.step): g *= inv_scale over every chunk of the table and
+// *found_inf = 1 as soon as one gradient element is not finite (one flag store per wave that saw one; the flag is never cleared here).
+__global__ __launch_bounds__(256) void amp_unscale_kernel(const long* __restrict__ tab, float inv_scale, float* __restrict__ found_inf) {
+    const long* e = tab + (long)blockIdx.x * CH;
+    float* g = (float*)e[2];
+    const long n = e[5];
+    bool bad = false;
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float v = g[i];
+        bad |= !(fabsf(v) <= 3.402823466e+38f);     // inf or nan
+        g[i] = v * inv_scale;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.0f;
+}
+
 }  // namespace mfvit
 
 using namespace mfvit;
@@ -113,6 +128,12 @@ int mfvit_adam_step(const int64_t* table, int nchunks, float lr, float beta1, fl
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     MFVIT_LAUNCH(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, lr, beta1, beta2, eps, weight_decay,
                        bc1, bc2s);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int mfvit_amp_unscale(const int64_t* table, int nchunks, float inv_scale, float* found_inf, mfvit_stream_t stream) {
+    if (!table || !found_inf || nchunks <= 0) return MFVIT_EINVAL;
+    MFVIT_LAUNCH(amp_unscale_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, inv_scale, found_inf);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

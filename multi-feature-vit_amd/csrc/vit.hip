@@ -15,13 +15,13 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Dims {
-    int dtype, B, T, np, D, depth, H, HD, F, M, Mp, es;
+    int dtype, B, T, np, D, depth, H, HD, F, M, Mp, es, ep;   // es: bytes per LOGICAL element of a dtype tensor; ep: storage elements per logical one
     bool save;
 };
 
 bool get_dims(const mfvit_vit_cfg* c, Dims& d) {
     if (!c) return false;
-    if (c->dtype != MFVIT_F32 && c->dtype != MFVIT_BF16) return false;
+    if (c->dtype != MFVIT_F32 && c->dtype != MFVIT_BF16 && c->dtype != MFVIT_BF16X3 && c->dtype != MFVIT_F16) return false;
     if (c->batch <= 0 || c->img_h <= 0 || c->img_w <= 0 || c->img_h % 16 || c->img_w % 16) return false;
     if (c->dim != 384 || c->depth <= 0 || c->heads <= 0 || c->dim % c->heads) return false;
     if (c->mlp_dim % 128 || c->mlp_dim <= 0) return false;
@@ -36,9 +36,11 @@ bool get_dims(const mfvit_vit_cfg* c, Dims& d) {
     d.F = c->mlp_dim;
     d.M = d.B * d.T;
     d.Mp = d.B * d.np;
-    d.es = c->dtype == MFVIT_BF16 ? 2 : 4;
+    d.es = (c->dtype == MFVIT_BF16 || c->dtype == MFVIT_F16) ? 2 : 4;   // split bf16: hi + lo = 4 bytes
+    d.ep = c->dtype == MFVIT_BF16X3 ? 2 : 1;
     d.save = c->save_for_backward != 0;
     if (d.HD != 32 && d.HD != 64) return false;
+    if (c->dtype == MFVIT_BF16X3 && d.HD != 32) return false;   // a head's row piece is one [hi x 32 | lo x 32] group
     return true;
 }
 
@@ -88,7 +90,7 @@ struct ShadowLayout {
 ShadowLayout shadow_layout(const Dims& d) {
     ShadowLayout S;
     const size_t D = d.D, F = d.F, es = d.es;
-    const bool hw = d.dtype == MFVIT_BF16;  // keep straight copies only when a cast is needed
+    const bool hw = d.dtype != MFVIT_F32;  // keep straight copies only when a cast is needed
     size_t o = 0;
     S.pe_w = o; o += hw ? align256(D * 768 * es) : 0;
     S.blk0 = o;
@@ -221,12 +223,12 @@ SideStream& side_stream(hipStream_t caller) {
 
 extern "C" {
 
-int mfvit_abi_version(void) { return 1; }
+int mfvit_abi_version(void) { return 2; }
 int mfvit_set_wgrad_stream(int enabled) {
     g_wgrad_stream.store(enabled ? 1 : 0, std::memory_order_relaxed);
     return MFVIT_OK;
 }
-const char* mfvit_build_info(void) { return "libmfvit_hip gfx950 (MFMA bf16 32x32x16 / f32 32x32x2), wave64"; }
+const char* mfvit_build_info(void) { return "libmfvit_hip gfx950 (MFMA bf16 | split-bf16 x3 | f16 32x32x16, f32 32x32x2), wave64, abi 2"; }
 
 size_t mfvit_vit_param_count(const mfvit_vit_cfg* cfg) {
     Dims d;
@@ -259,7 +261,7 @@ int mfvit_vit_prepare_shadow(const mfvit_vit_cfg* cfg, const float* params, void
     const ParamLayout L = param_layout(d);
     const ShadowLayout S = shadow_layout(d);
     char* sh = (char*)shadow;
-    const bool hw = d.dtype == MFVIT_BF16;
+    const bool hw = d.dtype != MFVIT_F32;
     if (hw) MFVIT_TRY(cast_transpose(d.dtype, params + L.pe_w, sh + S.pe_w, nullptr, d.D, 768, st));
     // one launch per weight type covers all `depth` blocks (identical shapes at fixed arena / shadow strides)
     const float* pb = params + L.blk0;
@@ -282,8 +284,9 @@ int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void*
     const WsLayout W = ws_layout(d);
     char* ws = (char*)workspace;
     const char* sh = (const char*)shadow;
-    const bool hw = d.dtype == MFVIT_BF16;
+    const bool hw = d.dtype != MFVIT_F32;
     const long D = d.D, F = d.F;
+    const long e = d.ep;   // leading dimensions of dtype tensors are in storage elements
     const float eps = cfg->ln_eps;
     auto xbuf = [&](int l) { return (float*)(ws + W.x0 + (d.save ? (size_t)l : 0) * W.x_stride); };
     auto stat = [&](int l) { return (float*)(ws + W.st0 + (d.save ? (size_t)l : 0) * W.st_stride); };
@@ -295,20 +298,20 @@ int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void*
     MFVIT_TRY(im2col16(d.dtype, img, ws + W.patches, d.B, cfg->img_h, cfg->img_w, st));
     {
         GemmP p = zero_gemm();
-        p.A = ws + W.patches; p.lda = 768;
-        p.W = hw ? (const void*)(sh + S.pe_w) : (const void*)(params + L.pe_w); p.ldw = 768;
+        p.A = ws + W.patches; p.lda = 768 * e;
+        p.W = hw ? (const void*)(sh + S.pe_w) : (const void*)(params + L.pe_w); p.ldw = 768 * e;
         p.M = d.Mp; p.N = d.D; p.K = 768;
         p.bias = params + L.pe_b;
         p.res = params + L.pos; p.ldres = D; p.res_mod = d.np; p.res_off = 1;
         p.orow_in = d.np; p.orow_out = d.T; p.orow_off = 1;
         p.out0 = xbuf(0); p.ldo0 = D;
-        p.out1 = blk(0) + W.y1; p.ldo1 = D;
+        p.out1 = blk(0) + W.y1; p.ldo1 = D * e;
         p.gamma = pblk(0) + L.ln1_w; p.beta = pblk(0) + L.ln1_b; p.eps = eps;
         p.mean = stat(0); p.rstd = stat(0) + d.M;
         MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
     }
     // cls rows: x_0[b,0] = cls_token + pos_embed[0]; LN1_0
-    MFVIT_TRY(ln_rows(d.dtype, d.D, params + L.cls, 0, params + L.pos, D, 1, xbuf(0), D, blk(0) + W.y1, D, 0, pblk(0) + L.ln1_w,
+    MFVIT_TRY(ln_rows(d.dtype, d.D, params + L.cls, 0, params + L.pos, D, 1, xbuf(0), D, blk(0) + W.y1, D * e, 0, pblk(0) + L.ln1_w,
                       pblk(0) + L.ln1_b, eps, stat(0), stat(0) + d.M, d.B, d.T, 0, 1, st));
 
     for (int l = 0; l < d.depth; ++l) {
@@ -317,42 +320,42 @@ int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void*
         const char* sb = sblk(l);
         {   // qkv = y1 Wqkv^T + b
             GemmP p = zero_gemm();
-            p.A = b + W.y1; p.lda = D;
-            p.W = hw ? (const void*)(sb + S.qkv_w) : (const void*)(pb + L.qkv_w); p.ldw = D;
+            p.A = b + W.y1; p.lda = D * e;
+            p.W = hw ? (const void*)(sb + S.qkv_w) : (const void*)(pb + L.qkv_w); p.ldw = D * e;
             p.M = d.M; p.N = 3 * d.D; p.K = d.D;
             p.bias = pb + L.qkv_b;
-            p.out0 = b + W.qkv; p.ldo0 = 3 * D;
+            p.out0 = b + W.qkv; p.ldo0 = 3 * D * e;
             MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS, p, st));
         }
         MFVIT_TRY(attn_fwd(d.dtype, b + W.qkv, b + W.attn, (float*)(b + W.lse), d.B, d.T, d.H, d.HD, st));
         {   // xmid = x + attn Wproj^T + b ; y2 = LN2(xmid)
             GemmP p = zero_gemm();
-            p.A = b + W.attn; p.lda = D;
-            p.W = hw ? (const void*)(sb + S.proj_w) : (const void*)(pb + L.proj_w); p.ldw = D;
+            p.A = b + W.attn; p.lda = D * e;
+            p.W = hw ? (const void*)(sb + S.proj_w) : (const void*)(pb + L.proj_w); p.ldw = D * e;
             p.M = d.M; p.N = d.D; p.K = d.D;
             p.bias = pb + L.proj_b;
             p.res = xbuf(l); p.ldres = D;
             p.out0 = b + W.xmid; p.ldo0 = D;
-            p.out1 = b + W.y2; p.ldo1 = D;
+            p.out1 = b + W.y2; p.ldo1 = D * e;
             p.gamma = pb + L.ln2_w; p.beta = pb + L.ln2_b; p.eps = eps;
             p.mean = (float*)(b + W.st2); p.rstd = (float*)(b + W.st2) + d.M;
             MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
         }
         {   // hpre = y2 W1^T + b1 ; hact = gelu(hpre)
             GemmP p = zero_gemm();
-            p.A = b + W.y2; p.lda = D;
-            p.W = hw ? (const void*)(sb + S.fc1_w) : (const void*)(pb + L.fc1_w); p.ldw = D;
+            p.A = b + W.y2; p.lda = D * e;
+            p.W = hw ? (const void*)(sb + S.fc1_w) : (const void*)(pb + L.fc1_w); p.ldw = D * e;
             p.M = d.M; p.N = d.F; p.K = d.D;
             p.bias = pb + L.fc1_b;
-            p.out0 = b + W.hpre; p.ldo0 = F;
-            p.out1 = b + W.hact; p.ldo1 = F;
+            p.out0 = b + W.hpre; p.ldo0 = F * e;
+            p.out1 = b + W.hact; p.ldo1 = F * e;
             MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS_GELU, p, st));
         }
         {   // x_{l+1} = xmid + hact W2^T + b2 ; y = LN(next norm1 | final norm)
             const bool last = l + 1 == d.depth;
             GemmP p = zero_gemm();
-            p.A = b + W.hact; p.lda = F;
-            p.W = hw ? (const void*)(sb + S.fc2_w) : (const void*)(pb + L.fc2_w); p.ldw = F;
+            p.A = b + W.hact; p.lda = F * e;
+            p.W = hw ? (const void*)(sb + S.fc2_w) : (const void*)(pb + L.fc2_w); p.ldw = F * e;
             p.M = d.M; p.N = d.D; p.K = d.F;
             p.bias = pb + L.fc2_b;
             p.res = (const float*)(b + W.xmid); p.ldres = D;
@@ -361,7 +364,7 @@ int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void*
                 p.out1 = features; p.ldo1 = D; p.y_f32 = 1;
                 p.gamma = params + L.norm_w; p.beta = params + L.norm_b;
             } else {
-                p.out1 = blk(l + 1) + W.y1; p.ldo1 = D;
+                p.out1 = blk(l + 1) + W.y1; p.ldo1 = D * e;
                 p.gamma = pblk(l + 1) + L.ln1_w; p.beta = pblk(l + 1) + L.ln1_b;
             }
             p.eps = eps;
@@ -385,6 +388,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
     char* ws = (char*)workspace;
     const char* sh = (const char*)shadow;
     const long D = d.D, F = d.F;
+    const long e = d.ep;   // leading dimensions of dtype tensors are in storage elements
     auto xbuf = [&](int l) { return (float*)(ws + W.x0 + (size_t)l * W.x_stride); };
     auto stat = [&](int l) { return (float*)(ws + W.st0 + (size_t)l * W.st_stride); };
     auto blk = [&](int l) { return ws + W.blk0 + (size_t)l * W.blk_stride; };
@@ -421,7 +425,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
             // final LayerNorm backward: dfeatures -> gx (grad of x_depth); dcol = d fc2_b of the last block
             if (!dfeatures) return MFVIT_EINVAL;
             MFVIT_TRY(ln_bwd_rows(d.dtype, d.D, dfeatures, D, xbuf(d.depth), D, stat(d.depth), stat(d.depth) + d.M, params + L.norm_w,
-                                  nullptr, 0, gx, D, pp(W.gxT, d.depth - 1), D, dparams + L.norm_w, dparams + L.norm_b,
+                                  nullptr, 0, gx, D, pp(W.gxT, d.depth - 1), D * e, dparams + L.norm_w, dparams + L.norm_b,
                                   gblk(d.depth - 1) + L.fc2_b, colpart, d.M, 1, 0, st));
         } else if (s >= 0) {
             const int l = s;
@@ -437,7 +441,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
             MFVIT_TRY(fork());                                    // gxT(l) is ready on the main stream
             {   // dW2 += gx^T hact
                 GemmP p = zero_gemm();
-                p.A = gxT; p.lda = D; p.W = b + W.hact; p.ldw = F;
+                p.A = gxT; p.lda = D * e; p.W = b + W.hact; p.ldw = F * e;
                 p.M = d.M; p.N = d.D; p.K = d.F;
                 p.out0 = gb + L.fc2_w; p.ldo0 = F;
                 p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
@@ -445,16 +449,16 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
             }
             {   // dhpre = (gx W2) * gelu'(hpre)
                 GemmP p = zero_gemm();
-                p.A = gxT; p.lda = D; p.W = sb + S.fc2_t; p.ldw = D;
+                p.A = gxT; p.lda = D * e; p.W = sb + S.fc2_t; p.ldw = D * e;
                 p.M = d.M; p.N = d.F; p.K = d.D;
-                p.aux = b + W.hpre; p.ldaux = F;
-                p.out0 = dhpre; p.ldo0 = F;
+                p.aux = b + W.hpre; p.ldaux = F * e;
+                p.out0 = dhpre; p.ldo0 = F * e;
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_GELU_BWD, p, st));
             }
             MFVIT_TRY(fork());
             {   // dW1 += dhpre^T y2
                 GemmP p = zero_gemm();
-                p.A = dhpre; p.lda = F; p.W = b + W.y2; p.ldw = D;
+                p.A = dhpre; p.lda = F * e; p.W = b + W.y2; p.ldw = D * e;
                 p.M = d.M; p.N = d.F; p.K = d.D;
                 p.cs0 = gb + L.fc1_b;                             // d fc1_b += column sums of dhpre (ones-fragment MFMA in the wgrad kernel)
                 p.out0 = gb + L.fc1_w; p.ldo0 = D;
@@ -463,20 +467,20 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
             }
             {   // gmid = LN2bwd(dhpre W1) + gx ; d ln2_w, d ln2_b, d proj_b
                 GemmP p = zero_gemm();
-                p.A = dhpre; p.lda = F; p.W = sb + S.fc1_t; p.ldw = F;
+                p.A = dhpre; p.lda = F * e; p.W = sb + S.fc1_t; p.ldw = F * e;
                 p.M = d.M; p.N = d.D; p.K = d.F;
                 p.aux = b + W.xmid; p.ldaux = D;
                 p.mean = (float*)(b + W.st2); p.rstd = (float*)(b + W.st2) + d.M;
                 p.gamma = pb + L.ln2_w;
                 p.res = gx; p.ldres = D;
-                p.out0 = gmid; p.ldo0 = D; p.out1 = gmidT; p.ldo1 = D;
+                p.out0 = gmid; p.ldo0 = D; p.out1 = gmidT; p.ldo1 = D * e;
                 p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = gb + L.proj_b; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
             MFVIT_TRY(fork());
             {   // dWproj += gmid^T attn
                 GemmP p = zero_gemm();
-                p.A = gmidT; p.lda = D; p.W = b + W.attn; p.ldw = D;
+                p.A = gmidT; p.lda = D * e; p.W = b + W.attn; p.ldw = D * e;
                 p.M = d.M; p.N = d.D; p.K = d.D;
                 p.out0 = gb + L.proj_w; p.ldo0 = D;
                 p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
@@ -484,9 +488,9 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
             }
             {   // dattn = gmid Wproj
                 GemmP p = zero_gemm();
-                p.A = gmidT; p.lda = D; p.W = sb + S.proj_t; p.ldw = D;
+                p.A = gmidT; p.lda = D * e; p.W = sb + S.proj_t; p.ldw = D * e;
                 p.M = d.M; p.N = d.D; p.K = d.D;
-                p.out0 = ws + W.dattn; p.ldo0 = D;
+                p.out0 = ws + W.dattn; p.ldo0 = D * e;
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, p, st));
             }
             MFVIT_TRY(attn_bwd(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, nullptr,
@@ -494,7 +498,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
             MFVIT_TRY(fork());
             {   // dWqkv += dqkv^T y1 ; d qkv_b += column sums of dqkv (ones-fragment MFMA inside the wgrad kernel)
                 GemmP p = zero_gemm();
-                p.A = dqkv; p.lda = 3 * D; p.W = b + W.y1; p.ldw = D;
+                p.A = dqkv; p.lda = 3 * D * e; p.W = b + W.y1; p.ldw = D * e;
                 p.M = d.M; p.N = 3 * d.D; p.K = d.D;
                 p.cs0 = gb + L.qkv_b;
                 p.out0 = gb + L.qkv_w; p.ldo0 = D;
@@ -506,13 +510,13 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
             {   // gx = LN1bwd(dqkv Wqkv) + gmid ; d ln1_w, d ln1_b, d fc2_b of block l-1 (or scratch for the embed stage)
                 if (l == 0 && hipMemsetAsync(colscr, 0, 2 * D * sizeof(float), st) != hipSuccess) return MFVIT_ELAUNCH;
                 GemmP p = zero_gemm();
-                p.A = dqkv; p.lda = 3 * D; p.W = sb + S.qkv_t; p.ldw = 3 * D;
+                p.A = dqkv; p.lda = 3 * D * e; p.W = sb + S.qkv_t; p.ldw = 3 * D * e;
                 p.M = d.M; p.N = d.D; p.K = 3 * d.D;
                 p.aux = xbuf(l); p.ldaux = D;
                 p.mean = stat(l); p.rstd = stat(l) + d.M;
                 p.gamma = pb + L.ln1_w;
                 p.res = gmid; p.ldres = D;
-                p.out0 = gx; p.ldo0 = D; p.out1 = pp(W.gxT, l - 1); p.ldo1 = D;
+                p.out0 = gx; p.ldo0 = D; p.out1 = pp(W.gxT, l - 1); p.ldo1 = D * e;
                 p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = l > 0 ? gblk(l - 1) + L.fc2_b : colscr; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
@@ -526,7 +530,7 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 MFVIT_TRY(axpy(dparams + L.pe_b, colscr, 1.0f, d.D, st));
                 MFVIT_TRY(axpy(dparams + L.pe_b, colscr + D, -1.0f, d.D, st));
                 GemmP p = zero_gemm();   // d pe_w += gx[patch rows]^T patches
-                p.A = pp(W.gxT, -1); p.lda = D; p.W = ws + W.patches; p.ldw = 768;
+                p.A = pp(W.gxT, -1); p.lda = D * e; p.W = ws + W.patches; p.ldw = 768 * e;
                 p.M = d.Mp; p.N = d.D; p.K = 768;
                 p.orow_in = d.np; p.orow_out = d.T; p.orow_off = 1;
                 p.out0 = dparams + L.pe_w; p.ldo0 = 768;
@@ -608,7 +612,7 @@ int mfvit_linear_res_ln_fwd(int dtype, const void* a, int64_t lda, const void* w
     GemmP p = zero_gemm();
     p.A = a; p.lda = lda; p.W = w; p.ldw = ldw; p.M = M; p.N = 384; p.K = K;
     p.bias = bias; p.res = res; p.ldres = ldres;
-    p.out0 = x_out; p.ldo0 = 384; p.out1 = y; p.ldo1 = 384; p.y_f32 = y_f32;
+    p.out0 = x_out; p.ldo0 = 384; p.out1 = y; p.ldo1 = (dtype == MFVIT_BF16X3 && !y_f32) ? 768 : 384; p.y_f32 = y_f32;
     p.gamma = gamma; p.beta = beta; p.eps = eps; p.mean = mean; p.rstd = rstd;
     return gemm_nt_row(dtype, REPI_RES_LN, p, (hipStream_t)stream);
 }
@@ -620,7 +624,7 @@ int mfvit_linear_dgrad_ln_bwd(int dtype, const void* dy, int64_t lddy, const voi
     p.A = dy; p.lda = lddy; p.W = wt; p.ldw = ldwt; p.M = M; p.N = 384; p.K = K;
     p.aux = x; p.ldaux = 384; p.mean = (float*)mean; p.rstd = (float*)rstd; p.gamma = gamma;
     p.res = dres; p.ldres = 384;
-    p.out0 = dx; p.ldo0 = 384; p.out1 = dx_t; p.ldo1 = 384;
+    p.out0 = dx; p.ldo0 = 384; p.out1 = dx_t; p.ldo1 = dtype == MFVIT_BF16X3 ? 768 : 384;
     p.cs0 = dgamma; p.cs1 = dbeta; p.cs2 = dcol;
     return gemm_nt_row(dtype, REPI_LNBWD_RES, p, (hipStream_t)stream);
 }
@@ -636,13 +640,14 @@ int mfvit_attention_bwd(int dtype, const void* qkv, const void* out, const void*
 int mfvit_layernorm_fwd(int dtype, const float* x, void* y, int y_f32, const float* gamma, const float* beta, float eps, float* mean,
                         float* rstd, int rows, int N, mfvit_stream_t stream) {
     if (!x || !y || !gamma || !beta) return MFVIT_EINVAL;
-    return ln_rows(dtype, N, x, N, nullptr, 0, 0, nullptr, 0, y, N, y_f32, gamma, beta, eps, mean, rstd, rows, 1, 0, 0, (hipStream_t)stream);
+    return ln_rows(dtype, N, x, N, nullptr, 0, 0, nullptr, 0, y, (dtype == MFVIT_BF16X3 && !y_f32) ? 2 * N : N, y_f32, gamma, beta, eps, mean, rstd, rows, 1, 0,
+                   0, (hipStream_t)stream);
 }
 int mfvit_layernorm_bwd(int dtype, const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* dres, float* dx, void* dx_t, float* dgamma, float* dbeta, float* dcol, int rows, int N,
                         mfvit_stream_t stream) {
     if (!dy || !x || !mean || !rstd || !gamma) return MFVIT_EINVAL;
-    return ln_bwd_rows(dtype, N, dy, N, x, N, mean, rstd, gamma, dres, N, dx, N, dx_t, N, dgamma, dbeta, dcol, nullptr, rows, 1, 0,
+    return ln_bwd_rows(dtype, N, dy, N, x, N, mean, rstd, gamma, dres, N, dx, N, dx_t, dtype == MFVIT_BF16X3 ? 2 * N : N, dgamma, dbeta, dcol, nullptr, rows, 1, 0,
                        (hipStream_t)stream);
 }
 int mfvit_cast_transpose(int dtype, const float* src, void* dst, void* dst_t, int R, int C, mfvit_stream_t stream) {

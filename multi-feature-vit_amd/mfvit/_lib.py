@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MFVIT_LIB") or os.path.join(_HERE, "libmfvit_hip.so")   # MFVIT_LIB: experiment builds
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3, F16 = 0, 1, 2, 3
 EPI_BIAS, EPI_BIAS_GELU, EPI_NONE = 0, 1, 3
 
 
@@ -76,6 +76,7 @@ SIGNATURES = {
     "mfvit_lars_step": (I, [P, I, I, P, F, F, F, F, P]),
     "mfvit_adam_step": (I, [P, I, F, F, F, F, F, I, P]),
     "mfvit_sgd_step": (I, [P, I, F, F, F, I, P]),
+    "mfvit_amp_unscale": (I, [P, I, F, P, P]),
     "mfvit_prenorm_xattn_forward": (I, [POINTER(FusionCfg), P, P, P, P, P, P]),
     "mfvit_prenorm_xattn_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P]),
     "mfvit_input_transform": (I, [P, P, P, I, I, I, P, P, P, P]),
@@ -136,9 +137,18 @@ def require_cuda(*tensors):
             raise MfvitError("MF-ViT HIP ops need tensors on a ROCm GPU ('cuda' device); there is no CPU fallback")
 
 
+PRECISIONS = ("bf16x3", "bf16", "fp16", "fp32")
+
+
 def dtype_code(precision):
+    """'bf16x3' = split bf16 (three bf16 MFMAs per product: f32-grade results, meets the 1e-3 logits gate); 'bf16' = throughput mode;
+    'fp16' = the reference's autocast arithmetic (pair with mfvit.amp.GradScaler); 'fp32' = exact f32 MFMA."""
+    if precision in ("bf16x3", "split", "split-bf16"):
+        return BF16X3
     if precision in ("bf16", "bfloat16"):
         return BF16
+    if precision in ("fp16", "f16", "float16", "half"):
+        return F16
     if precision in ("fp32", "f32", "float32"):
         return F32
-    raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+    raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")

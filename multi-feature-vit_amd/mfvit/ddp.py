@@ -20,11 +20,13 @@ class GradSync:
         self.avg = self.enabled and dist.get_backend(group) == "nccl"
 
     def _all_reduce(self, t, async_op):
+        """Mean over ranks, in place.  ONE call shape for every backend: RCCL reduces with AVG in a single pass; gloo (CPU tests,
+        one-GPU rehearsals) has no AVG, so the tensor is pre-scaled by 1/world and summed - the asynchronous handles issued from the
+        backward hooks are the same objects either way."""
         if self.avg:
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
-        h = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
         t.div_(self.world)
-        return h
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     # ---- encoder: called from VisionTransformerMoCo._run_backward after every stage
     def attach(self, vit, bucket_layers=None):

@@ -21,7 +21,10 @@ from ._lib import VitCfg, check, lib, ptr, stream
 
 
 def default_precision():
-    return os.environ.get("MFVIT_PRECISION", "bf16")
+    """'bf16x3' (split bf16: f32-grade results on the bf16 matrix core) unless MFVIT_PRECISION says otherwise: the reference's
+    finetune paths are fp32 (no autocast in MAIN_CA / MAIN_SS), so the default must meet the 1e-3 logits gate.  'bf16' is the
+    throughput mode, 'fp16' the reference's autocast pretraining arithmetic (MAIN_MOCO:349), 'fp32' exact f32 MFMA."""
+    return os.environ.get("MFVIT_PRECISION", "bf16x3")
 
 
 def build_2d_sincos_position_embedding(gh, gw, dim, temperature=10000.0):

@@ -5,11 +5,14 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import _lib, ops
-from ._lib import BF16, F32, check, lib, ptr, stream
+from ._lib import BF16, BF16X3, F16, F32, check, lib, ptr, stream
 
 
 def _tdtype(precision):
-    return torch.bfloat16 if _lib.dtype_code(precision) == BF16 else torch.float32
+    """Compute dtype of the projector / predictor MLPs.  'bf16x3' (f32-grade split products in the encoder) runs these small GEMMs
+    (n rows x 4096) on the exact-f32 MFMA kernels: the same accuracy class, and their cost is negligible beside the encoder."""
+    code = _lib.dtype_code(precision)
+    return {BF16: torch.bfloat16, F16: torch.float16, BF16X3: torch.float32, F32: torch.float32}[code]
 
 
 class _LinearFn(torch.autograd.Function):
@@ -68,7 +71,7 @@ class _BNFn(torch.autograd.Function):
         _lib.require_cuda(x)
         x = x.contiguous()
         n, C = x.shape
-        code = BF16 if x.dtype == torch.bfloat16 else F32
+        code = ops._code_of(x)
         dev = x.device
         mean = torch.empty(C, device=dev, dtype=torch.float32)
         invstd = torch.empty_like(mean)
@@ -78,8 +81,9 @@ class _BNFn(torch.autograd.Function):
             check(lib().mfvit_bn_stats(code, ptr(x), n, C, ptr(st), st.data_ptr() + 4 * C, stream()), "mfvit_bn_stats")
             st[2 * C] = float(n)
             if W > 1:
-                allst = torch.empty(W, 2 * C + 1, device=dev, dtype=torch.float32)
-                dist.all_gather_into_tensor(allst, st)
+                flat = torch.empty(W * (2 * C + 1), device=dev, dtype=torch.float32)    # concatenated form: every backend takes it
+                dist.all_gather_into_tensor(flat, st)
+                allst = flat.view(W, 2 * C + 1)
                 means = allst[:, :C].contiguous()
                 m2s = allst[:, C:2 * C].contiguous()
                 counts = allst[:, 2 * C].contiguous()

@@ -6,29 +6,54 @@ launches on torch's current HIP stream and returns freshly allocated tensors own
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_BIAS, EPI_BIAS_GELU, EPI_NONE, F32, check, lib, ptr, require_cuda, stream
+from ._lib import BF16, BF16X3, EPI_BIAS, EPI_BIAS_GELU, EPI_NONE, F16, F32, check, lib, ptr, require_cuda, stream
+
+_TORCH_OF = {BF16: torch.bfloat16, BF16X3: torch.bfloat16, F16: torch.float16, F32: torch.float32}
 
 
 def _tdtype(code):
-    return torch.bfloat16 if code == BF16 else torch.float32
+    return _TORCH_OF[code]
 
 
-def _code_of(t):
+def _code_of(t, split=False):
+    """dtype code of a tensor.  split=True: a bf16 tensor holding the I32 split layout (include/mfvit.h, MFVIT_BF16X3)."""
     if t.dtype == torch.bfloat16:
-        return BF16
-    if t.dtype == torch.float32:
+        return BF16X3 if split else BF16
+    if t.dtype == torch.float16 and not split:
+        return F16
+    if t.dtype == torch.float32 and not split:
         return F32
-    raise _lib.MfvitError(f"unsupported dtype {t.dtype}")
+    raise _lib.MfvitError(f"unsupported dtype {t.dtype}{' for a split tensor' if split else ''}")
 
 
-def linear_fwd(x, w, bias=None, gelu=False, persistent=False):
+def split_pack(x):
+    """f32 [..., N] (N % 32 == 0) -> split-bf16 storage [..., 2N]: every group of 32 columns as [hi x 32 | lo x 32] with
+    hi = bf16(x), lo = bf16(x - hi)   (torch restatement of the layout the kernels write; used by tests and tools)."""
+    x = x.float()
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    *lead, N = x.shape
+    g = torch.stack([hi.reshape(*lead, N // 32, 32), lo.reshape(*lead, N // 32, 32)], dim=-2)
+    return g.reshape(*lead, 2 * N).contiguous()
+
+
+def split_unpack(s):
+    """split-bf16 storage [..., 2N] -> f32 [..., N] (hi + lo)."""
+    *lead, N2 = s.shape
+    g = s.reshape(*lead, N2 // 64, 2, 32).float()
+    return (g[..., 0, :] + g[..., 1, :]).reshape(*lead, N2 // 2)
+
+
+def linear_fwd(x, w, bias=None, gelu=False, persistent=False, split=False):
     """y = x @ w.T + bias (x [M,K], w [N,K] of the same dtype).  gelu=True returns (gelu'(y), gelu(y)).
-    persistent=True runs the experimental persistent 256x128 kernel (bf16 only)."""
+    persistent=True runs the experimental persistent 256x128 kernel (bf16 only).  split=True: x, w and the results are split-bf16
+    storage ([M,2K], [N,2K] -> [M,2N])."""
     require_cuda(x, w, bias)
-    code = _code_of(x)
-    M, K = x.shape
+    code = _code_of(x, split)
+    e = 2 if split else 1
+    M, K = x.shape[0], x.shape[1] // e
     N = w.shape[0]
-    y = torch.empty(M, N, device=x.device, dtype=x.dtype)
+    y = torch.empty(M, N * e, device=x.device, dtype=x.dtype)
     y2 = torch.empty_like(y) if gelu else None
     epi = EPI_BIAS_GELU if gelu else (EPI_BIAS if bias is not None else EPI_NONE)
     if persistent == "ws":
@@ -39,7 +64,7 @@ def linear_fwd(x, w, bias=None, gelu=False, persistent=False):
         check(lib().mfvit_linear_fwd_persistent(epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N, ptr(y2), N, M, N, K,
                                                 stream()), "mfvit_linear_fwd_persistent")
         return (y, y2) if gelu else y
-    check(lib().mfvit_linear_fwd(code, epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N, ptr(y2), N, M, N, K,
+    check(lib().mfvit_linear_fwd(code, epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N * e, ptr(y2), N * e, M, N, K,
                                  stream()), "mfvit_linear_fwd")
     return (y, y2) if gelu else y
 
@@ -47,13 +72,14 @@ def linear_fwd(x, w, bias=None, gelu=False, persistent=False):
 WGRAD_SCRATCH_FLOATS = 384 * 128 * 128   # include/mfvit.h: MFVIT_WGRAD_SCRATCH_FLOATS
 
 
-def linear_wgrad(dy, x, out=None, scratch=None):
+def linear_wgrad(dy, x, out=None, scratch=None, split=False):
     """dW [N,K] (f32) += dy[M,N].T @ x[M,K].  scratch: optional f32 tensor of WGRAD_SCRATCH_FLOATS elements (split partials
-    as plain stores + a reduce pass instead of float atomics)."""
+    as plain stores + a reduce pass instead of float atomics).  split=True: dy, x are split-bf16 storage."""
     require_cuda(dy, x)
-    code = _code_of(dy)
-    M, N = dy.shape
-    K = x.shape[1]
+    code = _code_of(dy, split)
+    e = 2 if split else 1
+    M, N = dy.shape[0], dy.shape[1] // e
+    K = x.shape[1] // e
     if out is None:
         out = torch.zeros(N, K, device=dy.device, dtype=torch.float32)
     if scratch is not None:
@@ -67,13 +93,14 @@ def linear_wgrad(dy, x, out=None, scratch=None):
     return out
 
 
-def linear_res_ln_fwd(a, w, bias, res, gamma, beta, eps, y_f32=False):
+def linear_res_ln_fwd(a, w, bias, res, gamma, beta, eps, y_f32=False, split=False):
     """x_out = a @ w.T + bias + res ; y = LayerNorm(x_out).  Returns (x_out f32, y, mean, rstd)."""
     require_cuda(a, w, res)
-    code = _code_of(a)
-    M, K = a.shape
+    code = _code_of(a, split)
+    e = 2 if split else 1
+    M, K = a.shape[0], a.shape[1] // e
     x_out = torch.empty(M, 384, device=a.device, dtype=torch.float32)
-    y = torch.empty(M, 384, device=a.device, dtype=torch.float32 if y_f32 else a.dtype)
+    y = torch.empty(M, 384 if y_f32 else 384 * e, device=a.device, dtype=torch.float32 if y_f32 else a.dtype)
     mean = torch.empty(M, device=a.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     check(lib().mfvit_linear_res_ln_fwd(code, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(res),
@@ -82,14 +109,15 @@ def linear_res_ln_fwd(a, w, bias, res, gamma, beta, eps, y_f32=False):
     return x_out, y, mean, rstd
 
 
-def linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, gamma, dres, want_copy=True):
+def linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, gamma, dres, want_copy=True, split=False):
     """dx = LNbwd(dy @ wt.T ; x, mean, rstd, gamma) + dres.  wt is the TRANSPOSED weight [384, K].
     Returns (dx f32, dx copy in dy.dtype, dgamma, dbeta, dcol)."""
     require_cuda(dy, wt, x)
-    code = _code_of(dy)
-    M, K = dy.shape
+    code = _code_of(dy, split)
+    e = 2 if split else 1
+    M, K = dy.shape[0], dy.shape[1] // e
     dx = torch.empty(M, 384, device=dy.device, dtype=torch.float32)
-    dx_t = torch.empty(M, 384, device=dy.device, dtype=dy.dtype) if want_copy else None
+    dx_t = torch.empty(M, 384 * e, device=dy.device, dtype=dy.dtype) if want_copy else None
     dgamma = torch.zeros(384, device=dy.device, dtype=torch.float32)
     dbeta = torch.zeros_like(dgamma)
     dcol = torch.zeros_like(dgamma)
@@ -99,62 +127,71 @@ def linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, gamma, dres, want_copy=True):
     return dx, dx_t, dgamma, dbeta, dcol
 
 
-def attention_fwd(qkv, heads):
-    """qkv [B,T,3*D] (layout [B][T][3][H][d]) -> (out [B,T,D], lse [B,H,T])."""
+def attention_fwd(qkv, heads, split=False):
+    """qkv [B,T,3*D] (layout [B][T][3][H][d]) -> (out [B,T,D], lse [B,H,T]).  split=True: split-bf16 storage ([B,T,6*D] -> [B,T,2*D])."""
     require_cuda(qkv)
-    code = _code_of(qkv)
+    code = _code_of(qkv, split)
+    e = 2 if split else 1
     B, T, D3 = qkv.shape
-    D = D3 // 3
-    out = torch.empty(B, T, D, device=qkv.device, dtype=qkv.dtype)
+    D = D3 // (3 * e)
+    out = torch.empty(B, T, D * e, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
     check(lib().mfvit_attention_fwd(code, ptr(qkv), ptr(out), ptr(lse), B, T, heads, D // heads, stream()), "mfvit_attention_fwd")
     return out, lse
 
 
-def attention_bwd(qkv, out, dout, lse, heads, want_dbias=True):
+def attention_bwd(qkv, out, dout, lse, heads, want_dbias=True, split=False):
     require_cuda(qkv, out, dout, lse)
-    code = _code_of(qkv)
+    code = _code_of(qkv, split)
+    e = 2 if split else 1
     B, T, D3 = qkv.shape
-    D = D3 // 3
+    D = D3 // (3 * e)
     dqkv = torch.empty_like(qkv)
-    dbias = torch.zeros(D3, device=qkv.device, dtype=torch.float32) if want_dbias else None
+    dbias = torch.zeros(3 * D, device=qkv.device, dtype=torch.float32) if want_dbias else None
     check(lib().mfvit_attention_bwd(code, ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), B, T, heads, D // heads,
                                     stream()), "mfvit_attention_bwd")
     return dqkv, dbias
 
 
-def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32):
+def _code_of_dtype(dt, split=False):
+    if dt == torch.bfloat16:
+        return BF16X3 if split else BF16
+    return F16 if dt == torch.float16 else F32
+
+
+def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32, split=False):
     require_cuda(x, gamma, beta)
     rows, N = x.shape
-    y = torch.empty(rows, N, device=x.device, dtype=out_dtype)
+    y = torch.empty(rows, N * (2 if split else 1), device=x.device, dtype=out_dtype)
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    code = BF16 if out_dtype == torch.bfloat16 else F32
+    code = _code_of_dtype(out_dtype, split)
     check(lib().mfvit_layernorm_fwd(code, ptr(x), ptr(y), int(out_dtype == torch.float32), ptr(gamma), ptr(beta), eps, ptr(mean),
                                     ptr(rstd), rows, N, stream()), "mfvit_layernorm_fwd")
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, copy_dtype=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, copy_dtype=None, split=False):
     require_cuda(dy, x)
     rows, N = x.shape
     dx = torch.empty_like(x)
-    dx_t = torch.empty(rows, N, device=x.device, dtype=copy_dtype) if copy_dtype is not None else None
+    dx_t = torch.empty(rows, N * (2 if split else 1), device=x.device, dtype=copy_dtype) if copy_dtype is not None else None
     dgamma = torch.zeros(N, device=x.device, dtype=torch.float32)
     dbeta = torch.zeros_like(dgamma)
     dcol = torch.zeros_like(dgamma)
-    code = BF16 if copy_dtype == torch.bfloat16 else F32
+    code = _code_of_dtype(copy_dtype, split)
     check(lib().mfvit_layernorm_bwd(code, ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dx_t), ptr(dgamma),
                                     ptr(dbeta), ptr(dcol), rows, N, stream()), "mfvit_layernorm_bwd")
     return dx, dx_t, dgamma, dbeta, dcol
 
 
-def cast_transpose(src, dtype, want_straight=True, want_transposed=True):
+def cast_transpose(src, dtype, want_straight=True, want_transposed=True, split=False):
     require_cuda(src)
     R, C = src.shape
-    code = BF16 if dtype == torch.bfloat16 else F32
-    dst = torch.empty(R, C, device=src.device, dtype=dtype) if want_straight else None
-    dst_t = torch.empty(C, R, device=src.device, dtype=dtype) if want_transposed else None
+    code = _code_of_dtype(dtype, split)
+    e = 2 if split else 1
+    dst = torch.empty(R, C * e, device=src.device, dtype=dtype) if want_straight else None
+    dst_t = torch.empty(C, R * e, device=src.device, dtype=dtype) if want_transposed else None
     check(lib().mfvit_cast_transpose(code, ptr(src), ptr(dst), ptr(dst_t), R, C, stream()), "mfvit_cast_transpose")
     return dst, dst_t
 

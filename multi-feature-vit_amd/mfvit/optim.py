@@ -1,5 +1,15 @@
 """Multi-tensor optimizers on the HIP path: torch.optim.Optimizer subclasses with the reference's
-constructor signatures whose ``step()`` is one or two kernel launches over a device-resident chunk table."""
+constructor signatures whose ``step()`` is one or two kernel launches over a device-resident chunk table.
+
+State layout = the reference's / torch's, so optimizer state dicts move both ways between this package and the reference drivers
+(MAIN_MOCO:461-467 saves ``optimizer.state_dict()``, its resume path loads it):
+  LARS (OPT:10-43)            state[p] = {'mu'}
+  Adam / AdamW (torch.optim)  state[p] = {'step' (f32 scalar tensor), 'exp_avg', 'exp_avg_sq'}
+  SGD (torch.optim)           state[p] = {'momentum_buffer'}
+The device chunk tables are runtime caches of raw addresses: they live on the optimizer object (never inside ``param_groups``,
+which ``state_dict()`` pickles), are keyed by every address a row holds (parameter, gradient, both state tensors), and are dropped by
+``load_state_dict``.
+"""
 import torch
 
 from . import _lib
@@ -15,53 +25,88 @@ def _bump_versions(params):
 
 
 class _TableOptimizer(torch.optim.Optimizer):
-    nstate = 1
+    state_names = ("s0",)          # names of the per-parameter state tensors, in table-column order
 
-    def _table(self, group):
-        """(table tensor, ntensors) for the params of `group` that have gradients; rebuilt when any pointer changes."""
+    # ---- runtime caches (never pickled: Optimizer.__getstate__ keeps defaults / state / param_groups only)
+    def _cache(self):
+        c = self.__dict__.get("_mfvit_cache")
+        if c is None:
+            c = self.__dict__["_mfvit_cache"] = {}
+        return c
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._cache().clear()      # the loaded state tensors live at new addresses
+        for g in self.param_groups:     # checkpoints written by round-1 builds carried these runtime keys
+            g.pop("_mfvit_live", None)
+            g.pop("_mfvit_tables", None)
+
+    def _ensure_state(self, p):
+        st = self.state[p]
+        for name in self.state_names:
+            t = st.get(name)
+            if t is None:
+                st[name] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            elif (not t.is_cuda or t.device != p.device or t.dtype != torch.float32 or not t.is_contiguous()
+                  or t.shape != p.shape):
+                st[name] = t.to(device=p.device, dtype=torch.float32).reshape(p.shape).contiguous()
+        return st
+
+    def _table(self, gi, group):
+        """(table tensor, ntensors, live params) for the params of `group` that have gradients; rebuilt when any address changes."""
         ps = [p for p in group["params"] if p.grad is not None]
         if not ps:
-            return None, 0
+            return None, 0, ps
+        keys = []
         for p in ps:
             if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.grad.dtype != torch.float32:
                 raise _lib.MfvitError("the HIP optimizers need contiguous f32 parameters and gradients on the GPU")
             if not p.grad.is_contiguous():
                 p.grad = p.grad.contiguous()
-            st = self.state[p]
-            if "s0" not in st:
-                st["s0"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                if self.nstate > 1:
-                    st["s1"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-        group["_mfvit_live"] = ps
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+            st = self._ensure_state(p)
+            keys.append((p.data_ptr(), p.grad.data_ptr(), p.numel()) + tuple(st[n].data_ptr() for n in self.state_names))
+        key = tuple(keys)
         # Gradients are re-created every step (zero_grad(set_to_none=True)); the caching allocator hands the same few addresses out
         # in a cycle, so keep a table per address pattern instead of rebuilding (a ~700-row Python loop + an upload) whenever it
         # changes.  The upload goes through pinned memory and does not block the host: a pageable cudaMemcpy here would wait for the
         # whole backward still queued on the stream and leave the GPU idle until the host has caught up again (measured: 1.9 ms of
         # idle GPU per step).
-        cache = group.setdefault("_mfvit_tables", {})
+        cache = self._cache().setdefault(gi, {})
         hit = cache.get(key)
         if hit is None:
             rows = []
             for tid, p in enumerate(ps):
                 st = self.state[p]
                 n = p.numel()
+                s0 = st[self.state_names[0]].data_ptr()
+                s1 = st[self.state_names[1]].data_ptr() if len(self.state_names) > 1 else 0
                 for a in range(0, n, CHUNK):
                     c = min(CHUNK, n - a)
-                    rows.append([tid, p.data_ptr() + 4 * a, p.grad.data_ptr() + 4 * a, st["s0"].data_ptr() + 4 * a,
-                                 st["s1"].data_ptr() + 4 * a if self.nstate > 1 else 0, c, self._flag(p, group)])
+                    rows.append([tid, p.data_ptr() + 4 * a, p.grad.data_ptr() + 4 * a, s0 + 4 * a, s1 + 4 * a if s1 else 0, c,
+                                 self._flag(p, group)])
             host = torch.tensor(rows, dtype=torch.int64).pin_memory()
             if len(cache) >= 8:
                 cache.clear()
             hit = cache[key] = (host.to(ps[0].device, non_blocking=True), len(ps), host)   # keep the pinned source alive
-        return hit[0], hit[1]
+        return hit[0], hit[1], ps
 
     def _flag(self, p, group):
         return 0
 
+    @torch.no_grad()
+    def unscale_(self, inv_scale, found_inf):
+        """GradScaler.unscale_: g *= inv_scale for every gradient of this optimizer; found_inf (device f32[1]) is set to 1 when a
+        gradient held an inf / nan (mfvit_amp_unscale)."""
+        for gi, g in enumerate(self.param_groups):
+            table, nt, _ = self._table(gi, g)
+            if table is None:
+                continue
+            check(lib().mfvit_amp_unscale(ptr(table), table.shape[0], float(inv_scale), ptr(found_inf), stream()), "mfvit_amp_unscale")
+
 
 class LARS(_TableOptimizer):
     """LARS optimizer, no rate scaling or weight decay for parameters <= 1D (OPT:10-43)."""
+    state_names = ("mu",)
 
     def __init__(self, params, lr=0, weight_decay=0, momentum=0.9, trust_coefficient=0.001):
         defaults = dict(lr=lr, weight_decay=weight_decay, momentum=momentum, trust_coefficient=trust_coefficient)
@@ -72,19 +117,19 @@ class LARS(_TableOptimizer):
 
     @torch.no_grad()
     def step(self):
-        for g in self.param_groups:
-            table, nt = self._table(g)
+        for gi, g in enumerate(self.param_groups):
+            table, nt, live = self._table(gi, g)
             if table is None:
                 continue
             norms = torch.empty(2 * nt, device=table.device, dtype=torch.float32)
             check(lib().mfvit_lars_step(ptr(table), table.shape[0], nt, ptr(norms), float(g["lr"]), float(g["weight_decay"]),
                                         float(g["momentum"]), float(g["trust_coefficient"]), stream()), "mfvit_lars_step")
-            _bump_versions(g["_mfvit_live"])
+            _bump_versions(live)
 
 
 class Adam(_TableOptimizer):
     """torch.optim.Adam semantics (L2 weight decay folded into the gradient)."""
-    nstate = 2
+    state_names = ("exp_avg", "exp_avg_sq")
     decoupled = False
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
@@ -95,14 +140,28 @@ class Adam(_TableOptimizer):
 
     @torch.no_grad()
     def step(self):
-        for g in self.param_groups:
-            table, nt = self._table(g)
+        for gi, g in enumerate(self.param_groups):
+            table, nt, live = self._table(gi, g)
             if table is None:
                 continue
-            g["_step"] = g.get("_step", 0) + 1
+            # per-parameter 'step' like torch.optim (f32 scalar tensors on the host); one kernel launch serves one step number, so the
+            # parameters of a group must agree on it (they do unless a caller hand-edits the state)
+            steps = []
+            for p in live:
+                st = self.state[p]
+                t = st.get("step")
+                if not torch.is_tensor(t):
+                    t = st["step"] = torch.tensor(float(t or 0), dtype=torch.float32)
+                elif t.device.type != "cpu":
+                    t = st["step"] = t.detach().float().cpu()
+                steps.append(t)
+            step = int(steps[0]) + 1
+            if any(int(t) + 1 != step for t in (steps[len(steps) // 2], steps[-1])):
+                raise _lib.MfvitError("Adam: the parameters of one group disagree on their step count")
+            torch._foreach_add_(steps, 1.0)
             check(lib().mfvit_adam_step(ptr(table), table.shape[0], float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                                        float(g["eps"]), float(g["weight_decay"]), g["_step"], stream()), "mfvit_adam_step")
-            _bump_versions(g["_mfvit_live"])
+                                        float(g["eps"]), float(g["weight_decay"]), step, stream()), "mfvit_adam_step")
+            _bump_versions(live)
 
 
 class AdamW(Adam):
@@ -114,19 +173,19 @@ class AdamW(Adam):
 
 
 class SGD(_TableOptimizer):
-    """torch.optim.SGD semantics (momentum, L2 weight decay; no dampening / nesterov)."""
+    """torch.optim.SGD semantics (momentum, L2 weight decay; no dampening / nesterov).  torch initialises 'momentum_buffer' with the
+    first update d; a zero buffer gives the same first step (momentum * 0 + d), so the kernel never needs the first-step case."""
+    state_names = ("momentum_buffer",)
 
     def __init__(self, params, lr=1e-3, momentum=0, weight_decay=0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
 
     @torch.no_grad()
     def step(self):
-        for g in self.param_groups:
-            table, nt = self._table(g)
+        for gi, g in enumerate(self.param_groups):
+            table, nt, live = self._table(gi, g)
             if table is None:
                 continue
-            first = 0 if g.get("_started") else 1
-            g["_started"] = True
-            check(lib().mfvit_sgd_step(ptr(table), table.shape[0], float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), first,
+            check(lib().mfvit_sgd_step(ptr(table), table.shape[0], float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), 0,
                                        stream()), "mfvit_sgd_step")
-            _bump_versions(g["_mfvit_live"])
+            _bump_versions(live)

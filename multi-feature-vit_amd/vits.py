@@ -14,7 +14,7 @@ __all__ = ["vit_small", "vit_base", "vit_conv_small", "vit_conv_base", "vit_smal
 
 def vit_small(**kwargs):
     """ViT-S/16: embed 384, depth 12, 12 heads, mlp 4x, qkv bias, LN eps 1e-6 (moco-v3 ``vit_small``).
-    kwargs: num_classes (BLD:29-30), stop_grad_conv1 (MAIN_MOCO:274), img_size, precision ('bf16' | 'fp32')."""
+    kwargs: num_classes (BLD:29-30), stop_grad_conv1 (MAIN_MOCO:274), img_size, precision ('bf16x3' default | 'bf16' | 'fp16' | 'fp32')."""
     cfg = dict(patch_size=16, embed_dim=384, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True)
     cfg.update(kwargs)
     return VisionTransformerMoCo(**cfg)

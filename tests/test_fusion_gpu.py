@@ -136,17 +136,17 @@ def test_fus_crossvit_end_to_end_against_reference_golden():
 
 
 def test_two_rank_data_parallel_step_rehearsal():
-    """N = 2 rehearsal of bench.py's data-parallel path on ONE GPU (gloo backend, both ranks on cuda:0): rendezvous, per-block
-    asynchronous gradient all-reduce from the encoder backward hooks, flat exchange of the fusion gradients, max-over-ranks
-    timing, one JSON line from rank 0.  (RCCL itself needs one GPU per rank; the driver runs that at round end.)"""
+    """N = 2 rehearsal of bench.py's data-parallel path on ONE GPU (gloo backend, both ranks on cuda:0): bench.py's own launcher
+    (`--gpus 2` without a WORLD_SIZE), rendezvous, per-bucket asynchronous gradient all-reduce from the encoder backward hooks, flat
+    exchange of the fusion gradients, max-over-ranks timing, one JSON line from rank 0.  (RCCL itself needs one GPU per rank; the
+    driver runs that at round end.)"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MFVIT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "4", "--no-cpu-baseline"]
+    # `bench.py --gpus 2` starts its own two ranks (child process through torch.distributed.run) and relays rank 0's line
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]

@@ -14,7 +14,7 @@ P5="WRITE_SIZE"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $out/pass$i -- python3 $R/tools/one_op.py $op 4 > $out/pass$i.log 2>&1 || { tail -5 $out/pass$i.log; }
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $out/pass$i -- python3 $R/tools/one_op.py $op 4 > $out/pass$i.log 2>&1 || { rc=$?; echo "pass $i failed (rc $rc): not starting further passes on this box" >&2; tail -20 $out/pass$i.log >&2; exit $rc; }
 done
 cd $R
 python3 tools/pmc_summary.py $out
