@@ -116,9 +116,24 @@ def lib():
     return h
 
 
+def source_hash():
+    """sha1 over the kernel sources (csrc/*.hip, *.cuh, *.h + include/mfvit.h): stamps measurements (PMC traffic files under
+    profiles/) with the code they were taken on, so that bench.py never reports a figure measured on other kernels."""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(os.path.dirname(_HERE), "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cuh", ".h")))
+    files.append(os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "mfvit.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def check(rc, what):
     if rc != 0:
-        raise MfvitError(f"{what} failed with code {rc} (-22 = invalid argument, -5 = launch error)")
+        raise MfvitError(f"{what} failed with code {rc} (-22 = invalid argument, -5 = launch error, -38 = not built for this dtype / size)")
 
 
 def ptr(t):

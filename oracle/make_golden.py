@@ -17,6 +17,8 @@ What is exercised from the reference (paths relative to /root/reference/moco_pre
         _dequeue_and_enqueue (1-rank gloo group), concat_all_gather
   moco/builder_vit.py                  MoCo.contrastive_loss, MoCo_ViT.forward (symmetric MoCo-v3 loss; 1-rank gloo group,
         torch.Tensor.cuda mapped to the identity while it runs because builder_vit.py:93 calls .cuda() on the labels)
+  moco/builder_vit_mocov3structure_mocov2loss.py   MoCo.forward itself (its lines 154-199) on a toy encoder: same 1-rank gloo group and
+        Tensor.cuda -> identity shim (its :121, :194 call .cuda())  -> moco_forward.npz
   moco/optimizer.py                    LARS
 The ViT backbone is absent from the reference; where a backbone is needed the oracle's own restatement
 (oracle/ref_vit.py, parity unpinned) is wrapped in an object exposing ``features3D`` / ``__call__``.
@@ -308,6 +310,70 @@ def golden_moco_v3():
     print("moco_v3.npz loss", float(d["fwd_loss"]))
 
 
+def golden_moco_forward():
+    """MoCo.forward ITSELF (builder_vit_mocov3structure_mocov2loss.py:154-199: EMA, shuffle, key encoding with the shared predictor,
+    unshuffle, logits against the queue, temperature, labels, enqueue) of the reference, on a toy encoder, under a 1-rank gloo group
+    with torch.Tensor.cuda mapped to the identity while the reference code runs (its :121 and :194 call .cuda()).  Nothing
+    of the reference is altered.  Toy widths are MFMA-tile friendly (128) so that the HIP builder can run the same case."""
+    import torch.distributed as dist
+    import moco.builder_vit_mocov3structure_mocov2loss as bld
+
+    class Toy(torch.nn.Module):
+        def __init__(self, num_classes=1000, **_):
+            super().__init__()
+            self.body = torch.nn.Linear(12, 128)
+            self.head = torch.nn.Linear(128, num_classes)
+
+        def forward(self, x):
+            return self.head(self.body(x))
+
+    d = {}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29535"
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        torch.manual_seed(0)
+        n, T, mval = 8, 0.2, 0.99
+        m = bld.MoCo_ViT(Toy, types.SimpleNamespace(arch="vit_small"), dim=256, mlp_dim=128, T=T).double().train()
+        d["state_keys"] = np.array(sorted(m.state_dict().keys()))
+        with torch.no_grad():
+            for i, (name, p) in enumerate(m.named_parameters()):
+                if p.ndim == 1:      # BN affine / Linear bias: around 1 for BN weights, small otherwise
+                    p.copy_((1.0 if name.endswith("weight") else 0.0) + 0.1 * rng_tensor(540 + i, p.shape, dtype=torch.float64))
+                else:
+                    p.copy_(rng_tensor(540 + i, p.shape, dtype=torch.float64) / p.shape[1] ** 0.5)
+            m.queue.copy_(torch.nn.functional.normalize(rng_tensor(539, tuple(m.queue.shape), dtype=torch.float64), dim=0))
+            m.queue_ptr[0] = m.K - n                                   # the enqueue wraps the pointer to 0
+        d["param_names"] = np.array([n_ for n_, _ in m.named_parameters()])
+        d["param_shapes"] = np.array([",".join(map(str, p.shape)) for _, p in m.named_parameters()])
+        d.update(seed_param0=540, seed_queue=539, seed_q=531, seed_k=532, n=n, T=T, m=mval, K=m.K, ptr_before=m.K - n)
+        im_q = rng_tensor(531, (n, 12), dtype=torch.float64)
+        im_k = rng_tensor(532, (n, 12), dtype=torch.float64)
+        logits, labels = m(im_q, im_k, mval)
+        loss = torch.nn.functional.cross_entropy(logits, labels)       # MAIN_MOCO:535
+        loss.backward()
+        put(d, "logits", logits)
+        put(d, "logits_head", logits[:, :16], full=True)
+        d["labels"] = labels.numpy()
+        put(d, "loss", loss, full=True)
+        d["ptr_after"] = int(m.queue_ptr)
+        put(d, "queue_tail", m.queue[:, m.K - n:], full=True)          # the n enqueued keys
+        put(d, "queue", m.queue)
+        for name, p in m.momentum_encoder.named_parameters():
+            put(d, "mom." + name, p)
+        for name, p in list(m.base_encoder.named_parameters()) + [("predictor." + k_, v) for k_, v in m.predictor.named_parameters()]:
+            put(d, "d." + name, p.grad)
+        put(d, "pred_bn_running_mean", m.predictor[1].running_mean, full=True)   # updated TWICE per step (Q6): q pass and k pass
+        d["pred_bn_batches"] = int(m.predictor[1].num_batches_tracked)
+    finally:
+        torch.Tensor.cuda = real_cuda
+        dist.destroy_process_group()
+    np.savez_compressed(os.path.join(OUT, "moco_forward.npz"), **d)
+    print("moco_forward.npz loss", float(d["loss"]), "ptr", d["ptr_after"])
+
+
 def golden_lars():
     from moco.optimizer import LARS
     shapes = [(6, 5), (5,), (4, 3), (3, 2)]
@@ -335,8 +401,13 @@ def golden_lars():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                 # python oracle/make_golden.py golden_moco_forward ... : only the named generators
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     golden_cross_attention()
     golden_fusion()
     golden_moco()
     golden_moco_v3()
+    golden_moco_forward()
     golden_lars()
