@@ -197,16 +197,20 @@ def other_workloads(args, world, rank, dev, lib):
         opt = AdamW(train, lr=1.5e-4, weight_decay=0.1)                                                # MAIN_MOCO:338-340
         it = [0]
 
+        from mfvit.amp import GradScaler
+        scaler = GradScaler(enabled=args.precision == "fp16")                                          # MAIN_MOCO:349 (fp16 autocast path)
+
         def step():
             m = adjust_moco_momentum(it[0] / 1000.0, 300, 0.99)                                        # MAIN_MOCO:525-526
             it[0] += 1
             logits, labels = model(x1, x2, m)                                                          # MAIN_MOCO:534
             loss = cross_entropy_rows(logits, labels)                                                  # MAIN_MOCO:535
             opt.zero_grad(set_to_none=True)
-            loss.backward()                                                                            # MAIN_MOCO:546
+            scaler.scale(loss).backward()                                                              # MAIN_MOCO:546
             sync.reduce_grads(small)
             sync.finish()
-            opt.step()
+            scaler.step(opt)                                                                           # MAIN_MOCO:547
+            scaler.update()                                                                            # MAIN_MOCO:548
             return loss
         gflop, name = 36.80, "samples/sec (MoCo vit_small pretrain step, BASELINE configs[3] per-GPU slice of 128)"
     for _ in range(max(args.warmup, 1)):
@@ -228,8 +232,8 @@ def other_workloads(args, world, rank, dev, lib):
     if rank == 0:
         print(json.dumps(dict(metric=name, value=B * world * args.steps / dt, unit="images/sec", n_gpus=world, steps=args.steps,
                               warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
-                              vs_baseline=None, dtype=args.precision, data="synthetic",
-                              config=dict(workload=args.workload, per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
+                              vs_baseline=None, dtype=ARITH[args.precision], data="synthetic",
+                              config=dict(workload=args.workload, precision=args.precision, per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
                               model_tflops=gflop * B * world * args.steps / dt / 1e3 if args.img == 224 else None,
                               loss=float(loss.detach()))), flush=True)
     if world > 1:

@@ -18,7 +18,7 @@ template <typename T, int HD> __device__ __forceinline__ void load_row(const T* 
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int i = 0; i < HD / 8; ++i) {
-            const bf16x8 v = *(const bf16x8*)(p + 8 * i);
+            const typename Vec8<T>::type v = *(const typename Vec8<T>::type*)(p + 8 * i);
 #pragma unroll
             for (int j = 0; j < 8; ++j) r[8 * i + j] = (float)v[j];
         }
@@ -34,10 +34,10 @@ template <typename T, int HD> __device__ __forceinline__ void store_row(T* p, co
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int i = 0; i < HD / 8; ++i) {
-            bf16x8 v;
+            typename Vec8<T>::type v;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (bf16)r[8 * i + j];
-            *(bf16x8*)(p + 8 * i) = v;
+            for (int j = 0; j < 8; ++j) v[j] = from_f32<T>(r[8 * i + j]);
+            *(typename Vec8<T>::type*)(p + 8 * i) = v;
         }
     } else {
 #pragma unroll
@@ -53,7 +53,7 @@ template <typename T, int HD> __device__ __forceinline__ void stage_rows(const T
         const T* s = base + (long)t * row_stride + 4 * c;
         float4 v;
         if constexpr (sizeof(T) == 2) {
-            const bf16x4 w = *(const bf16x4*)s;
+            const typename Vec4<T>::type w = *(const typename Vec4<T>::type*)s;
             v = make_float4((float)w[0], (float)w[1], (float)w[2], (float)w[3]);
         } else {
             v = *(const float4*)s;
@@ -278,18 +278,37 @@ bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward);
 int attn_fwd_mfma(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st);
 int attn_bwd_mfma(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
                   hipStream_t st);
+bool attn_tiled_supported(int dtype, int Tn, int HDim);      // attention_tiled.hip: streaming kernels, any T, head_dim 32 / 64 / 96
+int attn_fwd_tiled(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, hipStream_t st);
+int attn_bwd_tiled(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int Tn, int H, int HDim,
+                   hipStream_t st);
+int attn_colsum(int dtype, const void* dqkv, int M, int N, float* dbias, hipStream_t st);
 static bool force_exact() {
     static const bool v = [] { const char* e = getenv("MFVIT_ATTN_EXACT"); return e && e[0] == '1'; }();
     return v;
 }
+static bool force_tiled() {   // MFVIT_ATTN_TILED=1: the streaming kernels also where the whole-head-in-LDS kernels would fit (tests, profiling)
+    static const bool v = [] { const char* e = getenv("MFVIT_ATTN_TILED"); return e && e[0] == '1'; }();
+    return v;
+}
+// whole-(image, head)-in-LDS MFMA kernels where they fit (ViT-S at 224^2: fastest) -> streaming MFMA kernels (long sequences, wide
+// heads, split bf16 beyond the LDS limits) -> exact VALU kernels (f32)
 int attn_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, hipStream_t st) {
-    if (!(force_exact() && dtype != MFVIT_BF16X3) && attn_mfma_supported(dtype, Tn, HDim, false)) return attn_fwd_mfma(dtype, qkv, out, lse, B, Tn, H, st);
+    const bool exact = force_exact() && dtype != MFVIT_BF16X3;
+    if (!exact && !force_tiled() && attn_mfma_supported(dtype, Tn, HDim, false)) return attn_fwd_mfma(dtype, qkv, out, lse, B, Tn, H, st);
+    if (!exact && attn_tiled_supported(dtype, Tn, HDim)) return attn_fwd_tiled(dtype, qkv, out, lse, B, Tn, H, HDim, st);
     return attn_fwd_exact(dtype, qkv, out, lse, B, Tn, H, HDim, st);
 }
 int attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
              int HDim, hipStream_t st) {
-    if (!(force_exact() && dtype != MFVIT_BF16X3) && attn_mfma_supported(dtype, Tn, HDim, true))
+    const bool exact = force_exact() && dtype != MFVIT_BF16X3;
+    if (!exact && !force_tiled() && attn_mfma_supported(dtype, Tn, HDim, true))
         return attn_bwd_mfma(dtype, qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+    if (!exact && attn_tiled_supported(dtype, Tn, HDim)) {
+        const int rc = attn_bwd_tiled(dtype, qkv, out, dout, lse, dqkv, B, Tn, H, HDim, st);
+        if (rc != MFVIT_OK || !dbias) return rc;
+        return attn_colsum(dtype, dqkv, B * Tn, 3 * H * HDim, dbias, st);
+    }
     return attn_bwd_exact(dtype, qkv, out, dout, lse, dqkv, dbias, B, Tn, H, HDim, st);
 }
 

@@ -442,6 +442,17 @@ bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward) {
     return bytes <= 160 * 1024;
 }
 
+// d qkv.bias = column sums of dqkv [M][N logical columns] (used by the tiled kernels, which do not fuse it)
+int attn_colsum(int dtype, const void* dqkv, int M, int N, float* dbias, hipStream_t st) {
+    const dim3 grid((M + 63) / 64);
+    if (dtype == MFVIT_BF16) MFVIT_LAUNCH((colsum_t_kernel<bf16>), grid, dim3(256), 0, st, (const bf16*)dqkv, (long)N, dbias, M, N);
+    else if (dtype == MFVIT_BF16X3) MFVIT_LAUNCH((colsum_t_kernel<sbf16>), grid, dim3(256), 0, st, (const bf16*)dqkv, (long)N * 2, dbias, M, N);
+    else if (dtype == MFVIT_F16) MFVIT_LAUNCH((colsum_t_kernel<f16>), grid, dim3(256), 0, st, (const f16*)dqkv, (long)N, dbias, M, N);
+    else return MFVIT_EINVAL;
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
 int attn_fwd_mfma(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
     if (dtype == MFVIT_BF16) return launch_fwd_t<bf16>(qkv, out, lse, B, Tn, H, st);
     if (dtype == MFVIT_BF16X3) return launch_fwd_t<sbf16>(qkv, out, lse, B, Tn, H, st);

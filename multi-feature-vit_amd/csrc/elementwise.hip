@@ -397,4 +397,18 @@ int colsum_rows(const float* x, long ld, float* out, int rows, int row_stride, i
     return MFVIT_OK;
 }
 
+// out[i] += sum_b x[b * n + i]   (d pos_emb of the token-input encoder: the position table is shared by the batch)
+__global__ __launch_bounds__(256) void batch_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int B, long n) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += x[(long)b * n + i];
+    out[i] += s;
+}
+int batch_sum(const float* x, float* out, int B, long n, hipStream_t st) {
+    MFVIT_LAUNCH(batch_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, out, B, n);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
 }  // namespace mfvit

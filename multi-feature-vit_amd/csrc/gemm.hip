@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
     for (int j = 0; j < Loop::TN; ++j) {
         csums[j] = 0.f;
         const int n = n0 + (wn * Loop::TN + j) * 32 + (lane & 31);
-        bj[j] = ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) && p.bias) ? p.bias[n] : 0.f;
+        bj[j] = ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) && p.bias) ? p.bias[n] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < Loop::TN; ++j) {
@@ -92,6 +92,9 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
                 if (EPI == EPI_BIAS_GELU) {
                     acc[i][j][r] = v;                                   // kept for the second output
                     store_elem<T>(e, ecol(j), gelu_grad_t<T>(v));       // out0 = gelu'(pre): all the backward needs
+                } else if (EPI == EPI_BIAS_RELU) {
+                    acc[i][j][r] = v;
+                    store_elem<T>(e, ecol(j), v > 0.f ? 1.f : 0.f);     // out0 = relu'(pre) (fuseattention.py:69: nn.ReLU)
                 } else if (EPI == EPI_GELU_BWD) {
                     v *= load_elem<T>(e, ecol(j));
                     store_elem<T>(e, ecol(j), v);
@@ -118,14 +121,15 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
         __syncthreads();
         if (tid < BN) p.cpart[(long)(m0 / BM) * p.N + n0 + tid] = sc[tid] + sc[BN + tid];
     }
-    if (EPI == EPI_BIAS_GELU) {
+    if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < Loop::TN; ++j)
 #pragma unroll
             for (int i = 0; i < Loop::TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) store_elem<T>(erow(i, r), ecol(j), gelu_t<T>(acc[i][j][r]));
+                for (int r = 0; r < 16; ++r)
+                    store_elem<T>(erow(i, r), ecol(j), EPI == EPI_BIAS_RELU ? fmaxf(acc[i][j][r], 0.f) : gelu_t<T>(acc[i][j][r]));
         store_tile(p.out1, p.ldo1);
     }
 }
@@ -735,6 +739,7 @@ int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
         case EPI_BIAS_GELU: return tile_by_dtype<EPI_BIAS_GELU>(dtype, p, st);
         case EPI_GELU_BWD: return tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
         case EPI_NONE: return tile_by_dtype<EPI_NONE>(dtype, p, st);
+        case EPI_BIAS_RELU: return tile_by_dtype<EPI_BIAS_RELU>(dtype, p, st);
     }
     return MFVIT_EINVAL;
 }

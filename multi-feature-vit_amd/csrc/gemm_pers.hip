@@ -351,6 +351,7 @@ bool gemm_nt_pers_supported(int dtype, int epi, const GemmP& p, bool force) {
     static const int on = [] { const char* e = getenv("MFVIT_PERS"); return e ? atoi(e) : 0; }();
     if ((!on && !force) || dtype != MFVIT_BF16 || p.nb > 1 || p.M < 1024) return false;
     if (p.N % PBN || p.N > PMAXN || p.K % 32 || p.K < 128) return false;
+    if (epi == EPI_BIAS_RELU) return false;                    // ReLU MLP (TransFuser-GPT): 128x128 kernel only
     if (epi == EPI_GELU_BWD && p.cs0) return false;            // column sums stay with the 128x128 kernel
     if ((long)p.M * p.lda * 2 >= (1L << 32) || (long)p.N * p.ldw * 2 >= (1L << 32)) return false;   // 32-bit byte offsets
     if (p.lda % 8 || p.ldw % 8 || p.ldo0 % 4 || (p.out1 && p.ldo1 % 4) || (p.aux && p.ldaux % 4)) return false;

@@ -21,10 +21,25 @@ namespace mfvit {
 
 namespace {
 
-constexpr int T2_BN = 128, T2_BK = 128, T2_KR = 64, T2_NS = 3;
-constexpr int T2_TILE = T2_KR * 256;            // 16 KB per operand and stage
+constexpr int T2_NS = 3;
+constexpr int T2_TILE = 16 * 1024;              // bytes per operand and stage (KR rows x TW columns x 2 B)
 constexpr int T2_STAGE = 2 * T2_TILE;           // 32 KB
 constexpr int T2_LPS = 8;                       // LDS-DMA instructions per wave and stage (4 per operand)
+
+// Tile geometry by element type.  Plain 16-bit types: 128 x 128 output tile, 64 reduction rows per stage.  Split bf16 (sbf16): the
+// operand tiles are 256 STORAGE columns wide = 128 logical columns as [hi x 32 | lo x 32] groups, 32 reduction rows per stage (the
+// same 16 KB per operand), so a workgroup still owns a 128 x 128 LOGICAL tile and each wave a 64 x 64 logical one:
+// per 16-row k step 8 fragments (hi / lo of 2 + 2 groups) feed 12 MFMAs  (a_hi b_hi + a_lo b_hi + a_hi b_lo per 32 x 32 tile).
+template <typename T> struct T2Geo {
+    static constexpr bool SPLIT = is_split<T>::value;
+    static constexpr int TW = SPLIT ? 256 : 128;   // storage columns per operand tile
+    static constexpr int KR = SPLIT ? 32 : 64;     // reduction rows per stage
+    static constexpr int ROWB = TW * 2;            // LDS row pitch in bytes (no padding: an LDS-DMA writes 1 KB contiguously)
+    static constexpr int CPR = ROWB / 16;          // 16-B chunks per row
+    static constexpr int RPI = 64 / CPR;           // rows filled by one LDS-DMA wave instruction
+    static constexpr int NF = TW / 2 / 32;         // 32-column fragments per operand and wave
+    static constexpr int BL = 128;                 // logical tile edge
+};
 
 template <int N> __device__ __forceinline__ void t2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -36,73 +51,77 @@ __device__ __forceinline__ void t2_glds16(const void* gsrc, unsigned lds_off) {
                  : "memory");
 }
 
-// transposed fragment of the swizzled image: lane holds column (rowbase + lane & 31), elements k = 16 s + 8 (lane >> 5) .. +8
+// transposed fragment of the swizzled image: lane holds column (rowbase + lane & 31), elements k = 16 s + 8 (lane >> 5) .. +8.
+// The 16-B chunks of row m sit XOR-swizzled by 4 * (m & 3): the 4 rows of one tr-read block land in 4 disjoint 64-B windows of
+// the bank row, whatever the row pitch (256 or 512 B).
 template <typename T> __device__ __forceinline__ typename Vec8<T>::type t2_frag(const char* t, int rowbase, int s, int lane) {
+    constexpr int ROWB = T2Geo<T>::ROWB;
     const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
     const int k0 = 16 * s + 8 * h + q;                       // (k0 & 3) == q, also for k0 + 4
     const int col = rowbase + 16 * g1 + 4 * pp;
-    const char* a = t + k0 * 256 + (((col >> 3) ^ (4 * q)) << 4) + (col & 7) * 2;
+    const char* a = t + k0 * ROWB + (((col >> 3) ^ (4 * q)) << 4) + (col & 7) * 2;
     typedef __attribute__((address_space(3))) s16x4* lptr;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)a);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 4 * 256));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a + 4 * ROWB));
     union { struct { s16x4 a, b; } s; typename Vec8<T>::type v; } u;
     u.s.a = lo;
     u.s.b = hi;
     return u.v;
 }
 
-// T = bf16 | f16 | sbf16.  Split tensors (sbf16): the tile grid runs over the STORAGE columns; a wave's four accumulators are the
-// hi*hi, hi*lo, lo*hi (lo*lo skipped) blocks of one 32 x 32 logical tile and are summed in the epilogue (see gemm_tn_kernel).
+// T = bf16 | f16 | sbf16 (split bf16, see T2Geo)
 template <typename T, bool CS>
 __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
-    constexpr bool SPLIT = is_split<T>::value;
-    constexpr int EP = elems_per<T>::value;
+    typedef T2Geo<T> G;
+    constexpr bool SPLIT = G::SPLIT;
+    constexpr int EP = elems_per<T>::value, TW = G::TW, KR = G::KR, ROWB = G::ROWB, CPR = G::CPR, RPI = G::RPI, NF = G::NF;
+    constexpr int NL = 2;                                    // 32 x 32 LOGICAL output tiles per wave and dimension
     typedef typename Vec8<T>::type frag_t;
     typedef typename Vec4<T>::elem E16;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntk = p.K * EP / T2_BK;
-    const int tiles = ntk * (p.N * EP / T2_BN);
+    const int ntk = p.K * EP / TW;
+    const int tiles = ntk * (p.N * EP / TW);
     const int lin = xcd_remap(blockIdx.x, gridDim.x);        // each XCD gets a contiguous run of the split-major block order
     const int split = lin / tiles, tile = lin % tiles;
-    const int n0 = (tile / ntk) * T2_BN, k0 = (tile % ntk) * T2_BK;
+    const int n0 = (tile / ntk) * TW, k0 = (tile % ntk) * TW;   // STORAGE columns
     int chunk = (p.M + p.splits - 1) / p.splits;
-    chunk = (chunk + T2_KR - 1) / T2_KR * T2_KR;
+    chunk = (chunk + KR - 1) / KR * KR;
     const int mbeg = split * chunk;
     const int mend = min(p.M, mbeg + chunk);
     if (mbeg >= mend) return;
-    const int nst = (mend - mbeg + T2_KR - 1) / T2_KR;
+    const int nst = (mend - mbeg + KR - 1) / KR;
     const E16* A = (const E16*)p.A;
     const E16* X = (const E16*)p.W;
 
-    // LDS-DMA g = wave + 4 i (i = 0..3) of an operand fills rows 4 g .. 4 g + 3: lane -> row 4 g + (lane >> 4), chunk position
-    // lane & 15, which receives source chunk (lane & 15) ^ (4 * (row & 3)) = (lane & 15) ^ (4 * (lane >> 4))
-    const int lrow = 4 * wave + (lane >> 4);                 // + 16 i
-    const int lch = (lane & 15) ^ (4 * (lane >> 4));
+    // LDS-DMA g = wave + 4 i (i = 0..3) of an operand fills rows RPI g .. RPI g + RPI - 1: lane -> row RPI g + lane / CPR, chunk
+    // position lane % CPR, which receives source chunk (lane % CPR) ^ (4 * (row & 3))   (4 RPI i is a multiple of 4)
+    const int lrow = RPI * wave + lane / CPR;                // + 4 RPI i
+    const int lch = (lane % CPR) ^ (4 * (lrow & 3));
     const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (unsigned)wave * 1024u);
     auto issue = [&](int st, int slot) {
         const unsigned sa = lbase + (unsigned)slot * T2_STAGE, sb = sa + T2_TILE;
-        const int mrow = mbeg + st * T2_KR + lrow;
+        const int mrow = mbeg + st * KR + lrow;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int m = mrow + 16 * i;
+            int m = mrow + 4 * RPI * i;
             m = m < p.M ? m : p.M - 1;                        // never read past the tensor (clamped rows are zeroed below)
             t2_glds16(A + (long)m * p.lda + n0 + lch * 8, sa + i * 4096);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int m = mrow + 16 * i;
+            int m = mrow + 4 * RPI * i;
             m = m < p.M ? m : p.M - 1;
             t2_glds16(X + (long)m * p.ldw + k0 + lch * 8, sb + i * 4096);
         }
     };
 
-    f32x16 acc[2][2], bacc[2];
+    f32x16 acc[NL][NL], bacc[NL];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NL; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NL; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
@@ -128,33 +147,54 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
             if (st + 2 < nst) issue(st + 2, slot == 0 ? 2 : slot - 1);      // (st + 2) % 3: read last in step st-1, free since the barrier
             char* ta = lds + slot * T2_STAGE;
             const char* tb = ta + T2_TILE;
-            const int valid = mend - mbeg - st * T2_KR;          // rows of this stage inside the split
-            if (valid < T2_KR) {                                 // partial last stage: zero the A rows past the end (block-uniform branch)
-                for (int q = tid; q < (T2_KR - valid) * 16; q += 256)
-                    *(uint4*)(ta + (valid + (q >> 4)) * 256 + (q & 15) * 16) = make_uint4(0, 0, 0, 0);
+            const int valid = mend - mbeg - st * KR;             // rows of this stage inside the split
+            if (valid < KR) {                                    // partial last stage: zero the A rows past the end (block-uniform branch)
+                for (int q = tid; q < (KR - valid) * CPR; q += 256)
+                    *(uint4*)(ta + (valid + q / CPR) * ROWB + (q % CPR) * 16) = make_uint4(0, 0, 0, 0);
                 __syncthreads();
             }
-            frag_t a[2][2], b[2][2];
+            frag_t a[2][NF], b[2][NF];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[0][i] = t2_frag<T>(ta, (wm * 2 + i) * 32, 0, lane);
+            for (int i = 0; i < NF; ++i) a[0][i] = t2_frag<T>(ta, (wm * NF + i) * 32, 0, lane);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[0][j] = t2_frag<T>(tb, (wn * 2 + j) * 32, 0, lane);
+            for (int j = 0; j < NF; ++j) b[0][j] = t2_frag<T>(tb, (wn * NF + j) * 32, 0, lane);
 #pragma unroll
-            for (int s = 0; s < T2_KR / 16; ++s) {
-                if (s + 1 < T2_KR / 16) {
+            for (int s = 0; s < KR / 16; ++s) {
+                if (s + 1 < KR / 16) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) a[(s + 1) & 1][i] = t2_frag<T>(ta, (wm * 2 + i) * 32, s + 1, lane);
+                    for (int i = 0; i < NF; ++i) a[(s + 1) & 1][i] = t2_frag<T>(ta, (wm * NF + i) * 32, s + 1, lane);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) b[(s + 1) & 1][j] = t2_frag<T>(tb, (wn * 2 + j) * 32, s + 1, lane);
+                    for (int j = 0; j < NF; ++j) b[(s + 1) & 1][j] = t2_frag<T>(tb, (wn * NF + j) * 32, s + 1, lane);
                 }
+                if constexpr (SPLIT) {   // fragments 2 l / 2 l + 1 = hi / lo part of logical group l
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < NL; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (!(SPLIT && i == 1 && j == 1)) acc[i][j] = MmaTraits<T>::mma(a[s & 1][i], b[s & 1][j], acc[i][j]);
-                if constexpr (WITH_CS) {
+                        for (int j = 0; j < NL; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][2 * i + 1], b[s & 1][2 * j], acc[i][j]);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) bacc[i] = MmaTraits<T>::mma(a[s & 1][i], ones, bacc[i]);
+                    for (int i = 0; i < NL; ++i)
+#pragma unroll
+                        for (int j = 0; j < NL; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][2 * i], b[s & 1][2 * j + 1], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < NL; ++i)
+#pragma unroll
+                        for (int j = 0; j < NL; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][2 * i], b[s & 1][2 * j], acc[i][j]);
+                    if constexpr (WITH_CS) {
+#pragma unroll
+                        for (int i = 0; i < NL; ++i) {
+                            bacc[i] = MmaTraits<T>::mma(a[s & 1][2 * i], ones, bacc[i]);
+                            bacc[i] = MmaTraits<T>::mma(a[s & 1][2 * i + 1], ones, bacc[i]);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NL; ++i)
+#pragma unroll
+                        for (int j = 0; j < NL; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][i], b[s & 1][j], acc[i][j]);
+                    if constexpr (WITH_CS) {
+#pragma unroll
+                        for (int i = 0; i < NL; ++i) bacc[i] = MmaTraits<T>::mma(a[s & 1][i], ones, bacc[i]);
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done before it reaches the next barrier
@@ -163,20 +203,12 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
     };
     if (do_cs) main_loop(std::true_type{});
     else main_loop(std::false_type{});
-    if constexpr (SPLIT) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc[0][0][r] += acc[0][1][r] + acc[1][0][r];
-            bacc[0][r] += bacc[1][r];
-        }
-    }
-    constexpr int NI = SPLIT ? 1 : 2;
-    const int nw = SPLIT ? n0 / 2 + wm * 32 : n0 + wm * 64, kw = SPLIT ? k0 / 2 + wn * 32 : k0 + wn * 64;   // LOGICAL origin of this wave's tile
+    const int nw = n0 / EP + wm * 64, kw = k0 / EP + wn * 64;   // LOGICAL origin of this wave's 64 x 64 tile
     float* out = (float*)p.out0;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NL; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NL; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = nw + i * 32 + acc_row(r, lane);
@@ -186,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
     if (CS) {
         if (do_cs && (lane & 31) == 0) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NL; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + nw + i * 32 + acc_row(r, lane), bacc[i][r]);
         }
@@ -195,35 +227,21 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
 
 }  // namespace
 
-static int t2_ep(int dtype) { return dtype == MFVIT_BF16X3 ? 2 : 1; }
 bool gemm_tn_glds_supported(int dtype, const GemmP& p) {
     static const int on = [] { const char* e = getenv("MFVIT_TN_GLDS"); return e ? atoi(e) : 1; }();
     if (!on || (dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || p.nb > 1 || p.orow_in || p.cpart) return false;
-    const int ep = t2_ep(dtype);
-    if (p.N * ep % T2_BN || p.K * ep % T2_BK || p.M < 4096) return false;
+    if (p.N % 128 || p.K % 128 || p.M < 4096) return false;     // 128 x 128 LOGICAL tiles in every mode
     if (p.lda % 8 || p.ldw % 8) return false;
     return true;
 }
 
 template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
-    constexpr int EP = elems_per<T>::value;
-    const int tiles = (p.N * EP / T2_BN) * (p.K * EP / T2_BK);
+    typedef T2Geo<T> G;
+    const int tiles = (p.N / 128) * (p.K / 128);
     if (p.splits <= 0) {
         static const int target = [] { const char* e = getenv("MFVIT_TN2_TARGET"); return e ? atoi(e) : 256; }();
-        // one workgroup per CU (96 KB of LDS): tiles x splits <= 256 when the tiles allow it; more tiles than CUs (split tensors:
-        // 4 x the storage tiles) run in whole rounds of one split each
-        int s = target / tiles;
-        const int maxs = (p.M + 4 * T2_KR - 1) / (4 * T2_KR);
-        if (EP == 2 && 2 * tiles > target) {
-            // more than half a round of tiles: the smallest split count (<= 8) whose grid fills >= 90 % of its rounds of 256 CUs
-            double best = 0.0;
-            for (int c = 1; c <= 8 && c <= maxs; ++c) {
-                const int g = tiles * c, rounds = (g + target - 1) / target;
-                const double eff = (double)g / ((double)rounds * target);
-                if (eff > best + 1e-9) { best = eff; s = c; }
-                if (eff >= 0.9) break;
-            }
-        }
+        int s = target / tiles;                              // one workgroup per CU (96 KB of LDS): tiles x splits <= 256
+        const int maxs = (p.M + 4 * G::KR - 1) / (4 * G::KR);
         p.splits = s < 1 ? 1 : (s > maxs ? maxs : s);
     }
     constexpr int bytes = T2_NS * T2_STAGE;

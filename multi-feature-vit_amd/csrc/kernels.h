@@ -4,7 +4,7 @@
 
 namespace mfvit {
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GELU_BWD = 2, EPI_NONE = 3 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GELU_BWD = 2, EPI_NONE = 3, EPI_BIAS_RELU = 4 };   // 4: out0 = relu'(pre), out1 = relu(pre)
 enum { REPI_RES_LN = 0, REPI_LNBWD_RES = 1 };
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st);
@@ -48,5 +48,6 @@ int ce_small(const float* logits, const long* target, float* loss_mean, float* d
 int add_rows(float* dst, long ldd, const float* src, long lds_, int rows, int N, hipStream_t st);
 int axpy(float* y, const float* x, float a, long n, hipStream_t st);
 int colsum_rows(const float* x, long ld, float* out, int rows, int row_stride, int row_off, int N, hipStream_t st);
+int batch_sum(const float* x, float* out, int B, long n, hipStream_t st);   // out[i] += sum_b x[b * n + i]
 
 }  // namespace mfvit

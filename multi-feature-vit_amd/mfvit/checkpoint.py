@@ -42,10 +42,13 @@ def save_checkpoint(checkpoint_folder, state, is_best, filename="last_checkpoint
 
 def strip_moco_prefix(state_dict, linear_keyword="head"):
     """In-place key surgery of MAIN_SS:326-333: keep `module.base_encoder.*` except the projector (`.head`), drop the prefix,
-    delete everything else (momentum encoder, predictor, queue)."""
-    prefix = "module.base_encoder."
+    delete everything else (momentum encoder, predictor, queue).  The reference always saves from a DistributedDataParallel wrapper
+    (keys start with 'module.'); a model trained with this package's GradSync is not wrapped, so the bare `base_encoder.*` layout
+    is accepted as well (a leading 'module.' is optional)."""
+    wrapped = any(k.startswith("module.") for k in state_dict)
+    prefix = "module.base_encoder." if wrapped else "base_encoder."
     for k in list(state_dict.keys()):
-        if k.startswith("module.base_encoder") and not k.startswith("module.base_encoder.%s" % linear_keyword):
+        if k.startswith(prefix) and not k.startswith(prefix + linear_keyword):
             state_dict[k[len(prefix):]] = state_dict[k]
         del state_dict[k]
     return state_dict
@@ -70,9 +73,10 @@ def sanity_check(state_dict, pretrained, semi_supervised=False, linear_keyword="
     if isinstance(pretrained, (str, os.PathLike)):
         pretrained = torch.load(pretrained, map_location="cpu")
     pre = pretrained["state_dict"]
+    pre_prefix = "module.base_encoder." if any(k.startswith("module.") for k in pre) else "base_encoder."
     for k in list(state_dict.keys()):
         if "%s.weight" % linear_keyword in k or "%s.bias" % linear_keyword in k:
             continue
-        k_pre = "module.base_encoder." + k[len(prefix):]
+        k_pre = pre_prefix + k[len(prefix):]
         assert (state_dict[k].cpu() == pre[k_pre].cpu()).all(), "{} is changed in linear classifier training.".format(k)
     return True

@@ -91,6 +91,9 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeats):
         model = ctx.model
+        if ctx.ws is None:
+            raise _lib.MfvitError("the encoder's saved activations were already released: a second backward through the same forward "
+                                  "(retain_graph=True) is not supported - run the forward again")
         grads = model._run_backward(ctx.cfg, ctx.ws, dfeats)
         model._release_ws(ctx.ws)
         ctx.ws = None

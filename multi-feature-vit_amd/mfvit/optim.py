@@ -177,8 +177,11 @@ class SGD(_TableOptimizer):
     first update d; a zero buffer gives the same first step (momentum * 0 + d), so the kernel never needs the first-step case."""
     state_names = ("momentum_buffer",)
 
-    def __init__(self, params, lr=1e-3, momentum=0, weight_decay=0):
-        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+    def __init__(self, params, lr=1e-3, momentum=0, weight_decay=0, dampening=0, nesterov=False):
+        if dampening != 0 or nesterov:
+            raise NotImplementedError("the HIP SGD kernel implements the reference's configuration (MAIN_CA:445-448): no dampening, no nesterov")
+        # dampening / nesterov are kept in the group so that torch.optim.SGD can load this optimizer's state dict (and vice versa)
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, dampening=0, nesterov=False))
 
     @torch.no_grad()
     def step(self):

@@ -366,6 +366,7 @@ def golden_moco_forward():
         for name, p in list(m.base_encoder.named_parameters()) + [("predictor." + k_, v) for k_, v in m.predictor.named_parameters()]:
             put(d, "d." + name, p.grad)
         put(d, "pred_bn_running_mean", m.predictor[1].running_mean, full=True)   # updated TWICE per step (Q6): q pass and k pass
+        put(d, "pred_bn_running_var", m.predictor[1].running_var, full=True)     # (the mean is ~0: its input is a mean-free BN output)
         d["pred_bn_batches"] = int(m.predictor[1].num_batches_tracked)
     finally:
         torch.Tensor.cuda = real_cuda

@@ -149,6 +149,16 @@ def test_checkpoint_layouts_and_pretrained_load(tmp_path):
         ck.sanity_check(ft.state_dict(), path)
     assert ck.sanity_check(ft.state_dict(), path, semi_supervised=True)                      # skipped, MAIN_CA:1018-1020
 
+    # a model trained with this package's GradSync is not wrapped in DDP: the bare 'base_encoder.*' layout loads the same way
+    bare = ck.pretrain_checkpoint(m, opt, epoch=4, arch="vit_small")
+    assert not any(k.startswith("module.") for k in bare["state_dict"])
+    ft2 = vits.vit_small(num_classes=3, depth=1)
+    msg2 = ck.load_pretrained_backbone(ft2, bare)
+    assert set(msg2.missing_keys) == {"head.weight", "head.bias"} and not msg2.unexpected_keys
+    assert ck.sanity_check(ft2.state_dict(), bare)
+    # optimizer state dicts never carry the HIP optimizers' runtime caches (raw device addresses)
+    assert all(not k.startswith("_mfvit") for g in state["optimizer"]["param_groups"] for k in g)
+
     opt2 = torch.optim.SGD(ft.parameters(), lr=0.1)
     fin = ck.finetune_checkpoint(ft, opt2, epoch=0, arch="vit_small", best_metric_val=0.9, best_metric_val_test=0.8, best_metric_test=0.85)
     assert list(fin.keys()) == ["epoch", "arch", "state_dict", "best_metric_val_test", "best_metric_val", "best_metric_test", "optimizer"]

@@ -3,6 +3,7 @@
       train-mode BatchNorm (forward, gradients, running statistics), EMA, enqueue with pointer wrap, LARS trajectory;
   (b) the CPU oracle (oracle/ref_moco.py) for the whole forward -> InfoNCE logits -> CE -> backward.
 All in precision='fp32' (exact-f32 MFMA); tolerances 1e-3 relative (north_star), measured values logged."""
+import copy
 import os
 import types
 from functools import partial
@@ -310,3 +311,228 @@ def test_raw_pointer_updates_refresh_weight_shadows():
         ema_update_(ref.flat_parameters(), m.flat_parameters(), 0.5, ref._arena_params)
         mix = ref(x)
     assert float((mix - before).abs().max()) > 0 or torch.equal(m.flat_parameters(), ref.flat_parameters())
+
+
+def test_optimizer_state_roundtrip_and_torch_compatibility(tmp_path):
+    """(1) step -> state_dict -> torch.save / load -> load_state_dict -> step must continue exactly like torch.optim
+    (the device chunk tables are runtime caches: not pickled, rebuilt for the loaded state tensors); (2) the state uses the
+    reference's / torch's key names, so a torch.optim (or reference LARS) state dict resumes here and vice versa."""
+    from moco.optimizer import LARS
+    from mfvit.optim import SGD, Adam, AdamW
+    shapes = [(70000,), (33, 7), (5,)]
+
+    def grads(step):
+        return [rng_tensor(900 + 10 * step + i, s).to(DEV) for i, s in enumerate(shapes)]
+
+    for mine, theirs, kw, keys in ((Adam, torch.optim.Adam, dict(lr=1e-2, weight_decay=0.1), {"step", "exp_avg", "exp_avg_sq"}),
+                                   (AdamW, torch.optim.AdamW, dict(lr=1e-2, weight_decay=0.1), {"step", "exp_avg", "exp_avg_sq"}),
+                                   (SGD, torch.optim.SGD, dict(lr=0.1, momentum=0.9, weight_decay=0.01), {"momentum_buffer"})):
+        a = [torch.nn.Parameter(rng_tensor(880 + i, s).to(DEV)) for i, s in enumerate(shapes)]
+        b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+        oa, ob = mine(a, **kw), theirs(b, **kw)
+        for step in range(2):
+            for pa, pb, g_ in zip(a, b, grads(step)):
+                pa.grad, pb.grad = g_.clone(), g_.clone()
+            oa.step(); ob.step()
+        sd = oa.state_dict()
+        assert all(set(st.keys()) == keys for st in sd["state"].values()), sd["state"][0].keys()
+        assert all(not k.startswith("_mfvit") for g_ in sd["param_groups"] for k in g_), "runtime caches leaked into param_groups"
+        path = os.path.join(tmp_path, f"{mine.__name__}.pt")
+        torch.save(sd, path)
+        # resume THIS optimizer's checkpoint in a fresh instance over fresh parameter tensors (new addresses)
+        a2 = [torch.nn.Parameter(p.detach().clone()) for p in a]
+        oa2 = mine(a2, **kw)
+        oa2.load_state_dict(torch.load(path, map_location=DEV))
+        # resume the TORCH optimizer's state here, and this one's in torch
+        a3 = [torch.nn.Parameter(p.detach().clone()) for p in b]
+        oa3 = mine(a3, **kw)
+        oa3.load_state_dict(copy.deepcopy(ob.state_dict()))     # load_state_dict keeps same-device tensors by reference: copy first
+        b2 = [torch.nn.Parameter(p.detach().clone()) for p in a]
+        ob2 = theirs(b2, **kw)
+        ob2.load_state_dict(torch.load(path, map_location=DEV))
+        for step in range(2, 4):
+            for ps, o in ((a, oa), (b, ob), (a2, oa2), (a3, oa3), (b2, ob2)):
+                for p, g_ in zip(ps, grads(step)):
+                    p.grad = g_.clone()
+                o.step()
+        for pa, pb, p2, p3, q2 in zip(a, b, a2, a3, b2):
+            torch.testing.assert_close(pa.detach(), pb.detach(), rtol=2e-5, atol=2e-6)
+            assert torch.equal(p2.detach(), pa.detach()), "resumed optimizer diverged from the uninterrupted one"
+            torch.testing.assert_close(p3.detach(), pb.detach(), rtol=2e-5, atol=2e-6)
+            torch.testing.assert_close(q2.detach(), pb.detach(), rtol=2e-5, atol=2e-6)
+    # LARS: the reference's state key
+    ps = [torch.nn.Parameter(rng_tensor(870 + i, s).to(DEV)) for i, s in enumerate([(6, 5), (5,)])]
+    opt = LARS(ps, lr=0.3, weight_decay=1e-3, momentum=0.9)
+    for p in ps:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    sd = opt.state_dict()
+    assert all(set(st.keys()) == {"mu"} for st in sd["state"].values())
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = LARS(ps2, lr=0.3, weight_decay=1e-3, momentum=0.9)
+    opt2.load_state_dict(copy.deepcopy(sd))
+    for q in (ps, ps2):
+        for p in q:
+            p.grad = torch.full_like(p, 0.5)
+    opt.step(); opt2.step()
+    for p, q in zip(ps, ps2):
+        assert torch.equal(p.detach(), q.detach())
+
+
+@pytest.mark.parametrize("wrapped", [True, False])
+def test_pretrain_checkpoint_loads_into_hip_backbone_and_matches_oracle(tmp_path, wrapped):
+    """SURVEY 8 f-3 on the GPU: a MoCo pretraining checkpoint (DDP-style 'module.' keys as the reference saves them,
+    MAIN_MOCO:461-467, or the bare layout of an unwrapped model) goes through the reference's key surgery (MAIN_SS:326-337) into
+    a HIP vit_small(num_classes=3); its logits must be the oracle's on the SAME weights, and the linear-probe sanity check
+    (MAIN_CA:1013-1040) must hold."""
+    import vits
+    from mfvit import checkpoint as ck
+    from moco.optimizer import LARS
+    depth = 2
+    moco = make_moco(depth=depth, mlp_dim=128, precision="bf16x3")
+    moco.base_encoder.load_state_dict(ref_vit.seeded_params(951, num_classes=0, depth=depth), strict=False)
+    moco = moco.to(DEV)
+    opt = LARS(moco.parameters(), 0.3, weight_decay=1e-6, momentum=0.9)
+    state = ck.pretrain_checkpoint(moco, opt, epoch=7, arch="vit_small")
+    if wrapped:
+        state["state_dict"] = {"module." + k: v for k, v in state["state_dict"].items()}
+    path = ck.save_checkpoint(str(tmp_path), state, is_best=False, filename="checkpoint_0007.pth.tar")
+    torch.manual_seed(3)
+    ft = vits.vit_small(num_classes=3, depth=depth, precision="bf16x3")
+    msg = ck.load_pretrained_backbone(ft, path)
+    assert set(msg.missing_keys) == {"head.weight", "head.bias"} and not msg.unexpected_keys
+    ft = ft.to(DEV)
+    assert ck.sanity_check(ft.state_dict(), path)
+    p = {k: v.detach().cpu() for k, v in ft.state_dict().items()}
+    x = rng_tensor(952, (3, 3, 224, 224))
+    with torch.no_grad():
+        ref_f = ref_vit.features3d(p, x)
+        ref_l = ref_vit.head_linear(p, ref_f[:, 0])
+        logits = ft(x.to(DEV))
+    e = scale_err(logits, ref_l)
+    log(f"f-3 checkpoint -> HIP backbone (wrapped={wrapped}): logits err {e:.2e}")
+    assert e < 1e-3 and logits.argmax(1).cpu().tolist() == ref_l.argmax(1).tolist()
+    for k, v in moco.base_encoder.state_dict().items():
+        if not k.startswith("head."):
+            assert torch.equal(ft.state_dict()[k], v), k
+
+
+class _ToyEncoder(torch.nn.Module):
+    """Stand-in encoder of the reference-generated MoCo.forward golden (oracle/make_golden.py::golden_moco_forward): a 12 -> 128
+    Linear body in front of `head`.  Carries the flat-arena interface the HIP builder's momentum update works on."""
+
+    def __init__(self, num_classes=1000, **_):
+        super().__init__()
+        from mfvit.arena import ParamArena
+        self.precision = "fp32"
+        self.body = torch.nn.Linear(12, 128)
+        self.head = torch.nn.Linear(128, num_classes)
+        self._pa = ParamArena
+
+    def _arena(self):
+        a = getattr(self, "_arena_obj", None)
+        if a is None or not a.intact() or a.flat.device != self.body.weight.device:
+            a = self._arena_obj = self._pa(list(self.body.named_parameters()))
+        return a
+
+    @property
+    def _arena_params(self):
+        return self._arena().params
+
+    def flat_parameters(self):
+        return self._arena().ensure()
+
+    def forward(self, x):
+        return self.head(self.body(x))
+
+
+def test_moco_forward_against_the_references_own_forward():
+    """The HIP builder's MoCo_ViT.forward (EMA, key path with the shared predictor, logits, enqueue with pointer wrap) against the
+    REFERENCE's MoCo.forward output on the same toy encoder, weights, queue and inputs (tests/golden/moco_forward.npz, BLD:154-199)."""
+    import moco.builder_vit_mocov3structure_mocov2loss as bld
+    from mfvit.moco_ops import cross_entropy_rows
+    from test_oracle_golden import moco_forward_golden_params
+    g = np.load(os.path.join(GOLDEN, "moco_forward.npz"), allow_pickle=False)
+    n, T, mval, K = int(g["n"]), float(g["T"]), float(g["m"]), int(g["K"])
+    W, queue = moco_forward_golden_params(g)
+    m = bld.MoCo_ViT(_ToyEncoder, types.SimpleNamespace(arch="vit_small"), 256, 128, T)
+    assert set(m.state_dict().keys()) == set(str(k) for k in g["state_keys"])                  # same layout as the reference's module
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            p.copy_(W[name].float())
+        m.queue.copy_(queue.float())
+        m.queue_ptr[0] = int(g["ptr_before"])
+    m = m.to(DEV).train()
+    im_q = rng_tensor(int(g["seed_q"]), (n, 12)).to(DEV)
+    im_k = rng_tensor(int(g["seed_k"]), (n, 12)).to(DEV)
+    logits, labels = m(im_q, im_k, mval)
+    loss = cross_entropy_rows(logits, labels)
+    loss.backward()
+    check_sampled(g, "logits", logits, rtol=1e-3, atol=2e-4)
+    e_head = scale_err(logits[:, :16], torch.from_numpy(g["logits_head"]))
+    assert labels.cpu().tolist() == g["labels"].tolist()
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    assert int(m.queue_ptr) == int(g["ptr_after"]) == 0
+    e_q = scale_err(m.queue[:, K - n:], torch.from_numpy(g["queue_tail"]))
+    for name, p in m.momentum_encoder.named_parameters():
+        check_sampled(g, "mom." + name, p, rtol=1e-5, atol=1e-6)
+    worst = 0.0
+    named = list(m.base_encoder.named_parameters()) + [("predictor." + k_, v) for k_, v in m.predictor.named_parameters()]
+    # gradients that are mathematically zero (a bias in front of a BatchNorm: body.bias) are rounding noise on both sides: the
+    # absolute tolerance is tied to the largest mean |gradient| of the model
+    gscale = max(float(g[f"d.{name}.abssum"]) / p.numel() for name, p in named)
+    for name, p in named:
+        check_sampled(g, "d." + name, p.grad, rtol=2e-3, atol=2e-3 * max(float(g[f"d.{name}.abssum"]) / p.numel(), 1e-2 * gscale))
+    assert int(m.predictor[1].num_batches_tracked) == int(g["pred_bn_batches"]) == 2          # Q6: BN stats updated by q AND k passes
+    # running_var after BOTH updates; the running mean's input is a mean-free BN output (numerically zero on both sides)
+    e_rv = scale_err(m.predictor[1].running_var, torch.from_numpy(g["pred_bn_running_var"]))
+    assert float(m.predictor[1].running_mean.abs().max()) < 1e-5 and float(np.abs(g["pred_bn_running_mean"]).max()) < 1e-12
+    log(f"MoCo.forward vs reference forward golden: logits[:, :16] {e_head:.2e} queue tail {e_q:.2e} predictor BN running_var {e_rv:.2e}")
+    assert e_head < 1e-3 and e_q < 1e-4 and e_rv < 1e-4 and worst == 0.0
+
+
+def test_fp16_moco_step_with_grad_scaler():
+    """configs[3]/[4] arithmetic (MAIN_MOCO:349,533,546-548): MoCo step with fp16 MFMA operands and loss scaling.  Against the f64
+    oracle on the same weights: logits at fp16 accuracy; after scaler.step the parameters moved exactly as an unscaled-gradient AdamW
+    step would move them (gradients are unscaled in place by mfvit_amp_unscale before the optimizer kernel reads them)."""
+    from mfvit.amp import GradScaler
+    from mfvit.moco_ops import cross_entropy_rows
+    from mfvit.optim import AdamW
+    depth, n, T, mval = 2, 8, 0.2, 0.99
+    m16 = make_moco(depth=depth, mlp_dim=512, T=T, precision="fp16")
+    m32 = make_moco(depth=depth, mlp_dim=512, T=T, precision="fp32")
+    sd = ref_vit.seeded_params(961, num_classes=0, depth=depth)
+    for mm in (m16, m32):
+        mm.base_encoder.load_state_dict(sd, strict=False)
+        mm.momentum_encoder.load_state_dict(sd, strict=False)
+    m32.load_state_dict(m16.state_dict())
+    m16, m32 = m16.to(DEV).train(), m32.to(DEV).train()
+    im_q, im_k = rng_tensor(962, (n, 3, 224, 224)).to(DEV), rng_tensor(963, (n, 3, 224, 224)).to(DEV)
+    scaler = GradScaler(init_scale=2.0 ** 14)
+    opt = AdamW([p for p in m16.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.1)
+    before = {k: v.detach().clone() for k, v in m16.named_parameters() if v.requires_grad}
+    logits, labels = m16(im_q, im_k, mval)
+    loss = cross_entropy_rows(logits, labels)
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    l32, lab32 = m32(im_q, im_k, mval)
+    loss32 = cross_entropy_rows(l32, lab32)
+    loss32.backward()
+    e_l = scale_err(logits, l32)
+    assert e_l < 1e-2 and abs(float(loss) - float(loss32)) < 2e-3 * abs(float(loss32))
+    # gradients after the unscale == the f32 model's gradients at fp16 accuracy.  Per tensor, relative L2 error; tensors whose
+    # gradient is tiny beside the largest one (mathematically-zero gradients in front of a BatchNorm, fp16 underflow territory) are
+    # compared against that largest norm instead.
+    g32 = dict(m32.named_parameters())
+    gmax = max(float(v.grad.norm()) for v in g32.values() if v.grad is not None)
+    worst, worst_name = 0.0, ""
+    for k, p in m16.named_parameters():
+        if p.grad is None:
+            continue
+        e = float((p.grad - g32[k].grad).norm()) / max(float(g32[k].grad.norm()), 1e-2 * gmax)
+        if e > worst:
+            worst, worst_name = e, k
+    moved = sum(float((p.detach() - before[k]).abs().max()) > 0 for k, p in m16.named_parameters() if k in before)
+    log(f"fp16 MoCo step + GradScaler: logits {e_l:.2e} vs fp32 model, worst unscaled-gradient L2 err {worst:.2e} ({worst_name}), {moved} tensors stepped, scale {scaler.get_scale()}")
+    assert worst < 5e-2 and moved == len(before) and scaler.get_scale() == 2.0 ** 14

@@ -8,7 +8,19 @@ dev = torch.device("cuda:0")
 M, D = 128 * 197, 384
 op = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-def r(*s, dt=torch.bfloat16, sc=1.0): return (torch.randn(*s, device=dev) * sc).to(dt)
+prec = sys.argv[3] if len(sys.argv) > 3 else "bf16"      # bf16 | bf16x3 | fp16
+SPLIT = prec == "bf16x3"
+def r(*s, dt=None, sc=1.0):
+    x = torch.randn(*s, device=dev) * sc
+    if dt is not None: return x.to(dt)
+    if SPLIT: return ops.split_pack(x)
+    return x.to(torch.float16 if prec == "fp16" else torch.bfloat16)
+_lf, _wg, _rl, _db, _af, _ab = ops.linear_fwd, ops.linear_wgrad, ops.linear_res_ln_fwd, ops.linear_dgrad_ln_bwd, ops.attention_fwd, ops.attention_bwd
+if SPLIT:
+    import functools
+    ops.linear_fwd, ops.linear_wgrad = functools.partial(_lf, split=True), functools.partial(_wg, split=True)
+    ops.linear_res_ln_fwd, ops.linear_dgrad_ln_bwd = functools.partial(_rl, split=True), functools.partial(_db, split=True)
+    ops.attention_fwd, ops.attention_bwd = functools.partial(_af, split=True), functools.partial(_ab, split=True)
 if op == "qkv":
     x, w, b = r(M, D), r(3 * D, D, sc=.05), r(3 * D, dt=torch.float32)
     fn = lambda: ops.linear_fwd(x, w, b)

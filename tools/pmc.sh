@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): bash tools/pmc.sh <tag> <op> ; writes gpurun_out/pmc_<tag>/pass*/ csv + summary
+# usage (on the GPU box, from the repo root): bash tools/pmc.sh <tag> <op> [precision] ; writes gpurun_out/pmc_<tag>/pass*/ csv + summary
 set -e
-tag=$1; op=$2
+tag=$1; op=$2; prec=${3:-bf16}
 R=$(pwd)
 out=$R/gpurun_out/pmc_$tag
 mkdir -p $out
@@ -14,7 +14,7 @@ P5="WRITE_SIZE"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $out/pass$i -- python3 $R/tools/one_op.py $op 4 > $out/pass$i.log 2>&1 || { rc=$?; echo "pass $i failed (rc $rc): not starting further passes on this box" >&2; tail -20 $out/pass$i.log >&2; exit $rc; }
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $out/pass$i -- python3 $R/tools/one_op.py $op 4 $prec > $out/pass$i.log 2>&1 || { rc=$?; echo "pass $i failed (rc $rc): not starting further passes on this box" >&2; tail -20 $out/pass$i.log >&2; exit $rc; }
 done
 cd $R
 python3 tools/pmc_summary.py $out

@@ -1,14 +1,18 @@
 """Summarise the rocprofv3 outputs of tools/profile_bench.sh: kernel_stats.csv + HBM traffic per launch / per mfvit_prof class."""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 
 out = sys.argv[1]
+precision = sys.argv[2] if len(sys.argv) > 2 else "bf16x3"
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multi-feature-vit_amd"))
+from mfvit._lib import source_hash  # noqa: E402
 
 
 def klass(name):
     if "gemm_tn_kernel" in name or "gemm_tn_glds_kernel" in name:
         return "gemm_tn_wgrad"
     if "gemm_nt_row_kernel" in name:
-        return "gemm_nt_row_res_ln" if "gemm_nt_row_kernelIDF16bLi0E" in name or "gemm_nt_row_kernelIfLi0E" in name else "gemm_nt_row_lnbwd"
+        # first template argument = element type, second = the epilogue (0: residual + LayerNorm forward, 1: LayerNorm backward)
+        return "gemm_nt_row_res_ln" if re.search(r"gemm_nt_row_kernelI(DF16b|DF16_|f|NS_5sbf16E)Li0E", name) or re.search(r"gemm_nt_row_kernel<[^,]+, 0,", name) else "gemm_nt_row_lnbwd"
     if "gemm_nt_tile_kernel" in name or "gemm_nt_pers_kernel" in name:
         return "gemm_nt_tile"
     if "attn_fwd" in name:
@@ -47,6 +51,6 @@ for name in sorted(set(vals["fetch"]) | set(vals["write"])):
 src = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`, "
        "MI355X; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section)")
 json.dump(dict(source=src, per_kernel=per_launch), open(os.path.join(out, "hbm_traffic_per_launch.json"), "w"), indent=1)
-json.dump(dict(source=src, per_class={c: dict(hbm_bytes_per_launch=int(b / n), launches_sampled=n) for c, (b, n) in by_class.items()}),
+json.dump(dict(source=src, source_hash=source_hash(), precision=precision, per_class={c: dict(hbm_bytes_per_launch=int(b / n), launches_sampled=n) for c, (b, n) in by_class.items()}),
           open(os.path.join(out, "hbm_traffic_by_class.json"), "w"), indent=1)
 print(json.dumps({c: round(b / n / 1e6, 1) for c, (b, n) in by_class.items()}))
