@@ -57,6 +57,13 @@ typedef struct mfvit_vit_cfg {
     int save_for_backward; /* 1: keep per-layer activations in the workspace */
     int stop_grad_conv1; /* 1: no gradient for patch_embed.proj.{weight,bias} (MAIN_MOCO:127-128,274) */
     float ln_eps;        /* 1e-6 */
+    /* ---- token-input ("GPT") mode: the TransFuser fusion transformer of fuseattention.py:84-212 is the same pre-LN block stack
+     * (separate query / key / value Linears = one packed [3 dim][dim] weight, ReLU MLP, LayerNorm eps 1e-5) fed with tokens
+     * instead of image patches; mfvit_gpt_forward / mfvit_gpt_backward run it through the encoder's kernels. */
+    int token_input;     /* 0: ViT-S/16 (patch embedding + cls token); 1: the input is a (batch, tokens, dim) f32 tensor */
+    int tokens;          /* token_input: sequence length (394 = 2 x 197 joint CXR + ENH tokens) */
+    int use_pos;         /* token_input: add the learnable pos_emb (args.pos_embed, fuseattention.py:186-189) */
+    int act;             /* MLP activation: 0 erf-GELU (timm Block), 1 ReLU (fuseattention.py:67-72) */
 } mfvit_vit_cfg;
 
 /* Parameter arena: one contiguous f32 buffer, tensors in timm registration order
@@ -88,6 +95,19 @@ int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void*
  * dfeatures: (B,T,dim) f32, read only when stage_hi == depth. */
 int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, void* workspace, const float* dfeatures,
                        float* dparams, int stage_hi, int stage_lo, mfvit_stream_t stream);
+
+/* Token-input encoder (cfg->token_input = 1): the GPT of the TransFuser fusion (fuseattention.py:84-212), heads x head_dim with
+ * head_dim in {32, 64, 96} (config.py: n_embd 384, n_head 4 -> 96), mlp_dim = block_exp * dim.
+ * Parameter arena (f32): pos_emb [tokens][dim], then per block
+ *   ln1.weight, ln1.bias, attn.{query,key,value}.weight as one [3 dim][dim] matrix, attn.{query,key,value}.bias [3 dim],
+ *   attn.proj.weight, attn.proj.bias, ln2.weight, ln2.bias, mlp.0.weight, mlp.0.bias, mlp.2.weight, mlp.2.bias,
+ * then ln_f.weight, ln_f.bias.  (mfvit_vit_param_layout: [0] = [1] = 0 pos_emb, [2] = [3] = first block, no patch embedding.)
+ * forward : out = ln_f(blocks(tokens + pos_emb))   (B, tokens, dim) f32            (fuseattention.py:186-192; dropouts are identity)
+ * backward: dtokens (B, tokens, dim) f32 = d loss / d tokens; dparams accumulated (pos_emb gradient = sum over the batch). */
+int mfvit_gpt_forward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, const float* tokens, void* workspace, float* out,
+                      mfvit_stream_t stream);
+int mfvit_gpt_backward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, void* workspace, const float* dout, float* dparams,
+                       float* dtokens, mfvit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Single ops (exposed for parity tests and for the MoCo projector / predictor path).

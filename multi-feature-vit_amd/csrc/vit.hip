@@ -16,19 +16,25 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Dims {
     int dtype, B, T, np, D, depth, H, HD, F, M, Mp, es, ep;   // es: bytes per LOGICAL element of a dtype tensor; ep: storage elements per logical one
-    bool save;
+    bool save, tok, use_pos;
+    int act;
 };
 
 bool get_dims(const mfvit_vit_cfg* c, Dims& d) {
     if (!c) return false;
     if (c->dtype != MFVIT_F32 && c->dtype != MFVIT_BF16 && c->dtype != MFVIT_BF16X3 && c->dtype != MFVIT_F16) return false;
-    if (c->batch <= 0 || c->img_h <= 0 || c->img_w <= 0 || c->img_h % 16 || c->img_w % 16) return false;
+    d.tok = c->token_input != 0;
+    if (c->batch <= 0) return false;
+    if (d.tok ? c->tokens <= 0 : (c->img_h <= 0 || c->img_w <= 0 || c->img_h % 16 || c->img_w % 16)) return false;
+    if (c->act != 0 && c->act != 1) return false;
     if (c->dim != 384 || c->depth <= 0 || c->heads <= 0 || c->dim % c->heads) return false;
     if (c->mlp_dim % 128 || c->mlp_dim <= 0) return false;
     d.dtype = c->dtype;
     d.B = c->batch;
-    d.np = (c->img_h / 16) * (c->img_w / 16);
-    d.T = d.np + 1;
+    d.np = d.tok ? c->tokens : (c->img_h / 16) * (c->img_w / 16);
+    d.T = d.tok ? c->tokens : d.np + 1;
+    d.use_pos = c->use_pos != 0;
+    d.act = c->act;
     d.D = c->dim;
     d.depth = c->depth;
     d.H = c->heads;
@@ -39,8 +45,9 @@ bool get_dims(const mfvit_vit_cfg* c, Dims& d) {
     d.es = (c->dtype == MFVIT_BF16 || c->dtype == MFVIT_F16) ? 2 : 4;   // split bf16: hi + lo = 4 bytes
     d.ep = c->dtype == MFVIT_BF16X3 ? 2 : 1;
     d.save = c->save_for_backward != 0;
-    if (d.HD != 32 && d.HD != 64) return false;
-    if (c->dtype == MFVIT_BF16X3 && d.HD != 32) return false;   // a head's row piece is one [hi x 32 | lo x 32] group
+    if (d.HD != 32 && d.HD != 64 && d.HD != 96) return false;
+    if (d.HD == 96 && c->dtype == MFVIT_F32) return false;      // head_dim 96 runs on the streaming MFMA kernels (16-bit types, split bf16)
+    if (c->dtype == MFVIT_BF16X3 && d.HD % 32) return false;    // a head's row piece is whole [hi x 32 | lo x 32] groups
     return true;
 }
 
@@ -54,10 +61,10 @@ ParamLayout param_layout(const Dims& d) {
     ParamLayout L;
     const long D = d.D, F = d.F;
     long o = 0;
-    L.cls = o; o += D;
+    L.cls = o; o += d.tok ? 0 : D;                   // token-input mode: no cls token, no patch embedding
     L.pos = o; o += (long)d.T * D;
-    L.pe_w = o; o += D * 768;
-    L.pe_b = o; o += D;
+    L.pe_w = o; o += d.tok ? 0 : D * 768;
+    L.pe_b = o; o += d.tok ? 0 : D;
     L.blk0 = o;
     long b = 0;
     L.ln1_w = b; b += D;
@@ -92,7 +99,7 @@ ShadowLayout shadow_layout(const Dims& d) {
     const size_t D = d.D, F = d.F, es = d.es;
     const bool hw = d.dtype != MFVIT_F32;  // keep straight copies only when a cast is needed
     size_t o = 0;
-    S.pe_w = o; o += hw ? align256(D * 768 * es) : 0;
+    S.pe_w = o; o += (hw && !d.tok) ? align256(D * 768 * es) : 0;
     S.blk0 = o;
     size_t b = 0;
     S.qkv_w = b; b += hw ? align256(3 * D * D * es) : 0;
@@ -126,7 +133,7 @@ WsLayout ws_layout(const Dims& d) {
     const size_t M = d.M, D = d.D, F = d.F, es = d.es;
     const size_t nl = d.save ? d.depth : 1;
     size_t o = 0;
-    W.patches = o; o += align256((size_t)d.Mp * 768 * es);
+    W.patches = o; o += d.tok ? 0 : align256((size_t)d.Mp * 768 * es);
     W.x0 = o; W.x_stride = align256(M * D * 4); o += W.x_stride * (d.save ? d.depth + 1 : 1);
     W.st0 = o; W.st_stride = align256(2 * M * 4); o += W.st_stride * (d.save ? d.depth + 1 : 1);
     W.blk0 = o;
@@ -262,7 +269,7 @@ int mfvit_vit_prepare_shadow(const mfvit_vit_cfg* cfg, const float* params, void
     const ShadowLayout S = shadow_layout(d);
     char* sh = (char*)shadow;
     const bool hw = d.dtype != MFVIT_F32;
-    if (hw) MFVIT_TRY(cast_transpose(d.dtype, params + L.pe_w, sh + S.pe_w, nullptr, d.D, 768, st));
+    if (hw && !d.tok) MFVIT_TRY(cast_transpose(d.dtype, params + L.pe_w, sh + S.pe_w, nullptr, d.D, 768, st));
     // one launch per weight type covers all `depth` blocks (identical shapes at fixed arena / shadow strides)
     const float* pb = params + L.blk0;
     char* sb = sh + S.blk0;
@@ -274,10 +281,15 @@ int mfvit_vit_prepare_shadow(const mfvit_vit_cfg* cfg, const float* params, void
     return MFVIT_OK;
 }
 
-int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, const float* img, void* workspace,
-                      float* features, mfvit_stream_t stream) {
+}  // extern "C"
+
+// Shared forward of the two front ends: ViT-S/16 (img = (B,3,H,W) image, patch embedding + cls token) and the token-input GPT
+// (img = (B,T,dim) tokens, + pos_emb).  Everything behind x_0 / LN1_0 is the same pre-LN block stack.
+static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, const float* img, void* workspace,
+                           float* features, mfvit_stream_t stream, bool want_tokens) {
     Dims d;
     if (!get_dims(cfg, d) || !params || !shadow || !img || !workspace || !features) return MFVIT_EINVAL;
+    if (d.tok != want_tokens) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const ParamLayout L = param_layout(d);
     const ShadowLayout S = shadow_layout(d);
@@ -294,6 +306,11 @@ int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void*
     auto pblk = [&](int l) { return params + L.blk0 + (long)l * L.blk_stride; };
     auto sblk = [&](int l) { return sh + S.blk0 + (size_t)l * S.blk_stride; };
 
+    if (d.tok) {
+        // token input (fuseattention.py:186-189): x_0 = tokens (+ pos_emb, shared by the batch); LN1_0 -> y1_0.  One row kernel pass.
+        MFVIT_TRY(ln_rows(d.dtype, d.D, img, D, d.use_pos ? params + L.pos : nullptr, D, d.T, xbuf(0), D, blk(0) + W.y1, D * e, 0,
+                          pblk(0) + L.ln1_w, pblk(0) + L.ln1_b, eps, stat(0), stat(0) + d.M, d.M, 1, 0, 0, st));
+    } else {
     // patch embedding: im2col -> row-complete GEMM (+bias +pos_embed) -> x_0, LN1_0 -> y1_0
     MFVIT_TRY(im2col16(d.dtype, img, ws + W.patches, d.B, cfg->img_h, cfg->img_w, st));
     {
@@ -313,6 +330,7 @@ int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void*
     // cls rows: x_0[b,0] = cls_token + pos_embed[0]; LN1_0
     MFVIT_TRY(ln_rows(d.dtype, d.D, params + L.cls, 0, params + L.pos, D, 1, xbuf(0), D, blk(0) + W.y1, D * e, 0, pblk(0) + L.ln1_w,
                       pblk(0) + L.ln1_b, eps, stat(0), stat(0) + d.M, d.B, d.T, 0, 1, st));
+    }
 
     for (int l = 0; l < d.depth; ++l) {
         char* b = blk(l);
@@ -349,7 +367,7 @@ int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void*
             p.bias = pb + L.fc1_b;
             p.out0 = b + W.hpre; p.ldo0 = F * e;
             p.out1 = b + W.hact; p.ldo1 = F * e;
-            MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS_GELU, p, st));
+            MFVIT_TRY(gemm_nt_tile(d.dtype, d.act == 1 ? EPI_BIAS_RELU : EPI_BIAS_GELU, p, st));
         }
         {   // x_{l+1} = xmid + hact W2^T + b2 ; y = LN(next norm1 | final norm)
             const bool last = l + 1 == d.depth;
@@ -375,11 +393,12 @@ int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void*
     return MFVIT_OK;
 }
 
-int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, void* workspace, const float* dfeatures,
-                       float* dparams, int stage_hi, int stage_lo, mfvit_stream_t stream) {
+// Shared backward; dinput (token-input mode only): d loss / d tokens, written by the embedding stage.
+static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, void* workspace, const float* dfeatures,
+                            float* dparams, float* dinput, int stage_hi, int stage_lo, mfvit_stream_t stream, bool want_tokens) {
     Dims d;
     if (!get_dims(cfg, d) || !params || !shadow || !workspace || !dparams) return MFVIT_EINVAL;
-    if (!d.save) return MFVIT_EINVAL;
+    if (!d.save || d.tok != want_tokens) return MFVIT_EINVAL;
     if (stage_hi > d.depth || stage_lo < -1 || stage_lo > stage_hi) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const ParamLayout L = param_layout(d);
@@ -520,6 +539,11 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
                 p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = l > 0 ? gblk(l - 1) + L.fc2_b : colscr; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
+        } else if (d.tok) {
+            // token-input embedding stage: gx = d x_0 = d tokens; d pos_emb = sum over the batch (fuseattention.py:187)
+            if (dinput && hipMemcpyAsync(dinput, gx, (size_t)d.M * D * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+                return MFVIT_ELAUNCH;
+            if (d.use_pos) MFVIT_TRY(batch_sum(gx, dparams + L.pos, d.B, (long)d.T * D, st));
         } else {
             // embed stage: gx = d x_0.  d cls_token = sum_b gx[b,0]; d pe_b = sum over patch rows; d pe_w = gx_patch^T patches.
             // pos_embed is a fixed table (requires_grad = False upstream): no gradient.
@@ -542,6 +566,26 @@ int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void
         if (hipEventRecord(ss.end, ss.s) != hipSuccess || hipStreamWaitEvent(st, ss.end, 0) != hipSuccess) return MFVIT_ELAUNCH;
     }
     return MFVIT_OK;
+}
+
+extern "C" {
+
+int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, const float* img, void* workspace,
+                      float* features, mfvit_stream_t stream) {
+    return encoder_forward(cfg, params, shadow, img, workspace, features, stream, false);
+}
+int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, void* workspace, const float* dfeatures,
+                       float* dparams, int stage_hi, int stage_lo, mfvit_stream_t stream) {
+    return encoder_backward(cfg, params, shadow, workspace, dfeatures, dparams, nullptr, stage_hi, stage_lo, stream, false);
+}
+int mfvit_gpt_forward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, const float* tokens, void* workspace, float* out,
+                      mfvit_stream_t stream) {
+    return encoder_forward(cfg, params, shadow, tokens, workspace, out, stream, true);
+}
+int mfvit_gpt_backward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, void* workspace, const float* dout, float* dparams,
+                       float* dtokens, mfvit_stream_t stream) {
+    if (!cfg || !dtokens || !dout) return MFVIT_EINVAL;
+    return encoder_backward(cfg, params, shadow, workspace, dout, dparams, dtokens, cfg->depth, -1, stream, true);
 }
 
 // ------------------------------------------------------------------------------------------------ single ops

@@ -21,7 +21,7 @@ EPI_BIAS, EPI_BIAS_GELU, EPI_NONE = 0, 1, 3
 class VitCfg(Structure):
     _fields_ = [("dtype", c_int), ("batch", c_int), ("img_h", c_int), ("img_w", c_int), ("dim", c_int), ("depth", c_int),
                 ("heads", c_int), ("mlp_dim", c_int), ("save_for_backward", c_int), ("stop_grad_conv1", c_int),
-                ("ln_eps", c_float)]
+                ("ln_eps", c_float), ("token_input", c_int), ("tokens", c_int), ("use_pos", c_int), ("act", c_int)]
 
 
 class FusionCfg(Structure):
@@ -45,6 +45,8 @@ SIGNATURES = {
     "mfvit_vit_workspace_bytes": (c_size_t, [POINTER(VitCfg)]),
     "mfvit_vit_forward": (I, [POINTER(VitCfg), P, P, P, P, P, P]),
     "mfvit_vit_backward": (I, [POINTER(VitCfg), P, P, P, P, P, I, I, P]),
+    "mfvit_gpt_forward": (I, [POINTER(VitCfg), P, P, P, P, P, P]),
+    "mfvit_gpt_backward": (I, [POINTER(VitCfg), P, P, P, P, P, P, P]),
     "mfvit_linear_fwd": (I, [I, I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
     "mfvit_linear_fwd_persistent": (I, [I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
     "mfvit_linear_fwd_ws": (I, [I, P, L, P, L, P, P, L, P, L, I, I, I, P]),

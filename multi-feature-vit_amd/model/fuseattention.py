@@ -1,0 +1,184 @@
+"""Drop-in for the reference's TransFuser-style fusion (moco_pretraining/moco/model/fuseattention.py): the same
+classes, constructor signatures, parameter names and state-dict keys
+
+    SelfAttention(n_embd, n_head, attn_pdrop, resid_pdrop)            fuseattention.py:21-58
+    Block(n_embd, n_head, block_exp, attn_pdrop, resid_pdrop)         :60-82
+    GPT(n_embd, n_head, block_exp, n_layer, vert_anchors, horz_anchors, seq_len, embd_pdrop, attn_pdrop, resid_pdrop, args, config)   :84-212
+    Encoder(model_cxr, model_enh, config, args)                       :215-323
+    TransFuser(model_cxr, model_enh, config, args)                    :330-395
+
+with ``GPT.forward`` (8 blocks of 4-head x 96 joint self-attention over the 2 x 197 CXR + ENH tokens, ReLU MLP) running as ONE
+composite call on the gfx950 kernels (mfvit_gpt_forward / mfvit_gpt_backward: the ViT encoder's GEMM / LayerNorm kernels, the
+streaming MFMA attention of csrc/attention_tiled.hip for head_dim 96).
+
+Scope notes (stated, not silent):
+  * the ViT branch only (``args.arch`` starting with 'vit'); the ResNet branch (:105, :176-184, :198-203) is the CNN path (SURVEY §2
+    out-of-scope rows) and raises NotImplementedError;
+  * dropout: the kernels have no dropout stage.  Eval mode and p = 0 are exact; TRAINING with a non-zero embd / attn / resid
+    dropout (config.py:40-42 sets 0.1) raises NotImplementedError instead of silently training without it;
+  * ``Block`` / ``SelfAttention`` are parameter holders here (the reference only ever runs them inside ``GPT``): their own
+    ``forward`` raises.
+"""
+import torch
+import torch.nn as nn
+
+from mfvit.encoder import _HeadFn, default_precision
+from mfvit.gpt import GptEngine
+
+
+def _init_linear(m):
+    m.weight.data.normal_(mean=0.0, std=0.02)                      # fuseattention.py:125-129
+    if m.bias is not None:
+        m.bias.data.zero_()
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, n_embd, n_head, attn_pdrop, resid_pdrop):
+        super().__init__()
+        assert n_embd % n_head == 0
+        self.key = nn.Linear(n_embd, n_embd)
+        self.query = nn.Linear(n_embd, n_embd)
+        self.value = nn.Linear(n_embd, n_embd)
+        self.attn_drop = nn.Dropout(attn_pdrop)
+        self.resid_drop = nn.Dropout(resid_pdrop)
+        self.proj = nn.Linear(n_embd, n_embd)
+        self.n_head = n_head
+
+    def forward(self, x):
+        raise NotImplementedError("SelfAttention runs inside GPT.forward on the HIP path (the reference never calls it on its own)")
+
+
+class Block(nn.Module):
+    def __init__(self, n_embd, n_head, block_exp, attn_pdrop, resid_pdrop):
+        super().__init__()
+        self.ln1 = nn.LayerNorm(n_embd)
+        self.ln2 = nn.LayerNorm(n_embd)
+        self.attn = SelfAttention(n_embd, n_head, attn_pdrop, resid_pdrop)
+        self.mlp = nn.Sequential(nn.Linear(n_embd, block_exp * n_embd), nn.ReLU(True), nn.Linear(block_exp * n_embd, n_embd),
+                                 nn.Dropout(resid_pdrop))
+
+    def forward(self, x):
+        raise NotImplementedError("Block runs inside GPT.forward on the HIP path (the reference never calls it on its own)")
+
+
+class GPT(nn.Module):
+    """fuseattention.py:84-212.  ``precision`` (extra keyword, default = the package default 'bf16x3'): MFMA operand type of the
+    GEMMs / attention; head_dim 96 has no exact-f32 kernel, so 'fp32' is refused."""
+
+    def __init__(self, n_embd, n_head, block_exp, n_layer, vert_anchors, horz_anchors, seq_len, embd_pdrop, attn_pdrop, resid_pdrop,
+                 args, config, precision=None):
+        super().__init__()
+        self.n_embd = n_embd
+        self.seq_len = seq_len
+        self.vert_anchors = vert_anchors
+        self.horz_anchors = horz_anchors
+        self.config = config
+        self.args = args
+        if args.arch.startswith('res'):
+            raise NotImplementedError("the ResNet branch of the TransFuser GPT (fuseattention.py:105,176-184) is the CNN path: out of scope")
+        self.n_tokens = ((self.config.n_views + 1) * seq_len * vert_anchors * horz_anchors) + 2           # :107
+        self.pos_emb = nn.Parameter(torch.zeros(1, self.n_tokens, n_embd))
+        self.drop = nn.Dropout(embd_pdrop)
+        self.blocks = nn.Sequential(*[Block(n_embd, n_head, block_exp, attn_pdrop, resid_pdrop) for _ in range(n_layer)])
+        self.ln_f = nn.LayerNorm(n_embd)
+        self.block_size = seq_len
+        self._pdrops = (embd_pdrop, attn_pdrop, resid_pdrop)
+        self.apply(self._init_weights)
+        self.precision = precision or default_precision()
+        self._engine = None
+        self._engine_cfg = (n_embd, n_layer, n_head, block_exp * n_embd)
+
+    def get_block_size(self):
+        return self.block_size
+
+    def _init_weights(self, module):
+        if isinstance(module, nn.Linear):
+            _init_linear(module)
+        elif isinstance(module, nn.LayerNorm):
+            module.bias.data.zero_()
+            module.weight.data.fill_(1.0)
+
+    def arena_named_parameters(self):
+        """Parameters in the C ABI's arena order (include/mfvit.h, mfvit_gpt_forward): query / key / value back to back = the packed
+        [3 dim][dim] qkv weight of the encoder kernels."""
+        out = [("pos_emb", self.pos_emb)]
+        for i, b in enumerate(self.blocks):
+            p = f"blocks.{i}."
+            out += [(p + "ln1.weight", b.ln1.weight), (p + "ln1.bias", b.ln1.bias),
+                    (p + "attn.query.weight", b.attn.query.weight), (p + "attn.key.weight", b.attn.key.weight),
+                    (p + "attn.value.weight", b.attn.value.weight), (p + "attn.query.bias", b.attn.query.bias),
+                    (p + "attn.key.bias", b.attn.key.bias), (p + "attn.value.bias", b.attn.value.bias),
+                    (p + "attn.proj.weight", b.attn.proj.weight), (p + "attn.proj.bias", b.attn.proj.bias),
+                    (p + "ln2.weight", b.ln2.weight), (p + "ln2.bias", b.ln2.bias),
+                    (p + "mlp.0.weight", b.mlp[0].weight), (p + "mlp.0.bias", b.mlp[0].bias),
+                    (p + "mlp.2.weight", b.mlp[2].weight), (p + "mlp.2.bias", b.mlp[2].bias)]
+        out += [("ln_f.weight", self.ln_f.weight), ("ln_f.bias", self.ln_f.bias)]
+        return out
+
+    def _eng(self):
+        use_pos = bool(getattr(self.args, "pos_embed", False))
+        if self._engine is None or self._engine.use_pos != use_pos:
+            dim, depth, heads, mlp = self._engine_cfg
+            self._engine = GptEngine(self.arena_named_parameters(), dim, depth, heads, mlp, self.n_tokens, use_pos, self.precision,
+                                     ln_eps=self.ln_f.eps)
+        return self._engine
+
+    def forward(self, cxr_tensor, enh_tensor):
+        if self.training and any(p > 0 for p in self._pdrops):
+            raise NotImplementedError("training with dropout > 0 (embd / attn / resid pdrop) is not built on the HIP path: the kernels have no "
+                                      "dropout stage.  Use model.eval() or construct the GPT with all three pdrop = 0")
+        _, ftrs, _ = cxr_tensor.shape                                                                       # :183
+        tokens = torch.cat([cxr_tensor, enh_tensor], dim=1)                                                  # :184
+        x = self._eng()(tokens)                                                                              # :186-192 (pos_emb, blocks, ln_f)
+        return x[:, :ftrs, :], x[:, ftrs:, :]                                                                # :207-208
+
+
+class Encoder(nn.Module):
+    """fuseattention.py:215-323 (ViT branch): features3D of both streams -> GPT -> residual -> cls rows -> sum."""
+
+    def __init__(self, model_cxr, model_enh, config, args):
+        super().__init__()
+        self.config = config
+        self.args = args
+        self.avgpool = nn.AdaptiveAvgPool2d((self.config.vert_anchors, self.config.horz_anchors))          # :233 (unused on the ViT branch)
+        if self.args.arch.startswith('res'):
+            raise NotImplementedError("the ResNet branch of the TransFuser encoder (fuseattention.py:240-242) is the CNN path: out of scope")
+        self.cxr_encoder = model_cxr.features3D                                                             # :244-245 (bound methods, like FUS:80,83)
+        self.enh_encoder = model_enh.features3D
+        self.transformer4 = GPT(n_embd=config.n_embd, n_head=config.n_head, block_exp=config.block_exp, n_layer=config.n_layer,
+                                vert_anchors=config.vert_anchors, horz_anchors=config.horz_anchors, seq_len=config.seq_len,
+                                embd_pdrop=config.embd_pdrop, attn_pdrop=config.attn_pdrop, resid_pdrop=config.resid_pdrop,
+                                args=args, config=config, precision=getattr(model_cxr, "precision", None))
+
+    def forward(self, cxr_image, enh_image):
+        bz = cxr_image.shape[0]
+        image_features = self.cxr_encoder(cxr_image)                                                        # :285
+        lidar_features = self.enh_encoder(enh_image)                                                        # :291
+        image_l4, lidar_l4 = self.transformer4(image_features, lidar_features)                              # :305
+        # only the cls rows of the residual sums are consumed (:316-317): add them there instead of over all 197 rows
+        image_cls = (image_features[:, 0] + image_l4[:, 0]).view(bz, self.config.n_views * self.config.seq_len, -1)
+        lidar_cls = (lidar_features[:, 0] + lidar_l4[:, 0]).view(bz, self.config.seq_len, -1)
+        fused_features = torch.cat([image_cls, lidar_cls], dim=1)                                           # :319
+        return torch.sum(fused_features, dim=1)                                                             # :320
+
+
+class TransFuser(nn.Module):
+    """fuseattention.py:330-395: Encoder + a 3-class Linear on the fused feature."""
+
+    def __init__(self, model_cxr, model_enh, config, args):
+        super().__init__()
+        self.config = config
+        self.args = args
+        self.encoder = Encoder(model_cxr, model_enh, config, args)
+        if self.args.arch.startswith('vit'):
+            self.output = nn.Linear(model_cxr.head.in_features, 3)                                          # :365
+        else:
+            raise NotImplementedError("ResNet TransFuser head (fuseattention.py:368): out of scope")
+        self.output.weight.data.normal_(mean=0.0, std=0.01)                                                 # :372-373
+        self.output.bias.data.zero_()
+
+    def forward(self, image_list, lidar_list):
+        fused_features = self.encoder(image_list, lidar_list)                                               # :386
+        if fused_features.is_cuda and self.output.weight.dtype == torch.float32:
+            return _HeadFn.apply(fused_features.unsqueeze(1), self.output.weight, self.output.bias)         # small-head HIP kernel
+        return self.output(fused_features)                                                                  # :393

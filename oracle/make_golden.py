@@ -19,6 +19,9 @@ What is exercised from the reference (paths relative to /root/reference/moco_pre
         torch.Tensor.cuda mapped to the identity while it runs because builder_vit.py:93 calls .cuda() on the labels)
   moco/builder_vit_mocov3structure_mocov2loss.py   MoCo.forward itself (its lines 154-199) on a toy encoder: same 1-rank gloo group and
         Tensor.cuda -> identity shim (its :121, :194 call .cuda())  -> moco_forward.npz
+  model/fuseattention.py               GPT, Encoder (ViT branch), TransFuser (eval mode) -> transfuser.npz; the file's module-level
+        ``from torchvision import models`` (torchvision absent: ordinary ModuleNotFoundError) is satisfied by a bare in-memory module object
+        that none of the exercised classes touch
   moco/optimizer.py                    LARS
 The ViT backbone is absent from the reference; where a backbone is needed the oracle's own restatement
 (oracle/ref_vit.py, parity unpinned) is wrapped in an object exposing ``features3D`` / ``__call__``.
@@ -55,11 +58,11 @@ def sample(t, n=4096):
     return dict(idx=idx.numpy(), val=f[idx].numpy(), sum=np.float64(f.sum()), abssum=np.float64(f.abs().sum()))
 
 
-def put(d, key, t, full=False):
+def put(d, key, t, full=False, n=4096):
     if full:
         d[key] = t.detach().double().numpy()
     else:
-        for k, v in sample(t).items():
+        for k, v in sample(t, n).items():
             d[f"{key}.{k}"] = v
 
 
@@ -375,6 +378,69 @@ def golden_moco_forward():
     print("moco_forward.npz loss", float(d["loss"]), "ptr", d["ptr_after"])
 
 
+def golden_transfuser():
+    """fuseattention.py: GPT.forward (8 blocks, 4 heads x 96, 394 joint tokens, ReLU MLP) and TransFuser.forward of the REFERENCE, eval
+    mode (its dropouts are then the identity), on seeded parameters; the encoders are stand-ins exposing `features3D` / `head`
+    (the backbone is absent from the reference).  The reference file imports torchvision (absent here: an ordinary
+    ModuleNotFoundError) for its CNN classes only; a bare in-memory module object named `torchvision.models` is registered, which GPT /
+    Encoder(ViT branch) / TransFuser never touch."""
+    from oracle import ref_gpt
+    m_tv = types.ModuleType("torchvision")
+    m_tv.models = types.ModuleType("torchvision.models")
+    sys.modules.setdefault("torchvision", m_tv)
+    sys.modules.setdefault("torchvision.models", m_tv.models)
+    from config.config import GlobalConfig
+    from model import fuseattention as fa
+
+    class Stream(torch.nn.Module):          # what Encoder / TransFuser touch of a backbone: features3D and head.in_features
+        def __init__(self, feats):
+            super().__init__()
+            self.feats = feats
+            self.head = torch.nn.Linear(384, 3)
+
+        def features3D(self, x):
+            return self.feats
+
+    cfg = GlobalConfig()
+    args = types.SimpleNamespace(arch="vit_small", pos_embed=True)
+    B = 2
+    fc = rng_tensor(601, (B, 197, 384), dtype=torch.float64).requires_grad_(True)
+    fe = rng_tensor(602, (B, 197, 384), dtype=torch.float64).requires_grad_(True)
+    torch.manual_seed(0)
+    model = fa.TransFuser(Stream(fc), Stream(fe), cfg, args).double().eval()
+    gp = ref_gpt.seeded_gpt_params(603, dtype=torch.float64, prefix="encoder.transformer4.")
+    sd = dict(gp)
+    sd["output.weight"] = rng_tensor(604, (3, 384), scale=0.05, dtype=torch.float64)
+    sd["output.bias"] = rng_tensor(605, (3,), scale=0.05, dtype=torch.float64)
+    missing = model.load_state_dict(sd, strict=True)
+    d = dict(seed_fc=601, seed_fe=602, seed_gpt=603, seed_ow=604, seed_ob=605, B=B, n_head=cfg.n_head, n_layer=cfg.n_layer,
+             block_exp=cfg.block_exp, n_tokens=int(model.encoder.transformer4.pos_emb.shape[1]))
+    d["state_keys"] = np.array(sorted(model.state_dict().keys()))
+    # (a) GPT alone
+    a, b = model.encoder.transformer4(fc, fe)
+    put(d, "gpt_cxr", a)
+    put(d, "gpt_enh", b)
+    put(d, "gpt_cxr_cls", a[:, 0], full=True)
+    # (b) TransFuser logits + gradients wrt the features and every parameter
+    img = torch.zeros(B, 3, 224, 224, dtype=torch.float64)
+    logits = model(img, img)
+    r = rng_tensor(606, (B, 3), dtype=torch.float64)
+    (logits * r).sum().backward()
+    d["seed_r"] = 606
+    put(d, "logits", logits, full=True)
+    put(d, "d.fc", fc.grad)
+    put(d, "d.fe", fe.grad)
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            put(d, "d." + name, p.grad, n=256)
+    # (c) without the positional embedding (args.pos_embed False, fuseattention.py:188-189)
+    args.pos_embed = False
+    a2, _ = model.encoder.transformer4(fc, fe)
+    put(d, "gpt_cxr_nopos_cls", a2[:, 0], full=True)
+    np.savez_compressed(os.path.join(OUT, "transfuser.npz"), **d)
+    print("transfuser.npz logits", logits.detach().numpy().ravel()[:3])
+
+
 def golden_lars():
     from moco.optimizer import LARS
     shapes = [(6, 5), (5,), (4, 3), (3, 2)]
@@ -411,4 +477,5 @@ if __name__ == "__main__":
     golden_moco()
     golden_moco_v3()
     golden_moco_forward()
+    golden_transfuser()
     golden_lars()

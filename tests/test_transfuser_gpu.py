@@ -1,0 +1,146 @@
+"""GPU parity of the TransFuser fusion drop-in (model/fuseattention.py -> mfvit_gpt_forward / mfvit_gpt_backward: the ViT encoder's
+GEMM / LayerNorm kernels in token-input mode + the streaming MFMA attention for 4 heads x 96) against
+  * tests/golden/transfuser.npz, produced by the REFERENCE's own GPT / TransFuser classes (fuseattention.py:84-212, 215-395), and
+  * the CPU oracle (oracle/ref_gpt.py + oracle/ref_vit.py) end to end with real HIP backbones.
+Precision 'bf16x3' (split bf16): outputs within 1e-3 relative, gradients within 2e-3 of their scale."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, check_sampled, rng_tensor
+from oracle import ref_gpt, ref_vit
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_transfuser.txt")
+
+
+def log(msg):
+    os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+    with open(REPORT, "a") as f:
+        f.write(msg + "\n")
+
+
+def scale_err(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+class Config:      # config/config.py:6,21,31-42 of the reference; dropouts zero here (the HIP path has no dropout stage)
+    seq_len, n_views, vert_anchors, horz_anchors = 1, 1, 14, 14
+    n_embd, block_exp, n_layer, n_head = 384, 3, 8, 4
+    embd_pdrop = resid_pdrop = attn_pdrop = 0.0
+
+
+class Stream(torch.nn.Module):
+    """What Encoder / TransFuser touch of a backbone: features3D, head.in_features (+ this package's `precision`)."""
+
+    def __init__(self, feats, precision):
+        super().__init__()
+        self.feats, self.precision = feats, precision
+        self.head = torch.nn.Linear(384, 3)
+
+    def features3D(self, x):
+        return self.feats
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("fp16", 1.5e-2)])
+def test_transfuser_against_reference_golden(precision, tol):
+    from model import fuseattention as fa
+    g = np.load(os.path.join(GOLDEN, "transfuser.npz"), allow_pickle=False)
+    B = int(g["B"])
+    fc = rng_tensor(int(g["seed_fc"]), (B, 197, 384)).to(DEV).requires_grad_(True)
+    fe = rng_tensor(int(g["seed_fe"]), (B, 197, 384)).to(DEV).requires_grad_(True)
+    args = types.SimpleNamespace(arch="vit_small", pos_embed=True)
+    model = fa.TransFuser(Stream(fc, precision), Stream(fe, precision), Config(), args)
+    assert set(model.state_dict().keys()) == set(str(k) for k in g["state_keys"])       # the reference module's state-dict layout
+    sd = {k: v for k, v in ref_gpt.seeded_gpt_params(int(g["seed_gpt"]), prefix="encoder.transformer4.").items()}
+    sd["output.weight"] = rng_tensor(int(g["seed_ow"]), (3, 384), scale=0.05)
+    sd["output.bias"] = rng_tensor(int(g["seed_ob"]), (3,), scale=0.05)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).train()                       # all pdrop = 0: training mode is allowed
+    a, b = model.encoder.transformer4(fc, fe)
+    assert a.shape == (B, 197, 384) and b.shape == (B, 197, 384)
+    e_a = scale_err(a[:, 0], torch.from_numpy(g["gpt_cxr_cls"]))
+    check_sampled(g, "gpt_cxr", a, rtol=tol, atol=tol)
+    check_sampled(g, "gpt_enh", b, rtol=tol, atol=tol)
+    img = torch.zeros(B, 3, 224, 224, device=DEV)
+    logits = model(img, img)
+    e_l = scale_err(logits, torch.from_numpy(g["logits"]))
+    r = rng_tensor(int(g["seed_r"]), (B, 3)).to(DEV)
+    (logits * r).sum().backward()
+    gt = 2 * tol
+    named = dict(model.named_parameters())
+
+    def chk(key, t):    # gradients: error relative to the tensor's largest sampled entry (most token rows carry a tiny gradient)
+        check_sampled(g, key, t, rtol=gt, atol=gt * float(np.abs(g[key + ".val"]).max()))
+
+    chk("d.fc", fc.grad)
+    chk("d.fe", fe.grad)
+    for k, v in named.items():
+        assert v.grad is not None, k
+        chk("d." + k, v.grad)
+    # without the positional embedding (args.pos_embed False)
+    args.pos_embed = False
+    with torch.no_grad():
+        a2, _ = model.encoder.transformer4(fc, fe)
+    e_np = scale_err(a2[:, 0], torch.from_numpy(g["gpt_cxr_nopos_cls"]))
+    log(f"TransFuser[{precision}] vs reference golden: gpt cls {e_a:.2e} logits {e_l:.2e} no-pos cls {e_np:.2e}")
+    assert e_a < tol and e_l < tol and e_np < tol
+
+
+def test_transfuser_end_to_end_with_hip_backbones_vs_oracle():
+    """images -> two HIP ViT-S backbones (depth 2) -> GPT fusion -> logits, forward + gradients into the backbones, vs the CPU oracle."""
+    import vits
+    from model import fuseattention as fa
+    depth, B = 2, 2
+    vit_p = [ref_vit.seeded_params(971 + i, num_classes=3, depth=depth) for i in range(2)]
+    backs = []
+    for p in vit_p:
+        m = vits.vit_small(num_classes=3, depth=depth, precision="bf16x3")
+        m.load_state_dict(p)
+        backs.append(m.to(DEV))
+    args = types.SimpleNamespace(arch="vit_small", pos_embed=True)
+    model = fa.TransFuser(backs[0], backs[1], Config(), args)
+    gp = ref_gpt.seeded_gpt_params(973, prefix="encoder.transformer4.")
+    gp["output.weight"], gp["output.bias"] = rng_tensor(974, (3, 384), scale=0.05), rng_tensor(975, (3,), scale=0.05)
+    model.load_state_dict(gp, strict=True)
+    model = model.to(DEV)
+    x, xe = rng_tensor(976, (B, 3, 224, 224)), rng_tensor(977, (B, 3, 224, 224))
+    logits = model(x.to(DEV), xe.to(DEV))
+    r = rng_tensor(978, (B, 3))
+    (logits * r.to(DEV)).sum().backward()
+    vp = [{k: v.double().requires_grad_(k != "pos_embed") for k, v in p.items()} for p in vit_p]
+    gpd = {k: v.double().requires_grad_(True) for k, v in gp.items()}
+    fc, fe = ref_vit.features3d(vp[0], x.double()), ref_vit.features3d(vp[1], xe.double())
+    ref = ref_gpt.transfuser_logits(gpd, fc, fe)
+    (ref * r.double()).sum().backward()
+    e_l = scale_err(logits, ref)
+    e_g = max(scale_err(backs[i].blocks[j].attn.qkv.weight.grad, vp[i][f"blocks.{j}.attn.qkv.weight"].grad) for i in (0, 1) for j in (0, 1))
+    k = "encoder.transformer4.blocks.3.attn.query.weight"
+    e_q = scale_err(dict(model.named_parameters())[k].grad, gpd[k].grad)
+    log(f"TransFuser end to end (HIP backbones, bf16x3): logits {e_l:.2e} backbone grad {e_g:.2e} GPT grad {e_q:.2e}")
+    assert e_l < 1e-3 and e_g < 2e-3 and e_q < 2e-3
+    assert logits.argmax(1).cpu().tolist() == ref.argmax(1).tolist()
+
+
+def test_transfuser_scope_is_stated_not_silent():
+    from model import fuseattention as fa
+    f = torch.zeros(1, 197, 384, device=DEV)
+
+    class Drop(Config):
+        embd_pdrop = resid_pdrop = attn_pdrop = 0.1               # config.py:40-42
+
+    args = types.SimpleNamespace(arch="vit_small", pos_embed=True)
+    m = fa.TransFuser(Stream(f, "bf16x3"), Stream(f, "bf16x3"), Drop(), args).to(DEV)
+    with pytest.raises(NotImplementedError, match="dropout"):
+        m.train()(torch.zeros(1, 3, 224, 224, device=DEV), torch.zeros(1, 3, 224, 224, device=DEV))
+    out = m.eval()(torch.zeros(1, 3, 224, 224, device=DEV), torch.zeros(1, 3, 224, 224, device=DEV))   # eval mode: dropout is the identity
+    assert out.shape == (1, 3) and torch.isfinite(out).all()
+    with pytest.raises(NotImplementedError):
+        fa.TransFuser(Stream(f, "bf16x3"), Stream(f, "bf16x3"), Config(), types.SimpleNamespace(arch="resnet50", pos_embed=True))
+    with pytest.raises(NotImplementedError):
+        fa.GPT(384, 4, 3, 8, 14, 14, 1, 0, 0, 0, args, Config(), precision="fp32")._eng()

@@ -1,0 +1,79 @@
+// Pure-MFMA ceiling of gfx950 for v_mfma_f32_32x32x16_bf16 (and the f16 twin): no LDS, no global loads in the loop, no epilogue -
+// what the matrix cores sustain under load (clock included).  Every GEMM roofline fraction in DESIGN.md is also quoted against THIS
+// number (the "practical ceiling"), next to the 2.5 PFLOP/s datasheet peak.
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_ceiling.hip -o tools/mfma_ceiling && tools/mfma_ceiling [waves_per_simd] [random|zero]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_loop(const bf16x8* __restrict__ in, float* __restrict__ out, int iters) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    bf16x8 a[NACC], b[NACC];
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) {
+        a[i] = in[(gid * 2 * NACC + 2 * i) & 0xffff];
+        b[i] = in[(gid * 2 * NACC + 2 * i + 1) & 0xffff];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[gid] = s;
+}
+
+int main(int argc, char** argv) {
+    const int wps = argc > 1 ? atoi(argv[1]) : 1;                 // waves per SIMD (4 SIMDs per CU)
+    const bool zero = argc > 2 && !strcmp(argv[2], "zero");
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    const int blocks = cus * wps;                                   // 256 threads = 4 waves = one per SIMD
+    const int iters = 20000, NACC = 8;
+    bf16x8* in;
+    float* out;
+    hipMalloc(&in, 65536 * sizeof(bf16x8));
+    hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
+    unsigned short* h = (unsigned short*)malloc(65536 * 16);
+    unsigned x = 12345u;
+    for (int i = 0; i < 65536 * 8; ++i) {
+        x = x * 1664525u + 1013904223u;
+        const float f = zero ? 0.f : ((int)(x >> 8) % 2001 - 1000) * 1e-3f;      // values in [-1, 1]
+        unsigned u;
+        memcpy(&u, &f, 4);
+        h[i] = (unsigned short)(u >> 16);
+    }
+    hipMemcpy(in, h, 65536 * 16, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_loop<NACC>, dim3(blocks), dim3(256), 0, 0, in, out, 2000);           // warm-up (clock ramp)
+    hipDeviceSynchronize();
+    float best = 1e30f, ms;
+    for (int rep = 0; rep < 5; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(mfma_loop<NACC>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double flop = 2.0 * 32 * 32 * 16 * (double)NACC * iters * blocks * 4;
+    printf("{\"kernel\": \"pure v_mfma_f32_32x32x16_bf16 loop, %d independent accumulators per wave, %d wave(s) per SIMD, %s operands\", "
+           "\"cus\": %d, \"ms\": %.3f, \"tflops\": %.1f, \"frac_of_2500\": %.3f, \"mfma_cycles_per_instr_at_2400MHz\": %.1f}\n",
+           NACC, wps, zero ? "zero" : "random", cus, best, flop / best / 1e9, flop / best / 1e9 / 2500.0,
+           best * 1e-3 * 2.4e9 / ((double)NACC * iters * wps));
+    return 0;
+}
