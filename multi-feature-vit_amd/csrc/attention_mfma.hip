@@ -27,27 +27,23 @@ namespace {
 // is [hi x 32 | lo x 32] (128 B), every product of two tensors runs as three MFMAs (hi*hi + lo*hi + hi*lo) and P / dS are split
 // in registers (hi = bf16(p), lo = bf16(p - hi)) before they feed the second product - f32-grade attention on the bf16 matrix core.
 constexpr int HD = 32;
+// LDS images: padded pitch RB + 16 (80 B, split 144 B): the natural-order b128 row reads are bank-conflict free, the transposed
+// ds_read_b64_tr_b16 reads are 2-way conflicted (rows q and q + 2 of a 4-row block share banks).  Tried in round 2 and dropped: unpadded
+// rows with the 16-B chunks XOR-swizzled by the row (chunk ^ ((row >> 2) & 3), split: ((row >> 1) & 1) << 2 | (row >> 2) & 3) make BOTH
+// patterns conflict free, but the chunk position then no longer folds into the ds_read immediate offset: +14 ... +70 VGPRs of
+// precomputed addresses and an address add per read - forward 55.4 -> 59.8 us, backward 158 -> 162 us (split bf16, B = 128): slower.
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 
-// LDS images are UNPADDED rows of RB bytes whose 16-B chunks are XOR-swizzled by a function of the row, chosen so that BOTH access
-// patterns are bank-conflict free (64 banks x 4 B; MI355X_MICROARCH.md LDS table):
-//   * natural-order fragments (ds_read_b128: lane groups of 16 rows {0-3,12-15,20-27} / {4-11,16-19,28-31}, one chunk per row), and
-//   * accumulator-order transposed fragments (ds_read_b64_tr_b16: per 32 lanes 4 consecutive rows x 4 consecutive 8-B pieces x 2).
-// plain 16-bit rows (64 B, 4 chunks):  chunk ^ ((row >> 2) & 3)           - 4 rows share a 256-B bank row and keep their chunk order
-// split rows (128 B, 8 chunks = hi 0-3 | lo 4-7):  chunk ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))   - rows r, r + 2 swap halves
-// (a padded pitch of 80 / 144 B kept the row reads conflict-free but left the transposed reads 2-way conflicted: 2.49 M conflict
-// cycles per launch in the bf16 backward, profiles/pmc/r01_pmc_attn_bwd.txt.)
 template <typename T> struct AttnT {
     static constexpr bool SP = is_split<T>::value;
     static constexpr int EP = SP ? 2 : 1;
-    static constexpr int RB = 64 * EP;        // bytes of one head row piece = LDS row pitch
+    static constexpr int RB = 64 * EP;        // bytes of one head row piece
+    static constexpr int RSB = RB + 16;       // padded LDS row pitch: b128 row reads of 16 consecutive rows are conflict-free
     typedef typename Vec8<T>::type frag_t;
     typedef typename Vec4<T>::type vec4_t;
     typedef typename Vec4<T>::elem E;
-    static __device__ __forceinline__ int swz(int row) { return SP ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3); }
-    // byte offset of logical 16-B chunk `chunk` of row `row`
-    static __device__ __forceinline__ int off(int row, int chunk) { return row * RB + ((chunk ^ swz(row)) << 4); }
+    static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) { return MmaTraits_mma(a, b, c); }
 };
 __device__ __forceinline__ f32x16 MmaTraits_mma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 MmaTraits_mma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
@@ -55,15 +51,15 @@ __device__ __forceinline__ f32x16 MmaTraits_mma(f16x8 a, f16x8 b, f32x16 c) { re
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // natural-order fragment: row (rowbase + lane&31), elements d = 16 s + 8 (lane>>5) .. +8 of part `part` (0 = hi / plain, 1 = lo)
-template <typename T> __device__ __forceinline__ typename Vec8<T>::type row_frag(const char* img, int rowbase, int s, int lane, int part = 0) {
-    return *(const typename Vec8<T>::type*)(img + AttnT<T>::off(rowbase + (lane & 31), 4 * part + 2 * s + (lane >> 5)));
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type row_frag(const char* img, int pitch, int rowbase, int s, int lane, int part = 0) {
+    return *(const typename Vec8<T>::type*)(img + (rowbase + (lane & 31)) * pitch + 64 * part + 32 * s + 16 * (lane >> 5));
 }
 // transposed fragment in ACCUMULATOR k order: lane holds column d = lane&31; element j = row (rowbase + 16 s + 8 (j>>2) + 4 h + (j&3))
-template <typename T> __device__ __forceinline__ typename Vec8<T>::type tr_frag(const char* img, int rowbase, int s, int lane, int part = 0) {
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type tr_frag(const char* img, int pitch, int rowbase, int s, int lane, int part = 0) {
     const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
-    const int row = rowbase + 16 * s + 4 * h + q, chunk = 4 * part + 2 * g1 + (p >> 1);
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + AttnT<T>::off(row, chunk) + 8 * (p & 1)));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(img + AttnT<T>::off(row + 8, chunk) + 8 * (p & 1)));
+    const char* a = img + (rowbase + 16 * s + 4 * h + q) * pitch + 64 * part + (16 * g1 + 4 * p) * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + 8 * pitch));
     union { struct { s16x4 a, b; } s; typename Vec8<T>::type v; } u;
     u.s.a = lo;
     u.s.b = hi;
@@ -117,11 +113,11 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<
     typedef AttnT<T> A;
     typedef typename A::E E;
     typedef typename A::frag_t frag_t;
-    constexpr int EP = A::EP, CPR = A::RB / 16;
+    constexpr int EP = A::EP, KP = A::RSB, VP = A::RB, CPR = A::RB / 16;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tpad = (Tn + 31) & ~31;
     char* Ks = lds;
-    char* Vs = lds + Tpad * A::RB;
+    char* Vs = lds + Tpad * KP;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);  // the heads of one image share an XCD: their row pieces share L2 lines
     const int b = bid / H, h = bid % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -136,8 +132,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<
             vk = *(const uint4*)rp;
             vv = *(const uint4*)(rp + hs);
         }
-        *(uint4*)(Ks + A::off(t, cidx)) = vk;
-        *(uint4*)(Vs + A::off(t, cidx)) = vv;
+        *(uint4*)(Ks + t * KP + 16 * cidx) = vk;
+        *(uint4*)(Vs + t * VP + 16 * cidx) = vv;
     }
     __syncthreads();
     const float c = scale * 1.4426950408889634f;
@@ -166,7 +162,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<
                     for (int r = 0; r < 16; ++r) sc[t][r] = 0.f;
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
-                        sc[t] = mma3<T>(row_frag<T>(Ks, (k0 + t) * 32, s, lane, 0), row_frag<T>(Ks, (k0 + t) * 32, s, lane, A::SP ? 1 : 0),
+                        sc[t] = mma3<T>(row_frag<T>(Ks, KP, (k0 + t) * 32, s, lane, 0), row_frag<T>(Ks, KP, (k0 + t) * 32, s, lane, A::SP ? 1 : 0),
                                         qf[s], ql[s], sc[t]);
                     if ((k0 + t + 1) * 32 > Tn) {  // last key tile: mask the zero-padded keys
 #pragma unroll
@@ -203,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<
                         frag_t ph, pl;
                         pack8<T>(sc[t], s, ph, pl);
                         if constexpr (!A::SP) pl = ph;
-                        o = mma3<T>(tr_frag<T>(Vs, (k0 + t) * 32, s, lane, 0), tr_frag<T>(Vs, (k0 + t) * 32, s, lane, A::SP ? 1 : 0), ph, pl, o);
+                        o = mma3<T>(tr_frag<T>(Vs, VP, (k0 + t) * 32, s, lane, 0), tr_frag<T>(Vs, VP, (k0 + t) * 32, s, lane, A::SP ? 1 : 0), ph, pl, o);
                     }
                 }
         }
@@ -216,17 +212,17 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<
 }
 
 // One 8-wave workgroup per (image, head): Q, K, V, dO of the head are read from HBM exactly once into four LDS images
-// (unpadded, chunk-swizzled: conflict-free for the row reads AND the transposed reads).  -lse/scale and
+// (padded pitch: conflict-free row reads; unpadded when only that fits the 160 KB of LDS).  -lse/scale and
 // -D = -rowsum(dO o O) enter the score MFMAs as accumulator initial values, so S - lse/scale and dP - D come out of the
 // matrix core and the VALU work per element is mul, exp2, mul, cvt (+ the hi / lo split of P and dS for split tensors).
-template <typename T>
+template <typename T, int PITCH>
 __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename Vec4<T>::elem* __restrict__ out,
                                                             const typename Vec4<T>::elem* __restrict__ dout, const float* __restrict__ lse,
                                                             typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale) {
     typedef AttnT<T> A;
     typedef typename A::E E;
     typedef typename A::frag_t frag_t;
-    constexpr int EP = A::EP, CPR = A::RB / 16, LO = A::SP ? 1 : 0, PITCH = A::RB;
+    constexpr int EP = A::EP, CPR = A::RB / 16, LO = A::SP ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tpad = (Tn + 31) & ~31;
     char* Qs = lds;
@@ -271,10 +267,10 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
                 }
             }
         }
-        *(uint4*)(Qs + A::off(t, cidx)) = vq;
-        *(uint4*)(Ks + A::off(t, cidx)) = vk;
-        *(uint4*)(Vs + A::off(t, cidx)) = vv;
-        *(uint4*)(dOs + A::off(t, cidx)) = vd;
+        *(uint4*)(Qs + t * PITCH + 16 * cidx) = vq;
+        *(uint4*)(Ks + t * PITCH + 16 * cidx) = vk;
+        *(uint4*)(Vs + t * PITCH + 16 * cidx) = vv;
+        *(uint4*)(dOs + t * PITCH + 16 * cidx) = vd;
         D += __shfl_xor(D, 1, 64);
         D += __shfl_xor(D, 2, 64);
         if constexpr (A::SP) D += __shfl_xor(D, 4, 64);
@@ -291,10 +287,10 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
         frag_t qf[2], ql[2], dof[2], dol[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            qf[s] = row_frag<T>(Qs, qt * 32, s, lane, 0);
-            ql[s] = row_frag<T>(Qs, qt * 32, s, lane, LO);
-            dof[s] = row_frag<T>(dOs, qt * 32, s, lane, 0);
-            dol[s] = row_frag<T>(dOs, qt * 32, s, lane, LO);
+            qf[s] = row_frag<T>(Qs, PITCH, qt * 32, s, lane, 0);
+            ql[s] = row_frag<T>(Qs, PITCH, qt * 32, s, lane, LO);
+            dof[s] = row_frag<T>(dOs, PITCH, qt * 32, s, lane, 0);
+            dol[s] = row_frag<T>(dOs, PITCH, qt * 32, s, lane, LO);
         }
         const float L = Ls[qt * 32 + (lane & 31)], Dq = Ds[qt * 32 + (lane & 31)];  // -lse/scale, -D
         f32x16 dq;
@@ -306,8 +302,8 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
             for (int r = 0; r < 16; ++r) { st[r] = L; dp[r] = Dq; }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                st = mma3<T>(row_frag<T>(Ks, kt * 32, s, lane, 0), row_frag<T>(Ks, kt * 32, s, lane, LO), qf[s], ql[s], st);
-                dp = mma3<T>(row_frag<T>(Vs, kt * 32, s, lane, 0), row_frag<T>(Vs, kt * 32, s, lane, LO), dof[s], dol[s], dp);
+                st = mma3<T>(row_frag<T>(Ks, PITCH, kt * 32, s, lane, 0), row_frag<T>(Ks, PITCH, kt * 32, s, lane, LO), qf[s], ql[s], st);
+                dp = mma3<T>(row_frag<T>(Vs, PITCH, kt * 32, s, lane, 0), row_frag<T>(Vs, PITCH, kt * 32, s, lane, LO), dof[s], dol[s], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r)  // dS^T / scale (padded keys: K rows are zero, so their dQ contribution vanishes)
@@ -317,7 +313,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
                 frag_t sh, sl;
                 pack8<T>(st, s, sh, sl);
                 if constexpr (!A::SP) sl = sh;
-                dq = mma3<T>(tr_frag<T>(Ks, kt * 32, s, lane, 0), tr_frag<T>(Ks, kt * 32, s, lane, LO), sh, sl, dq);
+                dq = mma3<T>(tr_frag<T>(Ks, PITCH, kt * 32, s, lane, 0), tr_frag<T>(Ks, PITCH, kt * 32, s, lane, LO), sh, sl, dq);
             }
         }
         const int q = qt * 32 + (lane & 31);
@@ -328,10 +324,10 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
         frag_t kf[2], kl[2], vf[2], vl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            kf[s] = row_frag<T>(Ks, kt * 32, s, lane, 0);
-            kl[s] = row_frag<T>(Ks, kt * 32, s, lane, LO);
-            vf[s] = row_frag<T>(Vs, kt * 32, s, lane, 0);
-            vl[s] = row_frag<T>(Vs, kt * 32, s, lane, LO);
+            kf[s] = row_frag<T>(Ks, PITCH, kt * 32, s, lane, 0);
+            kl[s] = row_frag<T>(Ks, PITCH, kt * 32, s, lane, LO);
+            vf[s] = row_frag<T>(Vs, PITCH, kt * 32, s, lane, 0);
+            vl[s] = row_frag<T>(Vs, PITCH, kt * 32, s, lane, LO);
         }
         f32x16 dk, dv;
 #pragma unroll
@@ -348,8 +344,8 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                sm = mma3<T>(row_frag<T>(Qs, qt * 32, s, lane, 0), row_frag<T>(Qs, qt * 32, s, lane, LO), kf[s], kl[s], sm);   // S[q][key] - lse[q]/scale
-                dp = mma3<T>(row_frag<T>(dOs, qt * 32, s, lane, 0), row_frag<T>(dOs, qt * 32, s, lane, LO), vf[s], vl[s], dp);  // dP[q][key] - D[q]
+                sm = mma3<T>(row_frag<T>(Qs, PITCH, qt * 32, s, lane, 0), row_frag<T>(Qs, PITCH, qt * 32, s, lane, LO), kf[s], kl[s], sm);   // S[q][key] - lse[q]/scale
+                dp = mma3<T>(row_frag<T>(dOs, PITCH, qt * 32, s, lane, 0), row_frag<T>(dOs, PITCH, qt * 32, s, lane, LO), vf[s], vl[s], dp);  // dP[q][key] - D[q]
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -362,8 +358,8 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
                 pack8<T>(sm, s, ph, pl);
                 pack8<T>(dp, s, sh, sl);
                 if constexpr (!A::SP) { pl = ph; sl = sh; }
-                dv = mma3<T>(tr_frag<T>(dOs, qt * 32, s, lane, 0), tr_frag<T>(dOs, qt * 32, s, lane, LO), ph, pl, dv);
-                dk = mma3<T>(tr_frag<T>(Qs, qt * 32, s, lane, 0), tr_frag<T>(Qs, qt * 32, s, lane, LO), sh, sl, dk);
+                dv = mma3<T>(tr_frag<T>(dOs, PITCH, qt * 32, s, lane, 0), tr_frag<T>(dOs, PITCH, qt * 32, s, lane, LO), ph, pl, dv);
+                dk = mma3<T>(tr_frag<T>(Qs, PITCH, qt * 32, s, lane, 0), tr_frag<T>(Qs, PITCH, qt * 32, s, lane, LO), sh, sl, dk);
             }
         }
         const int k = kt * 32 + (lane & 31);
@@ -402,7 +398,7 @@ __global__ __launch_bounds__(256) void colsum_t_kernel(const typename Vec4<T>::e
 template <typename T> int launch_fwd_t(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
     typedef typename Vec4<T>::elem E;
     const int Tpad = (Tn + 31) & ~31;
-    const int bytes = 2 * Tpad * AttnT<T>::RB;
+    const int bytes = Tpad * (AttnT<T>::RSB + AttnT<T>::RB);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
@@ -413,17 +409,24 @@ template <typename T> int launch_fwd_t(const void* qkv, void* out, float* lse, i
 template <typename T> int launch_bwd_t(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
                                        int H, hipStream_t st) {
     typedef typename Vec4<T>::elem E;
+    constexpr int RSB = AttnT<T>::RSB, RB = AttnT<T>::RB;
     const int Tpad = (Tn + 31) & ~31;
-    const int bytes = 4 * Tpad * AttnT<T>::RB + 2 * Tpad * 4;
+    const bool wide = 4 * Tpad * RSB + 2 * Tpad * 4 <= 160 * 1024;
+    const int bytes = 4 * Tpad * (wide ? RSB : RB) + 2 * Tpad * 4;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
     {
         ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
-        MFVIT_LAUNCH((attn_bwd_mfma_kernel<T>), dim3(B * H), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse, (E*)dqkv, Tn,
-                     H, 1.0f / sqrtf((float)HD));
+        if (wide)
+            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RSB>), dim3(B * H), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
+                         (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
+        else
+            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RB>), dim3(B * H), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
+                         (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
         MFVIT_CHECK_LAUNCH();
     }
     if (dbias) {
@@ -440,7 +443,7 @@ bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward) {
     if ((dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || HDim != HD || Tn < 1) return false;
     const int Tpad = (Tn + 31) & ~31;
     const int rb = dtype == MFVIT_BF16X3 ? 128 : 64;
-    const int bytes = backward ? 4 * Tpad * rb + 2 * Tpad * 4 : 2 * Tpad * rb;
+    const int bytes = backward ? 4 * Tpad * rb + 2 * Tpad * 4 : Tpad * (rb + 16) + Tpad * rb;
     return bytes <= 160 * 1024;
 }
 

@@ -107,6 +107,20 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
     gelu_parts_fast(x, cdf, e);
     return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
+// gelu(x) and gelu'(x) together: the erf / exp evaluation is shared (the fc1 epilogue needs both; computed separately they cost two
+// transcendental evaluations per element in a VALU-bound epilogue)
+template <typename T> __device__ __forceinline__ void gelu_both_t(float x, float& g, float& dg) {
+    if constexpr (sizeof(T) == 2) {
+        float cdf, e;
+        gelu_parts_fast(x, cdf, e);
+        g = x * cdf;
+        dg = fmaf(x * 0.39894228040143267794f, e, cdf);
+    } else {
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        g = x * cdf;
+        dg = cdf + x * (0.39894228040143267794f * __expf(-0.5f * x * x));
+    }
+}
 template <typename T> __device__ __forceinline__ float gelu_t(float x) { return sizeof(T) == 2 ? gelu_fast(x) : gelu_erf(x); }
 template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) { return sizeof(T) == 2 ? gelu_grad_fast(x) : gelu_erf_grad(x); }
 

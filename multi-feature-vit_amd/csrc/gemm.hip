@@ -90,8 +90,10 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
                 float v = acc[i][j][r] + bj[j];
                 T* e = erow(i, r);
                 if (EPI == EPI_BIAS_GELU) {
-                    acc[i][j][r] = v;                                   // kept for the second output
-                    store_elem<T>(e, ecol(j), gelu_grad_t<T>(v));       // out0 = gelu'(pre): all the backward needs
+                    float gv, dgv;
+                    gelu_both_t<T>(v, gv, dgv);                         // one erf / exp evaluation for both outputs
+                    acc[i][j][r] = gv;                                  // gelu(pre): the second output, stored below
+                    store_elem<T>(e, ecol(j), dgv);                     // out0 = gelu'(pre): all the backward needs
                 } else if (EPI == EPI_BIAS_RELU) {
                     acc[i][j][r] = v;
                     store_elem<T>(e, ecol(j), v > 0.f ? 1.f : 0.f);     // out0 = relu'(pre) (fuseattention.py:69: nn.ReLU)
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
             for (int i = 0; i < Loop::TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    store_elem<T>(erow(i, r), ecol(j), EPI == EPI_BIAS_RELU ? fmaxf(acc[i][j][r], 0.f) : gelu_t<T>(acc[i][j][r]));
+                    store_elem<T>(erow(i, r), ecol(j), EPI == EPI_BIAS_RELU ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r]);
         store_tile(p.out1, p.ldo1);
     }
 }

@@ -75,8 +75,19 @@ def test_transfuser_against_reference_golden(precision, tol):
     gt = 2 * tol
     named = dict(model.named_parameters())
 
-    def chk(key, t):    # gradients: error relative to the tensor's largest sampled entry (most token rows carry a tiny gradient)
-        check_sampled(g, key, t, rtol=gt, atol=gt * float(np.abs(g[key + ".val"]).max()))
+    gmax = max(float(np.abs(g[f"d.{k}.val"]).max()) for k in named)
+
+    def chk(key, t):
+        # gradients: error relative to the tensor's largest sampled entry (most token rows carry a tiny gradient); tensors whose
+        # gradient is mathematically zero (attn.key.bias: a shift of every key leaves the softmax unchanged) are rounding noise on both
+        # sides and are held to a floor tied to the largest parameter gradient.  fp16 only: a ReLU unit whose pre-activation is within
+        # fp16 rounding of zero may switch side (its whole contribution appears / vanishes): at most 1 % of the sampled entries may
+        # miss the tolerance; split bf16 gets no such allowance.
+        f = t.detach().double().flatten().cpu()
+        idx, val = torch.from_numpy(g[key + ".idx"]), torch.from_numpy(g[key + ".val"])
+        atol = gt * max(float(val.abs().max()), 1e-3 * gmax)
+        bad = int(((f[idx] - val).abs() > atol + gt * val.abs()).sum())
+        assert bad <= (0 if precision == "bf16x3" else max(1, idx.numel() // 100)), (key, bad, idx.numel())
 
     chk("d.fc", fc.grad)
     chk("d.fe", fe.grad)
