@@ -235,6 +235,9 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // ---------------------------------------------------------------------------------------------------
 // NT main loop:  acc[TM][TN] (32x32 tiles) += A[m0.., :] * W[n0.., :]^T, double-buffered LDS, one barrier
 // per K tile, next tile's global loads issued before the MFMAs of the current one (write after).
+// (Tried in round 2 for the row-complete kernels, which run ONE workgroup per CU, and dropped: prefetching the activation tile two K
+// tiles ahead through a second register set.  Measured inside the step, split bf16: proj / fc2 + LN 118.8 -> 147 us, LN-backward
+// 156 -> 190 us - the extra live registers and the longer dependency chain cost more than the HBM latency they were meant to hide.)
 template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
     static constexpr bool PIPE = MFVIT_NT_PIPE;
     static constexpr int NT = WM * WN * 64;
@@ -244,89 +247,56 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
     typedef KTile<T, BN, BKB> TB;
     static constexpr int STAGE_BYTES = TA::BYTES + TB::BYTES;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr bool SPLIT = is_split<T>::value;
+    static_assert(!SPLIT || BKB == 128, "a split K tile is one 32-wide k group: [hi x 32 | lo x 32] = 128 bytes per row");
 
-    static __device__ __forceinline__ void run(const GemmP& p, int m0, int n0, char* lds, f32x16 (&acc)[TM][TN]) {
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        const int wm = wave / WN, wn = wave % WN;
-        const T* A = (const T*)p.A;
-        const T* W = (const T*)p.W;
-        KStage<T, BM, BKB, NT> sa;
-        KStage<T, BN, BKB, NT> sb;
+    // the MFMAs of one K tile held in LDS (ta: A rows, tb: W rows)
+    static __device__ __forceinline__ void compute(const char* ta, const char* tb, int wm, int wn, int lane, f32x16 (&acc)[TM][TN]) {
+        if constexpr (SPLIT) {
+            // split product: per 16-wide k step  acc += a_lo b_hi + a_hi b_lo + a_hi b_hi  (3 MFMAs from 4 fragments; the fragments
+            // of step 1 are read while the 12 - 18 MFMAs of step 0 run).  MFMA steps 0, 1 of the row are the hi parts, 2, 3 the lo
+            // parts (KTile<sbf16>).
+            typename MmaTraits<T>::frag_t ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        constexpr bool SPLIT = is_split<T>::value;
-        static_assert(!SPLIT || BKB == 128, "a split K tile is one 32-wide k group: [hi x 32 | lo x 32] = 128 bytes per row");
-        const int nk = p.K * elems_per<T>::value / BK;      // K tiles over the STORAGE width
-        sa.load(A, p.lda, m0, p.M, 0, tid);
-        sb.load(W, p.ldw, n0, p.N, 0, tid);
-        sa.store(lds, tid);
-        sb.store(lds + TA::BYTES, tid);
-        __syncthreads();
-        int cur = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            const char* ta = lds + cur * STAGE_BYTES;
-            const char* tb = ta + TA::BYTES;
-            if (kt + 1 < nk) {
-                sa.load(A, p.lda, m0, p.M, (kt + 1) * BK, tid);
-                sb.load(W, p.ldw, n0, p.N, (kt + 1) * BK, tid);
+            for (int i = 0; i < TM; ++i) {
+                ah[0][i] = TA::frag(ta, (wm * TM + i) * 32, 0, lane);
+                al[0][i] = TA::frag(ta, (wm * TM + i) * 32, 2, lane);
             }
-            if constexpr (SPLIT) {
-                // split product: per 16-wide k step  acc += a_hi b_hi + a_lo b_hi + a_hi b_lo  (3 MFMAs from 4 fragments; the
-                // fragments of step 1 are read while the 12 - 18 MFMAs of step 0 run).  MFMA steps 0, 1 of the row are the hi
-                // parts, 2, 3 the lo parts (KTile<sbf16>).
-                typename MmaTraits<T>::frag_t ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ah[0][i] = TA::frag(ta, (wm * TM + i) * 32, 0, lane);
-                    al[0][i] = TA::frag(ta, (wm * TM + i) * 32, 2, lane);
-                }
+            for (int j = 0; j < TN; ++j) {
+                bh[0][j] = TB::frag(tb, (wn * TN + j) * 32, 0, lane);
+                bl[0][j] = TB::frag(tb, (wn * TN + j) * 32, 2, lane);
+            }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bh[0][j] = TB::frag(tb, (wn * TN + j) * 32, 0, lane);
-                    bl[0][j] = TB::frag(tb, (wn * TN + j) * 32, 2, lane);
-                }
+            for (int s = 0; s < 2; ++s) {
+                if (s == 0) {
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    if (s == 0) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) {
-                            ah[1][i] = TA::frag(ta, (wm * TM + i) * 32, 1, lane);
-                            al[1][i] = TA::frag(ta, (wm * TM + i) * 32, 3, lane);
-                        }
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            bh[1][j] = TB::frag(tb, (wn * TN + j) * 32, 1, lane);
-                            bl[1][j] = TB::frag(tb, (wn * TN + j) * 32, 3, lane);
-                        }
+                    for (int i = 0; i < TM; ++i) {
+                        ah[1][i] = TA::frag(ta, (wm * TM + i) * 32, 1, lane);
+                        al[1][i] = TA::frag(ta, (wm * TM + i) * 32, 3, lane);
                     }
-                    if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(al[s][i], bh[s][j], acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[s][i], bl[s][j], acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[s][i], bh[s][j], acc[i][j]);
-                    if (PIPE) __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < TN; ++j) {
+                        bh[1][j] = TB::frag(tb, (wn * TN + j) * 32, 1, lane);
+                        bl[1][j] = TB::frag(tb, (wn * TN + j) * 32, 3, lane);
+                    }
                 }
-                if (kt + 1 < nk) {
-                    char* na = lds + (cur ^ 1) * STAGE_BYTES;
-                    sa.store(na, tid);
-                    sb.store(na + TA::BYTES, tid);
-                }
-                __syncthreads();
-                cur ^= 1;
-                continue;
+                if (PIPE) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(al[s][i], bh[s][j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[s][i], bl[s][j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[s][i], bh[s][j], acc[i][j]);
+                if (PIPE) __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
             // fragments double-buffered by hand: the LDS reads of sub-step s+1 are issued before the MFMAs of sub-step s (left to
             // itself the compiler waits right behind each read, which at 1-2 waves per SIMD exposes the LDS latency every sub-step)
             typename MmaTraits<T>::frag_t a[2][TM], b[2][TN];
@@ -349,13 +319,46 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
                     for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][i], b[s & 1][j], acc[i][j]);
                 if (PIPE) __builtin_amdgcn_sched_barrier(0);
             }
-            if (kt + 1 < nk) {
-                char* na = lds + (cur ^ 1) * STAGE_BYTES;
-                sa.store(na, tid);
-                sb.store(na + TA::BYTES, tid);
-            }
+        }
+    }
+
+    static __device__ __forceinline__ void run(const GemmP& p, int m0, int n0, char* lds, f32x16 (&acc)[TM][TN]) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+        const T* A = (const T*)p.A;
+        const T* W = (const T*)p.W;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int nk = p.K * elems_per<T>::value / BK;      // K tiles over the STORAGE width
+        {
+            KStage<T, BM, BKB, NT> sa;
+            KStage<T, BN, BKB, NT> sb;
+            sa.load(A, p.lda, m0, p.M, 0, tid);
+            sb.load(W, p.ldw, n0, p.N, 0, tid);
+            sa.store(lds, tid);
+            sb.store(lds + TA::BYTES, tid);
             __syncthreads();
-            cur ^= 1;
+            int cur = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                const char* ta = lds + cur * STAGE_BYTES;
+                const char* tb = ta + TA::BYTES;
+                if (kt + 1 < nk) {
+                    sa.load(A, p.lda, m0, p.M, (kt + 1) * BK, tid);
+                    sb.load(W, p.ldw, n0, p.N, (kt + 1) * BK, tid);
+                }
+                compute(ta, tb, wm, wn, lane, acc);
+                if (kt + 1 < nk) {
+                    char* na = lds + (cur ^ 1) * STAGE_BYTES;
+                    sa.store(na, tid);
+                    sb.store(na + TA::BYTES, tid);
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
         }
     }
 };

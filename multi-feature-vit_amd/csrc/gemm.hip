@@ -24,7 +24,7 @@ namespace mfvit {
 
 // ------------------------------------------------------------------------------------------ tile kernel
 template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_tile_kernel(GemmP p) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 workgroups per CU (64 - 68 KB of LDS each): register budget 256 per wave
     constexpr int BM = 128, BN = 128, BKB = 128, WM = 2, WN = 2;
     typedef NtLoop<T, BM, BN, BKB, WM, WN> Loop;
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -646,7 +646,8 @@ template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_
     if constexpr (REPI == REPI_RES_LN) {
         // 128-row variant: every workgroup streams the whole W[384][K] from L2, so doubling the rows per workgroup halves that
         // traffic (the row kernels' main loop is bound by it); worth it once K is large enough to amortise the 77 % grid fill
-        if (v == 4 || (v == 2 && p.K >= 768 && p.M >= 128 * 128)) return launch_row_v<T, REPI, 2, 128, 128>(p, st);
+        static const int bm128 = [] { const char* e = getenv("MFVIT_ROW_BM128"); return e ? atoi(e) : 1; }();   // 0: 64-row tiles everywhere (A/B switch)
+        if (v == 4 || (v == 2 && bm128 && p.K >= 768 && p.M >= 128 * 128)) return launch_row_v<T, REPI, 2, 128, 128>(p, st);
     }
     return launch_row_v<T, REPI, 2, 128, 64>(p, st);
 }
