@@ -352,3 +352,40 @@ def test_grad_scaler_semantics():
     assert sc2.get_scale() == 1024.0
     w.grad = torch.full_like(w, float("nan"))
     assert sc.step(opt) is None
+
+
+@pytest.mark.parametrize("precision,tol", [("fp16", 2e-2), ("bf16x3", 1e-3)])
+def test_two_stream_384_ca_step(precision, tol):
+    """BASELINE configs[4] shape: two-stream MF-ViT CA step at 384 x 384 (577 tokens per stream) in the config's own arithmetic (fp16)
+    and in the f32-grade default (split bf16: 577 tokens are beyond the whole-head LDS images, so the streaming attention kernels of
+    csrc/attention_tiled.hip run).  Forward + backward against the CPU oracle (depth 2 keeps the oracle in seconds)."""
+    import vits_returnftrs as vits
+    from mfvit.losses import cross_entropy
+    fus = importlib.import_module(FUS_MOD)
+    depth, B, img = 2, 2, 384
+    vit_p = [ref_vit.seeded_params(17 + i, num_classes=3, depth=depth, img_size=img) for i in range(2)]
+    fus_p = ref_fusion.seeded_fusion_params(19)
+    backs = []
+    for p in vit_p:
+        m = vits.vit_small(num_classes=3, depth=depth, precision=precision, img_size=img)
+        m.load_state_dict(p)
+        backs.append(m.to("cuda:0"))
+    model = fus.Fus_CrossViT(backs[0], backs[1])
+    model.load_state_dict(fus_p)
+    model = model.to("cuda:0")
+    x, xe = rng_tensor(91, (B, 3, img, img)), rng_tensor(92, (B, 3, img, img))
+    y = torch.tensor([2, 0])
+    fused, x_c, x_e = model(backs[0], backs[1], x.to("cuda:0"), xe.to("cuda:0"))
+    out = fused + x_c + x_e
+    loss, preds = cross_entropy(out, y.to("cuda:0"))
+    loss.backward()
+    fpd = {k: v.clone().requires_grad_(True) for k, v in fus_p.items()}
+    vpd = [{k: v.clone().requires_grad_(k != "pos_embed") for k, v in p.items()} for p in vit_p]
+    r_out, r_preds, r_loss, _ = ref_fusion.ca_step(fpd, vpd[0], vpd[1], x, xe, y)
+    r_loss.backward()
+    e_out = rel_err(out, r_out)
+    e_b = max(rel_err(backs[i].blocks[j].attn.qkv.weight.grad, vpd[i][f"blocks.{j}.attn.qkv.weight"].grad) for i in (0, 1) for j in (0, 1))
+    log(f"two-stream 384^2 CA step [{precision}]: logits {e_out:.2e} backbone-grad {e_b:.2e} loss {float(loss):.6f} vs {float(r_loss):.6f}")
+    assert e_out < tol and e_b < 2 * tol
+    if precision == "bf16x3":
+        assert preds.cpu().tolist() == r_preds.tolist()
