@@ -327,7 +327,12 @@ class VisionTransformerMoCo(nn.Module):
         # The flat gradient arena is reused from step to step (stable addresses: the optimizers' device tables stay valid) unless a
         # parameter still holds a gradient - accumulation over several backward passes, or a second pass through this encoder
         # inside one autograd run (MoCo-v3 feeds both views through the base encoder) - in which case a fresh one is allocated.
-        ga = getattr(self, "_grad_arena", None)
+        # ALIASING CONTRACT: gradient tensors handed out by one backward are views of this arena and are overwritten
+        # by the next backward once every parameter's .grad is None again.  A caller that keeps gradients outside .grad across steps
+        # (torch.autograd.grad results, detached copies of views kept after zero_grad(set_to_none=True)) must clone them, or switch
+        # the reuse off: MFVIT_GRAD_ARENA_REUSE=0 / model.reuse_grad_arena = False (a fresh arena per backward, 87 MB per encoder).
+        reuse = getattr(self, "reuse_grad_arena", os.environ.get("MFVIT_GRAD_ARENA_REUSE", "1") != "0")
+        ga = getattr(self, "_grad_arena", None) if reuse else None
         # (`_grad_arena_lent` covers the second case before autograd has accumulated the first pass's views into p.grad; it is
         # cleared by the next forward.)
         if (ga is not None and not getattr(self, "_grad_arena_lent", False) and ga.shape == self._arena.shape
@@ -388,9 +393,11 @@ class VisionTransformerMoCo(nn.Module):
 
     def forward_head(self, feats):
         h = self.head
-        if isinstance(h, nn.Linear) and h.out_features <= 64 and h.weight.dtype == torch.float32:
+        if isinstance(h, nn.Linear) and h.weight.dtype == torch.float32 and feats.is_cuda:
+            # every plain Linear head (3 classes after MAIN_CA:309, the constructor's default 1000, BLD:29's mlp_dim before it is
+            # replaced) runs on the row-dot head kernels over the cls rows: no rocBLAS call on the product path
             return _HeadFn.apply(feats, h.weight, h.bias)
-        return h(feats[:, 0])
+        return h(feats[:, 0])      # a module the caller installed (MoCo's projector MLP: HIP Linear / BatchNorm nodes of its own)
 
     def forward(self, x):
         """head(features3D(x)[:, 0])  (timm forward_features + head; all dropouts are 0)."""

@@ -202,3 +202,19 @@ def test_cpu_input_fails_loudly():
     m, _ = build("fp32", 531, depth=1)
     with pytest.raises(MfvitError):
         m(torch.zeros(1, 3, 224, 224))
+
+
+def test_default_1000_class_head_runs_on_the_hip_head_kernels():
+    """vits.vit_small() keeps timm's default 1000-way head; its forward / backward go through mfvit_head_fwd / _bwd (row-dot kernels
+    over the cls rows), not through a library GEMM - checked against the oracle's head on the same weights."""
+    m, p = build("bf16x3", 541, depth=1, num_classes=1000)
+    x = rng_tensor(542, (3, 3, 224, 224))
+    logits = m(x.to("cuda:0"))
+    assert logits.shape == (3, 1000) and type(logits.grad_fn).__name__ == "_HeadFnBackward"
+    pd = {k: v.double().requires_grad_(k.startswith("head")) for k, v in p.items()}
+    ref = ref_vit.head_linear(pd, ref_vit.features3d(pd, x.double())[:, 0])
+    assert scale_err(logits, ref) < 1e-3
+    r = rng_tensor(543, (3, 1000))
+    (logits * r.to("cuda:0")).sum().backward()
+    (ref * r.double()).sum().backward()
+    assert scale_err(m.head.weight.grad, pd["head.weight"].grad) < 1e-3 and scale_err(m.head.bias.grad, pd["head.bias"].grad) < 1e-3
