@@ -347,18 +347,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ('nccl' on ROCm) in production; MFVIT_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
-        dist.init_process_group(os.environ.get("MFVIT_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     if args.gpus != world:
         if rank == 0:
             print(f"[bench] --gpus {args.gpus} does not match WORLD_SIZE {world}: refusing to report a {world}-rank number as "
                   f"{args.gpus} GPUs", file=sys.stderr)
         sys.exit(2)
-    local = local % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
+    local = local % max(torch.cuda.device_count(), 1)      # (device_count() does not initialise the GPU)
+    torch.cuda.set_device(local)                           # bind the rank to its GPU BEFORE the communicator is created
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL ('nccl' on ROCm) in production; MFVIT_DIST_BACKEND=gloo lets several ranks share one GPU for rehearsals
+        dist.init_process_group(os.environ.get("MFVIT_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     from mfvit import _lib
     lib = _lib.lib()
 
