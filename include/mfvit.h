@@ -148,6 +148,13 @@ int mfvit_linear_dgrad_ln_bwd(int dtype, const void* dy, int64_t lddy, const voi
 int mfvit_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int head_dim, mfvit_stream_t stream);
 int mfvit_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias_qkv,
                         int B, int T, int H, int head_dim, mfvit_stream_t stream);
+/* FUSED multi-head self-attention forward (timm Attention.forward up to the output projection: qkv Linear -> softmax(q k^T / sqrt(d)) v;
+ * the "fused-attention kernel" of the north star): one workgroup per (image, head) computes the head's q, k, v from the LayerNorm-ed
+ * tokens x [B][T][D] and the packed weight wqkv [3D][D] (+ bias [3D] f32), keeps them on chip and runs the attention core.
+ * qkv_out [B][T][3][H][32] (optional, NULL = not written: no-grad forwards), out [B][T][D], lse [B][H][T].  dtype: MFVIT_BF16 |
+ * MFVIT_F16 | MFVIT_BF16X3 (x, wqkv, qkv_out, out in that type; split: leading dimensions in storage elements); head_dim 32, T <= 256. */
+int mfvit_mhsa_fused_fwd(int dtype, const void* x, int64_t ldx, const void* wqkv, int64_t ldw, const float* bias, void* qkv_out, void* out,
+                         float* lse, int B, int T, int H, int head_dim, int D, mfvit_stream_t stream);
 /* LayerNorm over rows of width N in {384, 768} (f32 in; y of dtype or f32). */
 int mfvit_layernorm_fwd(int dtype, const float* x, void* y, int y_f32, const float* gamma, const float* beta, float eps, float* mean,
                         float* rstd, int rows, int N, mfvit_stream_t stream);

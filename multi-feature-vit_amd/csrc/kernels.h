@@ -30,6 +30,11 @@ int attn_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, i
 int attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
              int H, int HD, hipStream_t st);
 
+// mhsa_fused.hip: QKV projection + attention core in one workgroup per (image, head) (head_dim 32, T <= 256; 16-bit types and split bf16)
+bool mhsa_fused_supported(int dtype, int Tn, int HDim, int D);
+int mhsa_fused_fwd(int dtype, const void* x, long ldx, const void* wqkv, long ldw, const float* bias, void* qkv_out, void* out, float* lse, int B,
+                   int Tn, int H, int D, hipStream_t st);
+
 int im2col16(int dtype, const float* img, void* P, int B, int H, int W, hipStream_t st);
 int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long ld1, int mod1, float* xout, long ldx, void* y, long ldy,
             int y_f32, const float* gamma, const float* beta, float eps, float* mean, float* rstd, int rows, int row_stride, int row_off,

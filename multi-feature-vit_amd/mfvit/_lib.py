@@ -56,6 +56,7 @@ SIGNATURES = {
     "mfvit_linear_dgrad_ln_bwd": (I, [I, P, L, P, L, P, P, P, P, P, P, P, P, P, P, I, I, P]),
     "mfvit_attention_fwd": (I, [I, P, P, P, I, I, I, I, P]),
     "mfvit_attention_bwd": (I, [I, P, P, P, P, P, P, I, I, I, I, P]),
+    "mfvit_mhsa_fused_fwd": (I, [I, P, L, P, L, P, P, P, P, I, I, I, I, I, P]),
     "mfvit_layernorm_fwd": (I, [I, P, P, I, P, P, F, P, P, I, I, P]),
     "mfvit_layernorm_bwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
     "mfvit_cast_transpose": (I, [I, P, P, P, I, I, P]),

@@ -140,6 +140,22 @@ def attention_fwd(qkv, heads, split=False):
     return out, lse
 
 
+def mhsa_fused_fwd(x, wqkv, bias, heads, want_qkv=True, split=False):
+    """Fused qkv projection + attention core: x [B,T,D], wqkv [3D,D] (both of the same 16-bit type; split: storage layout), bias [3D] f32
+    -> (out [B,T,D], lse [B,H,T], qkv [B,T,3D] or None)."""
+    require_cuda(x, wqkv, bias)
+    code = _code_of(x, split)
+    e = 2 if split else 1
+    B, T, De = x.shape
+    D = De // e
+    out = torch.empty(B, T, D * e, device=x.device, dtype=x.dtype)
+    lse = torch.empty(B, heads, T, device=x.device, dtype=torch.float32)
+    qkv = torch.empty(B, T, 3 * D * e, device=x.device, dtype=x.dtype) if want_qkv else None
+    check(lib().mfvit_mhsa_fused_fwd(code, ptr(x), x.stride(1), ptr(wqkv), wqkv.stride(0), ptr(bias), ptr(qkv), ptr(out), ptr(lse), B, T, heads,
+                                     D // heads, D, stream()), "mfvit_mhsa_fused_fwd")
+    return out, lse, qkv
+
+
 def attention_bwd(qkv, out, dout, lse, heads, want_dbias=True, split=False):
     require_cuda(qkv, out, dout, lse)
     code = _code_of(qkv, split)

@@ -389,3 +389,65 @@ def test_two_stream_384_ca_step(precision, tol):
     assert e_out < tol and e_b < 2 * tol
     if precision == "bf16x3":
         assert preds.cpu().tolist() == r_preds.tolist()
+
+
+@pytest.mark.parametrize("mode", ATT_MODES, ids=[m.name for m in ATT_MODES])
+@pytest.mark.parametrize("B,T", [(2, 197), (3, 50), (1, 256), (2, 33)])
+def test_fused_mhsa_forward(mode, B, T):
+    """mfvit_mhsa_fused_fwd (csrc/mhsa_fused.hip: qkv projection + attention core in one workgroup per (image, head)) against float64
+    math on the same rounded inputs: attention output, log-sum-exp and the qkv tensor it hands to the backward; and against the
+    separate qkv GEMM + attention kernels (same operands -> same results up to the rounding of the stored q, which the fused kernel
+    never rounds for its own use)."""
+    from mfvit import ops
+    H, D = 12, 384
+    x, w, bias = rnd((B, T, D), 31), rnd((3 * D, D), 32, 0.05), rnd((3 * D,), 33, 0.5)
+    xr, wr = mode.rounded(x), mode.rounded(w)
+    qkv_ref = xr @ wr.t() + bias.double()
+    o_ref, lse_ref = _attn_ref(qkv_ref, H)
+    out, lse, qkv = ops.mhsa_fused_fwd(mode.pack(x), mode.pack(w), bias.to(dev()), H, split=mode.split)
+    e_q, e_o, e_l = rel_err(mode.unpack(qkv), qkv_ref), rel_err(mode.unpack(out), o_ref), rel_err(lse, lse_ref)
+    out2, lse2, none = ops.mhsa_fused_fwd(mode.pack(x), mode.pack(w), bias.to(dev()), H, want_qkv=False, split=mode.split)
+    assert none is None and torch.equal(out2, out) and torch.equal(lse2, lse)                    # the no-grad form: same numbers, no qkv
+    qkv_u = ops.linear_fwd(mode.pack(x).reshape(B * T, -1), mode.pack(w), bias.to(dev()), split=mode.split).reshape(B, T, -1)
+    out_u, lse_u = ops.attention_fwd(qkv_u, H, split=mode.split)
+    e_u = rel_err(mode.unpack(out), mode.unpack(out_u).double())
+    log(f"fused MHSA[{mode.name},B={B},T={T}] qkv {e_q:.2e} out {e_o:.2e} lse {e_l:.2e} vs unfused {e_u:.2e}")
+    t_l = 1e-5 if mode.split else (2e-3 if mode.name == "fp16" else 1.5e-2)      # lse carries the rounding of x and W
+    assert e_q < mode.tol and e_o < 2 * mode.tol and e_l < t_l and e_u < 2 * mode.tol
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+def test_encoder_with_fused_mhsa_matches_unfused(precision, tmp_path):
+    """MFVIT_MHSA_FUSED is read once per process: the encoder-level switch is exercised in a child process - forward features and all
+    gradients of a depth-2 encoder with the fused kernel against the default path."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path[:0] = [%r, %r]\n"
+        "import vits\n"
+        "from conftest import rng_tensor\n"
+        "from oracle import ref_vit\n"
+        "m = vits.vit_small(num_classes=3, depth=2, precision=%r); m.load_state_dict(ref_vit.seeded_params(551, num_classes=3, depth=2)); m = m.to('cuda:0')\n"
+        "x = rng_tensor(552, (3, 3, 224, 224)).to('cuda:0'); w = rng_tensor(553, (3, 197, 384)).to('cuda:0')\n"
+        "f = m.features3D(x); (f * w).sum().backward()\n"
+        "with torch.no_grad(): g = m.features3D(x)\n"
+        "torch.save({'f': f.detach().cpu(), 'g': g.cpu(), 'grad': m._last_grad_arena.cpu()}, sys.argv[1])\n"
+    ) % (os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multi-feature-vit_amd"),
+         os.path.dirname(os.path.abspath(__file__)), precision)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ("0", "1", "2"):
+        path = os.path.join(str(tmp_path), f"fused_{precision}_{mode}.pt")
+        env = dict(os.environ, MFVIT_MHSA_FUSED=mode, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(path))
+    base, fused, nograd_only = outs
+    tol = 2e-2 if precision == "bf16" else 1e-4
+    for k in ("f", "g", "grad"):
+        assert rel_err(fused[k], base[k].double()) < tol, (k, rel_err(fused[k], base[k].double()))
+    # mode 2: the training forward is the default path (bit-identical features; the weight gradients carry float atomics, whose order
+    # differs from run to run)
+    assert torch.equal(nograd_only["f"], base["f"]) and rel_err(nograd_only["grad"], base["grad"].double()) < 1e-5
+    assert rel_err(nograd_only["g"], base["g"].double()) < tol
+    log(f"encoder with fused MHSA [{precision}]: features {rel_err(fused['f'], base['f'].double()):.2e} grads {rel_err(fused['grad'], base['grad'].double()):.2e}")

@@ -2,10 +2,12 @@
 # usage: bash tools/kstats.sh <tag> <python script + args>   -> prints per-kernel average duration (rocprofv3 --kernel-trace --stats)
 tag=$1; shift
 R=$(pwd)
+script=$1; shift
+[[ $script != /* ]] && script=$R/$script      # rocprofv3 runs from /tmp: make the script path absolute
 out=$R/gpurun_out/ks_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 "$@" > $out/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 "$script" "$@" > $out/log.txt 2>&1
 cd $R
 python3 - $out <<'PY'
 import csv, glob, sys, os
