@@ -30,7 +30,13 @@ template <typename T> struct FT {
     static constexpr bool SP = is_split<T>::value;
     static constexpr int EP = SP ? 2 : 1;
     static constexpr int RB = 64 * EP;           // bytes of one head row piece
-    static constexpr int PITCH = RB + 16;        // K / V image pitch
+    // K / V image pitch.  Every access to these images is 8 bytes wide (accumulator-order ds_read_b64 row reads, ds_read_b64_tr_b16,
+    // 8-byte row-piece stores), so the rows only need 8-byte alignment: with RB + 8 (18 / 34 dwords) the 32 rows of a ds_read_b64
+    // group fall into 32 distinct bank pairs (conflict free); RB + 16 made rows r and r + 16 collide (6.3 M conflict cycles per launch).
+    static constexpr int PITCH = RB + 8;
+    // V image: read only through ds_read_b64_tr_b16 (4 rows x 32 B per 16 lanes): plain 64-byte rows WITHOUT padding put the 4 rows of a
+    // block into 4 disjoint 16-dword windows (conflict free); split rows keep the K pitch (rows q, q + 2 overlap partly either way)
+    static constexpr int VPITCH = SP ? RB + 8 : RB;
     typedef typename Vec8<T>::type frag_t;
     typedef typename Vec4<T>::type vec4_t;
     typedef typename Vec4<T>::elem E;
@@ -71,9 +77,9 @@ template <typename T> __device__ __forceinline__ typename Vec8<T>::type f_row_fr
 // transposed fragment of the V image in ACCUMULATOR k order (as attention_mfma.hip::tr_frag)
 template <typename T> __device__ __forceinline__ typename Vec8<T>::type f_tr_frag(const char* img, int rowbase, int s, int lane, int part) {
     const int h = lane >> 5, g1 = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
-    const char* a = img + (rowbase + 16 * s + 4 * h + q) * FT<T>::PITCH + 64 * part + (16 * g1 + 4 * p) * 2;
+    const char* a = img + (rowbase + 16 * s + 4 * h + q) * FT<T>::VPITCH + 64 * part + (16 * g1 + 4 * p) * 2;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + 8 * FT<T>::PITCH));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + 8 * FT<T>::VPITCH));
     union { struct { s16x4 a, b; } s; typename Vec8<T>::type v; } u;
     u.s.a = lo;
     u.s.b = hi;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(FNT, 1) void mhsa_fused_fwd_kernel(const typename V
         const bool live = tok < Tn;
         // keys / values past the end: zero rows (their scores are masked below, their V rows must not hold NaNs)
         f_store_tile_T<T>((E*)(Ks + tok * F::PITCH), acc[1], live ? 1.0f : 0.0f, lane);
-        f_store_tile_T<T>((E*)(Vs + tok * F::PITCH), acc[2], live ? 1.0f : 0.0f, lane);
+        f_store_tile_T<T>((E*)(Vs + tok * F::VPITCH), acc[2], live ? 1.0f : 0.0f, lane);
         if (qkv_out && live) {
             E* dst = qkv_out + ((long)b * Tn + tok) * 3 * H * FH * EP + (long)h * FH * EP;
             f_store_tile_T<T>(dst, acc[0], 1.0f, lane);
@@ -285,7 +291,7 @@ template <typename T> int launch_fused(const void* x, long ldx, const void* wqkv
                                        int B, int Tn, int H, int D, hipStream_t st) {
     typedef typename Vec4<T>::elem E;
     const int Tpad = (Tn + 31) & ~31;
-    const int stage = (96 + Tpad) * 128, images = 2 * Tpad * FT<T>::PITCH;
+    const int stage = (96 + Tpad) * 128, images = Tpad * (FT<T>::PITCH + FT<T>::VPITCH);
     const int bytes = 2 * stage > images ? 2 * stage : images;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)mhsa_fused_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
