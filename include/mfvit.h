@@ -118,7 +118,8 @@ int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const 
                      int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream);
 /* Experimental second implementation of the same linear (bf16 only; N % 128 == 0, N <= 1536, K % 32 == 0, K >= 128, M >= 1024):
  * persistent 256x128-tile kernel with an LDS-DMA ring pipelined across tiles (csrc/gemm_pers.hip).  Same results; opt-in
- * for the encoder with MFVIT_PERS=1. */
+ * for the encoder with MFVIT_PERS=1.  epilogue + 100 selects the split-bf16 instantiation (MFVIT_BF16X3 operands and outputs in the I32
+ * layout, leading dimensions in storage elements; K % 32 == 0; opt-in for the encoder with MFVIT_PERS_SPLIT=1). */
 int mfvit_linear_fwd_persistent(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                                 int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream);
 /* Experimental third implementation (bf16; N % 128 == 0, N <= 1536, K % 64 == 0, K >= 128, M >= 1024): warp-specialised

@@ -731,7 +731,7 @@ static int tn_by_dtype(int dtype, const GemmP& p, hipStream_t st) { MFVIT_BY_DTY
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
     if (gemm_nt_ws_supported(dtype, epi, p)) return gemm_nt_ws(epi, p, st);
-    if (gemm_nt_pers_supported(dtype, epi, p)) return gemm_nt_pers(epi, p, st);
+    if (gemm_nt_pers_supported(dtype, epi, p)) return gemm_nt_pers(dtype, epi, p, st);
     if (epi == EPI_GELU_BWD && p.cpart && p.cs0) {
         const int rc = tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
         if (rc != MFVIT_OK) return rc;

@@ -9,7 +9,7 @@ enum { REPI_RES_LN = 0, REPI_LNBWD_RES = 1 };
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st);
 bool gemm_nt_pers_supported(int dtype, int epi, const GemmP& p, bool force = false);   // gemm_pers.hip: persistent 256x128 kernel (bf16, short K)
-int gemm_nt_pers(int epi, const GemmP& p, hipStream_t st);
+int gemm_nt_pers(int dtype, int epi, const GemmP& p, hipStream_t st);
 bool gemm_nt_ws_supported(int dtype, int epi, const GemmP& p, bool force = false);   // gemm_ws.hip: warp-specialised persistent kernel
 int gemm_nt_ws(int epi, const GemmP& p, hipStream_t st);
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st);

@@ -624,13 +624,15 @@ int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const 
 int mfvit_linear_fwd_persistent(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                                 int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream) {
     if (!x || !w || !y) return MFVIT_EINVAL;
+    const int pdt = epilogue >= 100 ? MFVIT_BF16X3 : MFVIT_BF16;     // epilogue + 100: the split-bf16 instantiation (I32 operands / outputs)
+    epilogue = epilogue >= 100 ? epilogue - 100 : epilogue;
     if (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU && epilogue != EPI_NONE) return MFVIT_EINVAL;
     if (epilogue == EPI_BIAS_GELU && !y2) return MFVIT_EINVAL;
     GemmP p = zero_gemm();
     p.A = x; p.lda = ldx; p.W = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
     p.bias = bias; p.out0 = y; p.ldo0 = ldy; p.out1 = y2; p.ldo1 = ldy2;
-    if (!gemm_nt_pers_supported(MFVIT_BF16, epilogue, p, true)) return MFVIT_EINVAL;
-    return gemm_nt_pers(epilogue, p, (hipStream_t)stream);
+    if (!gemm_nt_pers_supported(pdt, epilogue, p, true)) return MFVIT_EINVAL;
+    return gemm_nt_pers(pdt, epilogue, p, (hipStream_t)stream);
 }
 int mfvit_linear_fwd_ws(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
                         void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream) {

@@ -61,8 +61,8 @@ def linear_fwd(x, w, bias=None, gelu=False, persistent=False, split=False):
                                         stream()), "mfvit_linear_fwd_ws")
         return (y, y2) if gelu else y
     if persistent:
-        check(lib().mfvit_linear_fwd_persistent(epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N, ptr(y2), N, M, N, K,
-                                                stream()), "mfvit_linear_fwd_persistent")
+        check(lib().mfvit_linear_fwd_persistent(epi + (100 if split else 0), ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N * e,
+                                                ptr(y2), N * e, M, N, K, stream()), "mfvit_linear_fwd_persistent")
         return (y, y2) if gelu else y
     check(lib().mfvit_linear_fwd(code, epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N * e, ptr(y2), N * e, M, N, K,
                                  stream()), "mfvit_linear_fwd")

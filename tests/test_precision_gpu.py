@@ -451,3 +451,23 @@ def test_encoder_with_fused_mhsa_matches_unfused(precision, tmp_path):
     assert torch.equal(nograd_only["f"], base["f"]) and rel_err(nograd_only["grad"], base["grad"].double()) < 1e-5
     assert rel_err(nograd_only["g"], base["g"].double()) < tol
     log(f"encoder with fused MHSA [{precision}]: features {rel_err(fused['f'], base['f'].double()):.2e} grads {rel_err(fused['grad'], base['grad'].double()):.2e}")
+
+
+@pytest.mark.parametrize("M,N,K", [(197 * 128, 1152, 384), (197 * 33 + 5, 1536, 384), (1100, 384, 1536), (4096, 128, 128)])
+def test_split_linear_fwd_persistent(M, N, K):
+    """The persistent 256x128 LDS-DMA kernel (csrc/gemm_pers.hip) in its split-bf16 instantiation: against float64 math and, bit for
+    bit, against the default 128x128 split kernel (same products in the same order per output element), all three epilogues."""
+    from mfvit import ops
+    mode = MODES[0]
+    x, w, b = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3)
+    xd, wd, bd = mode.pack(x), mode.pack(w), b.to(dev())
+    ref = mode.rounded(x) @ mode.rounded(w).t() + b.double()
+    y = ops.linear_fwd(xd, wd, bd, persistent=True, split=True)
+    e = rel_err(mode.unpack(y), ref)
+    log(f"split linear_fwd_persistent[{M},{N},{K}] {e:.2e}")
+    assert e < SPLIT_TOL
+    assert torch.equal(y, ops.linear_fwd(xd, wd, bd, split=True))
+    dact, act = ops.linear_fwd(xd, wd, bd, gelu=True, persistent=True, split=True)
+    dact0, act0 = ops.linear_fwd(xd, wd, bd, gelu=True, split=True)
+    assert torch.equal(dact, dact0) and torch.equal(act, act0)
+    assert torch.equal(ops.linear_fwd(xd, wd, None, persistent=True, split=True), ops.linear_fwd(xd, wd, None, split=True))
