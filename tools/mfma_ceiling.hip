@@ -1,7 +1,7 @@
 // Pure-MFMA ceiling of gfx950 for v_mfma_f32_32x32x16_bf16 (and the f16 twin): no LDS, no global loads in the loop, no epilogue -
 // what the matrix cores sustain under load (clock included).  Every GEMM roofline fraction in DESIGN.md is also quoted against THIS
 // number (the "practical ceiling"), next to the 2.5 PFLOP/s datasheet peak.
-//   hipcc --offload-arch=gfx950 -O3 tools/mfma_ceiling.hip -o tools/mfma_ceiling && tools/mfma_ceiling [waves_per_simd] [random|zero]
+//   hipcc --offload-arch=gfx950 -O3 tools/mfma_ceiling.hip -o tools/mfma_ceiling && tools/mfma_ceiling [waves_per_simd] [random|zero] [accumulators]
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,7 +41,8 @@ int main(int argc, char** argv) {
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
     const int blocks = cus * wps;                                   // 256 threads = 4 waves = one per SIMD
-    const int iters = 20000, NACC = 8;
+    const int iters = 20000;
+    const int NACC = argc > 3 ? atoi(argv[3]) : 8;                  // independent accumulators per wave: 8 (default), 4, 2, 1
     bf16x8* in;
     float* out;
     hipMalloc(&in, 65536 * sizeof(bf16x8));
@@ -59,12 +60,18 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(mfma_loop<NACC>, dim3(blocks), dim3(256), 0, 0, in, out, 2000);           // warm-up (clock ramp)
+    auto launch = [&](int it) {
+        if (NACC == 8) hipLaunchKernelGGL(mfma_loop<8>, dim3(blocks), dim3(256), 0, 0, in, out, it);
+        else if (NACC == 4) hipLaunchKernelGGL(mfma_loop<4>, dim3(blocks), dim3(256), 0, 0, in, out, it);
+        else if (NACC == 2) hipLaunchKernelGGL(mfma_loop<2>, dim3(blocks), dim3(256), 0, 0, in, out, it);
+        else hipLaunchKernelGGL(mfma_loop<1>, dim3(blocks), dim3(256), 0, 0, in, out, it);
+    };
+    launch(2000);                                                                                  // warm-up (clock ramp)
     hipDeviceSynchronize();
     float best = 1e30f, ms;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(mfma_loop<NACC>, dim3(blocks), dim3(256), 0, 0, in, out, iters);
+        launch(iters);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
