@@ -447,7 +447,7 @@ def main():
                    loss=float(loss.detach()), roofline=roof)
         print("[bench] gpu " + json.dumps(out), file=sys.stderr, flush=True)
         ref_out = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is an N = 1 measurement (the other ranks would only wait for it)
             cb, ref_out = cpu_baseline(args, run.model, run.backs, run.x, run.xe, run.target)
             out["cpu_baseline"] = cb
             par = parity_vs_oracle(run, ref_out)      # same (final) weights as the oracle copy, same first pairs
