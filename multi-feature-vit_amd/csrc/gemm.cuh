@@ -89,23 +89,29 @@ template <int R, int BKB> struct KTile<float, R, BKB> {
 };
 
 // Register-staged global -> LDS copy of a K-contiguous tile (R rows x BKB bytes) by NT threads.
-template <typename T, int R, int BKB, int NT> struct KStage {
+// HALF (split tensors, BKB = 64): the tile is HALF a 32-wide k group - storage elements [hi x 16 | lo x 16] of group k0 / 64, half
+// (k0 / 32) & 1 - so that a double-buffered stage is 64 B per row and two workgroups fit a CU (row-complete kernels); the LDS row is then
+// MFMA step 0 = hi, step 1 = lo.  k0 counts storage elements in steps of 32 as for any other tile.
+template <typename T, int R, int BKB, int NT, bool HALF = false> struct KStage {
     typedef KTile<T, R, BKB> Tile;
     static constexpr int CPR = BKB / 16;
     static constexpr int TOTAL = R * CPR;
     static constexpr int NCH = (TOTAL + NT - 1) / NT;
     static constexpr int EPC = 16 / sizeof(T);  // elements per chunk
     static_assert(TOTAL % NT == 0 || TOTAL < NT, "tile chunks must divide over the block (or fit in one pass)");
+    static_assert(!HALF || (BKB == 64 && is_split<T>::value), "half-group tiles are a split-tensor layout");
     uint4 reg[NCH];
     // rows >= rmax are clamped (their products are never stored)
     __device__ __forceinline__ void load(const T* base, long ld, int row0, int rmax, int k0, int tid) {
+        const int kb = HALF ? (k0 & ~63) + ((k0 >> 5) & 1) * 16 : k0;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int q = tid + i * NT, row = q / CPR, c = q % CPR;
             if (TOTAL < NT && q >= TOTAL) continue;
             int gr = row0 + row;
             gr = gr < rmax ? gr : rmax - 1;
-            reg[i] = *(const uint4*)(base + (long)gr * ld + k0 + c * EPC);
+            const int co = HALF ? (c >> 1) * 32 + (c & 1) * 8 : c * EPC;
+            reg[i] = *(const uint4*)(base + (long)gr * ld + kb + co);
         }
     }
     __device__ __forceinline__ void store(char* t, int tid) const {
@@ -248,11 +254,39 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
     static constexpr int STAGE_BYTES = TA::BYTES + TB::BYTES;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
     static constexpr bool SPLIT = is_split<T>::value;
-    static_assert(!SPLIT || BKB == 128, "a split K tile is one 32-wide k group: [hi x 32 | lo x 32] = 128 bytes per row");
+    static constexpr bool HALF = SPLIT && BKB == 64;   // half a k group per tile, see KStage
+    // (Tried for the two-workgroups-per-CU row kernels and dropped: the activation chunk - ONE 16-byte load per thread and tile - fetched
+    // three tiles ahead through a rotating register queue, weight loads issued first so that the in-order vmcnt does not wait for the
+    // youngest activation load.  hipcc's waitcnt insertion treats the loop-carried reuse of a queue register as a hazard and puts a
+    // vmcnt(0..2) in front of every deep load, i.e. right behind the six weight loads of the tile - slower than the plain loop.)
+    static_assert(!SPLIT || BKB == 128 || BKB == 64, "a split K tile is one 32-wide k group ([hi x 32 | lo x 32] = 128 bytes per row) or half of one");
 
     // the MFMAs of one K tile held in LDS (ta: A rows, tb: W rows)
     static __device__ __forceinline__ void compute(const char* ta, const char* tb, int wm, int wn, int lane, f32x16 (&acc)[TM][TN]) {
-        if constexpr (SPLIT) {
+        if constexpr (HALF) {
+            // one 16-wide k step per tile: MFMA step 0 of the row = hi, step 1 = lo
+            typename MmaTraits<T>::frag_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) al[i] = TA::frag(ta, (wm * TM + i) * 32, 1, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bh[j] = TB::frag(tb, (wn * TN + j) * 32, 0, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ah[i] = TA::frag(ta, (wm * TM + i) * 32, 0, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bl[j] = TB::frag(tb, (wn * TN + j) * 32, 1, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(al[i], bh[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[i], bh[j], acc[i][j]);
+        } else if constexpr (SPLIT) {
             // split product: per 16-wide k step  acc += a_lo b_hi + a_hi b_lo + a_hi b_hi  (3 MFMAs from 4 fragments; the fragments
             // of step 1 are read while the 12 - 18 MFMAs of step 0 run).  MFMA steps 0, 1 of the row are the hi parts, 2, 3 the lo
             // parts (KTile<sbf16>).
@@ -335,8 +369,8 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         const int nk = p.K * elems_per<T>::value / BK;      // K tiles over the STORAGE width
         {
-            KStage<T, BM, BKB, NT> sa;
-            KStage<T, BN, BKB, NT> sb;
+            KStage<T, BM, BKB, NT, HALF> sa;
+            KStage<T, BN, BKB, NT, HALF> sb;
             sa.load(A, p.lda, m0, p.M, 0, tid);
             sb.load(W, p.ldw, n0, p.N, 0, tid);
             sa.store(lds, tid);

@@ -141,7 +141,7 @@ constexpr int ROW_BN = 384, ROW_BKB = 64, ROW_RS = 132;
 
 // Full-row totals of per-lane partials p[i][r] (row = i*32 + acc_row(r)), summed over the 32 column lanes of the
 // 4 waves, through LDS (red: [64][132] floats, tot: [64]).  Three barriers; all 256 threads must call it.
-template <int TM, int BM, int NTHREADS>
+template <int TM, int BM, int NTHREADS, bool READBACK = true>
 __device__ __forceinline__ void row_reduce(float (&p)[TM][16], float* red, float* tot, int lane, int wm, int wn, int tid) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -161,15 +161,293 @@ __device__ __forceinline__ void row_reduce(float (&p)[TM][16], float* red, float
         if (q == 0) tot[row] = s;
     }
     __syncthreads();
+    if constexpr (READBACK) {       // (otherwise the caller reads tot[] when it needs a total; red is free again after the barrier above)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) p[i][r] = tot[(wm * TM + i) * 32 + acc_row(r, lane)];
-    __syncthreads();
+            for (int r = 0; r < 16; ++r) p[i][r] = tot[(wm * TM + i) * 32 + acc_row(r, lane)];
+        __syncthreads();
+    }
 }
 
+// Epilogues of the TWO-WORKGROUPS-PER-CU row kernel (4 waves side by side, 64 x 96 per wave: TM = 2, TN = 3; 256 registers).  Same
+// arithmetic as the epilogues inside gemm_nt_row_kernel below, organised for the register budget: row partials go straight into the LDS
+// reduction arrays and the row totals / saved statistics are read back from LDS where they are used (no [TM][16] register copies), the
+// LayerNorm backward recomputes the normalised input from a second read of x (L2: this workgroup fetched it a moment ago) instead of
+// keeping it in 96 registers, and global loads are issued in batches of 24 - 48 with the arithmetic behind a scheduling barrier.
+constexpr int ROW_LEAN_LDS = 2 * 64 * ROW_RS * 4 + 4 * 64 * 4;
+template <typename T, int REPI, int BM, int TM, int TN>
+__device__ __forceinline__ void row_epilogue_lean(const GemmP& p, int m0, f32x16 (&acc)[TM][TN], char* lds) {
+    static_assert(BM == 64 && TM == 2, "one row of four waves over a 64-row tile");
+    constexpr int BN = ROW_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    float* red1 = (float*)lds;
+    float* red2 = red1 + BM * ROW_RS;
+    float* tot1 = red2 + BM * ROW_RS;
+    float* tot2 = tot1 + BM;
+    float* smu = tot2 + BM;
+    float* srs = smu + BM;
+    const float invN = 1.0f / (float)BN;
+    int ncol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) ncol[j] = (wn * TN + j) * 32 + (lane & 31);
+    auto lrow = [&](int i, int r) { return i * 32 + acc_row(r, lane); };
+    auto put = [&](float* red, int i, int r, float v) { red[lrow(i, r) * ROW_RS + wn * 32 + (lane & 31)] = v; };
+    // totals of the 128 partials of every row: thread (row, quarter) sums 32 of them, two shuffles finish the row
+    auto finish = [&](const float* ra, float* ta, const float* rb, float* tb) {
+        __syncthreads();
+        const int row = tid >> 2, q = tid & 3;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const float* red = w ? rb : ra;
+            if (!red) continue;
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 v = *(const float4*)&red[row * ROW_RS + 32 * q + 4 * k];
+                sum += (v.x + v.y) + (v.z + v.w);
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            if (q == 0) (w ? tb : ta)[row] = sum;
+        }
+        __syncthreads();
+    };
+
+    if constexpr (REPI == REPI_RES_LN) {
+        float bj[TN], gj[TN], btj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bj[j] = p.bias ? p.bias[ncol[j]] : 0.f;
+            gj[j] = p.gamma[ncol[j]];
+            btj[j] = p.beta[ncol[j]];
+        }
+        const float* __restrict__ resp = p.res;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {           // v = acc + bias + residual: 48 loads in flight, then the adds
+            if (resp) {
+                float t[16][TN];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + lrow(i, r);
+                    const int mm = m < p.M ? m : p.M - 1;
+                    const long rrow = p.res_mod ? (mm % p.res_mod) + p.res_off : out_row(p, mm);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) t[r][j] = resp[rrow * p.ldres + ncol[j]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j][r] += bj[j] + t[r][j];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j][r] += bj[j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) sum += acc[i][j][r];
+                put(red1, i, r, sum);
+            }
+        finish(red1, tot1, nullptr, nullptr);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {       // two-pass variance
+                const float mu = tot1[lrow(i, r)] * invN;
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float d = acc[i][j][r] - mu;
+                    sum += d * d;
+                }
+                put(red1, i, r, sum);
+            }
+        finish(red1, tot2, nullptr, nullptr);
+        int m0c = m0;
+        asm volatile("" : "+s"(m0c));            // fresh row arithmetic for the stores (no 32 row offsets kept alive from the loads)
+        float* __restrict__ xo = (float*)p.out0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {       // stores only; padded rows replicate row M-1 -> identical duplicate stores
+                const int mraw = m0c + lrow(i, r);
+                const int m = mraw < p.M ? mraw : p.M - 1;
+                const int orow = out_row(p, m);
+                const float mu = tot1[lrow(i, r)] * invN;
+                const float rs = rsqrtf(tot2[lrow(i, r)] * invN + p.eps);
+                if (wn == 0 && (lane & 31) == 0 && p.mean) {
+                    p.mean[orow] = mu;
+                    p.rstd[orow] = rs;
+                }
+                if (xo) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) xo[(long)orow * p.ldo0 + ncol[j]] = acc[i][j][r];
+                }
+                if (p.y_f32) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) ((float*)p.out1)[(long)orow * p.ldo1 + ncol[j]] = (acc[i][j][r] - mu) * rs * gj[j] + btj[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        store_elem<T>((T*)p.out1 + (long)orow * p.ldo1, ncol[j], (acc[i][j][r] - mu) * rs * gj[j] + btj[j]);
+                }
+            }
+    } else {  // REPI_LNBWD_RES: acc = dL/dy (y = LN output); aux = saved LN input x (f32)
+        float gj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) gj[j] = p.gamma[ncol[j]];
+        const float* __restrict__ auxp = (const float*)p.aux;
+        const float* __restrict__ resp = p.res;
+        if (tid < BM) {                          // the saved statistics of the workgroup's rows, once
+            const int mm = m0 + tid < p.M ? m0 + tid : p.M - 1;
+            smu[tid] = p.mean[mm];
+            srs[tid] = p.rstd[mm];
+        }
+        __syncthreads();
+        float cs_g[TN], cs_b[TN], cs_x[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) cs_g[j] = cs_b[j] = cs_x[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float xv[16][TN];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + lrow(i, r);
+                const int mm = m < p.M ? m : p.M - 1;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) xv[r][j] = auxp[(long)mm * p.ldaux + ncol[j]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = m0 + lrow(i, r) < p.M;
+                const float mu = smu[lrow(i, r)], rs = srs[lrow(i, r)];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float h = (xv[r][j] - mu) * rs;
+                    const float dy = acc[i][j][r];      // padded rows replicate row M-1; only the column sums mask them
+                    const float g = dy * gj[j];
+                    s1 += g;
+                    s2 += g * h;
+                    cs_g[j] += ok ? dy * h : 0.f;
+                    cs_b[j] += ok ? dy : 0.f;
+                }
+                put(red1, i, r, s1);
+                put(red2, i, r, s2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // pin the column sums here: left alone, the compiler sinks their whole accumulation chain below the branches of phase 2 and carries
+        // the 96 h values (in scratch) and the 96 dy values to get there
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(cs_g[j]), "+v"(cs_b[j]));
+        finish(red1, tot1, red2, tot2);
+        // the second read of x: launder the row base and the pointer, or the compiler proves the loads redundant and keeps the 96
+        // values of the first read alive across the reduction - in scratch
+        int m0b = m0;
+        const float* x2 = auxp;
+        asm volatile("" : "+s"(m0b), "+s"(x2));
+        float gj2[TN];                            // likewise dy * gamma: one multiply again instead of 96 values carried over
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            gj2[j] = gj[j];
+            asm volatile("" : "+v"(gj2[j]));
+        }
+        auto phase2 = [&](auto has_res) {
+            constexpr bool RES = decltype(has_res)::value;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    float xv[8][TN], rv[8][RES ? TN : 1];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int m = m0b + lrow(i, hf * 8 + e);
+                        const int mm = m < p.M ? m : p.M - 1;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            xv[e][j] = x2[(long)mm * p.ldaux + ncol[j]];
+                            if constexpr (RES) rv[e][j] = resp[(long)mm * p.ldres + ncol[j]];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = hf * 8 + e;
+                        const bool ok = m0b + lrow(i, r) < p.M;
+                        const float mu = smu[lrow(i, r)], rs = srs[lrow(i, r)];
+                        const float c1 = tot1[lrow(i, r)] * invN, c2 = tot2[lrow(i, r)] * invN;
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float h = (xv[e][j] - mu) * rs;
+                            float dx = rs * (acc[i][j][r] * gj2[j] - c1 - h * c2);
+                            if constexpr (RES) dx += rv[e][j];
+                            acc[i][j][r] = dx;
+                            cs_x[j] += ok ? dx : 0.f;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        };
+        if (resp)
+            phase2(std::true_type());
+        else
+            phase2(std::false_type());
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(cs_x[j]));
+        int m0c = m0;
+        asm volatile("" : "+s"(m0c));
+        float* __restrict__ dxo = (float*)p.out0;
+        T* __restrict__ dxt = (T*)p.out1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {       // stores only
+                const int mraw = m0c + lrow(i, r);
+                const int m = mraw < p.M ? mraw : p.M - 1;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) dxo[(long)m * p.ldo0 + ncol[j]] = acc[i][j][r];
+                if (dxt) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) store_elem<T>(dxt + (long)m * p.ldo1, ncol[j], acc[i][j][r]);
+                }
+            }
+        // column sums: red1 is free (the totals live behind red2); [3][BN] scratch
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float a = cs_g[j], b = cs_b[j], c = cs_x[j];
+            a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 32, 64);
+            c += __shfl_xor(c, 32, 64);
+            if (lane < 32) {
+                if (p.cpart) {
+                    p.cpart[(long)blockIdx.x * 3 * BN + 0 * BN + ncol[j]] = a;      // one wave row: the per-workgroup partial IS the wave's
+                    p.cpart[(long)blockIdx.x * 3 * BN + 1 * BN + ncol[j]] = b;
+                    p.cpart[(long)blockIdx.x * 3 * BN + 2 * BN + ncol[j]] = c;
+                } else {
+                    if (p.cs0) atomicAdd(p.cs0 + ncol[j], a);
+                    if (p.cs1) atomicAdd(p.cs1 + ncol[j], b);
+                    if (p.cs2) atomicAdd(p.cs2 + ncol[j], c);
+                }
+            }
+        }
+    }
+}
+
+// WM == 1 (4 waves, 64 x 96 per wave, 16-bit types with a 64-byte K tile = 56 KB of LDS): built for TWO workgroups per CU - the register
+// budget is forced to 256 and the LayerNorm-backward epilogue recomputes the normalised input instead of keeping it (RECOMP).
 template <typename T, int REPI, int WM, int BKB, int BM>
-__global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
+__global__ __launch_bounds__(WM * 256, (WM == 1 && sizeof(T) == 2) ? 2 : 1) void gemm_nt_row_kernel(GemmP p) {
     constexpr int BN = ROW_BN, WN = 4;
     typedef NtLoop<T, BM, BN, BKB, WM, WN> Loop;
     constexpr int TM = Loop::TM, TN = Loop::TN;  // (2 | 1) x 3
@@ -195,6 +473,11 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
         Loop::run(p, m0, 0, lds, acc);  // ends with a barrier: the staging LDS is free from here on
     }
 
+    constexpr bool LEAN = WM == 1 && sizeof(T) == 2 && BM == 64;      // the two-workgroups-per-CU variant: 256 registers
+    if constexpr (LEAN) {
+        row_epilogue_lean<T, REPI, BM, TM, TN>(p, m0, acc, lds);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     float* red = (float*)lds;
@@ -290,11 +573,11 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j) gj[j] = p.gamma[ncol[j]];
         const float* __restrict__ auxp = (const float*)p.aux;
         const float* __restrict__ resp = p.res;
-        f32x16 xh[TM][TN];
-        float p1[TM][16], p2[TM][16], rsv[TM][16];
         float cs_g[TN], cs_b[TN], cs_x[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) cs_g[j] = cs_b[j] = cs_x[j] = 0.f;
+        f32x16 xh[TM][TN];
+        float p1[TM][16], p2[TM][16], rsv[TM][16];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -341,6 +624,7 @@ __global__ __launch_bounds__(WM * 256) void gemm_nt_row_kernel(GemmP p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) cs_x[j] += ok ? acc[i][j][r] : 0.f;
             }
+    
         float* __restrict__ dxo = (float*)p.out0;
         T* __restrict__ dxt = (T*)p.out1;
 #pragma unroll
@@ -625,7 +909,9 @@ template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v
     constexpr int need = BM * ROW_RS * 4 + BM * 4;
     constexpr int need2 = WM * 3 * ROW_BN * 4;
     constexpr int bytes0 = Loop::LDS_BYTES > need ? Loop::LDS_BYTES : need;
-    constexpr int bytes = bytes0 > need2 ? bytes0 : need2;
+    constexpr int bytes1 = bytes0 > need2 ? bytes0 : need2;
+    constexpr bool lean = WM == 1 && sizeof(T) == 2 && BM == 64;
+    constexpr int bytes = lean && ROW_LEAN_LDS > bytes1 ? ROW_LEAN_LDS : bytes1;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_row_kernel<T, REPI, WM, BKB, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -638,8 +924,18 @@ template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v
 }
 template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_t st) {
     const int v = row_variant();
-    if constexpr (!is_split<T>::value) {   // (a split K tile is a whole [hi | lo] group: 128-byte rows only)
+    if constexpr (sizeof(T) == 2) {
+        // two co-resident 4-wave workgroups per CU (64-byte K tiles; split tensors: half a k group per tile): each hides the other's
+        // HBM latency, barriers and row-statistics epilogue.  Measured (split bf16, M = 25,216, isolated launches): proj + LN 65 -> 50 us,
+        // fc2 + LN 179 -> 156, qkv-dgrad + LN-backward 146 -> 132, fc1-dgrad + LN-backward 194 -> 172.  Only once M gives more than one
+        // workgroup per CU: at M = 12,608 (197 workgroups) a CU would hold 4 waves instead of 8 and the step is 5-7 % slower.
+        static const int lean = [] { const char* e = getenv("MFVIT_ROW_LEAN"); return e ? atoi(e) : 1; }();    // A/B switch
+        if (v == 0 || (v == 2 && lean && p.M > 256 * 64) || p.K * elems_per<T>::value % (128 / (int)sizeof(T)))
+            return launch_row_v<T, REPI, 1, 64, 64>(p, st);
+    } else {
         if (v == 0 || p.K % (128 / (int)sizeof(T))) return launch_row_v<T, REPI, 1, 64, 64>(p, st);
+    }
+    if constexpr (!is_split<T>::value) {
         if (v == 3) return launch_row_v<T, REPI, 2, 64, 64>(p, st);
     }
     if (v == 1) return launch_row_v<T, REPI, 1, 128, 64>(p, st);

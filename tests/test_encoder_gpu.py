@@ -94,7 +94,10 @@ def test_backward_all_parameters(precision, tol, stop_grad_conv1):
 def test_full_size_batch_is_sample_independent(precision):
     """BASELINE configs[2] size (B = 128 at 224^2, M = 25,216 token rows - too big for the CPU oracle): a ViT has no cross-sample
     op, so every sample of the full batch must come out exactly as it does in the small batches the oracle tests cover (the GEMM
-    tiles, attention workgroups and row kernels may not leak between rows, pad rows or tile tails).  Forward: bit-exact.  Backward:
+    tiles, attention workgroups and row kernels may not leak between rows, pad rows or tile tails).  Forward: bit-exact in fp32; in the
+    16-bit modes the row-complete GEMMs switch to their two-workgroups-per-CU variant above 16,384 token rows (same sums, but a
+    separately compiled epilogue: an f32 last-bit difference can flip a bf16 rounding), so there the rows must agree to a few bf16
+    ulps - a leak between rows or tiles would be an O(1) error.  Backward:
     the input-independent reduction order of the split-M weight gradients changes with M, so the full-batch gradient is compared
     with the SUM of the sub-batch gradients at rounding level."""
     m, _ = build(precision, 601, depth=2 if precision == "fp32" else 12)
@@ -104,7 +107,11 @@ def test_full_size_batch_is_sample_independent(precision):
         full = m.features3D(x)
         for lo, n in ((0, 4), (60, 3), (125, 3)):                   # first, middle and the tail rows of the last M-tile
             part = m.features3D(x[lo:lo + n].contiguous())
-            assert torch.equal(full[lo:lo + n], part), (precision, lo)
+            if precision == "fp32":
+                assert torch.equal(full[lo:lo + n], part), (precision, lo)
+            else:
+                e = ((full[lo:lo + n] - part).abs().max() / part.abs().max()).item()
+                assert e < 1e-2, (precision, lo, e)
     assert torch.isfinite(full).all()
     # gradient linearity over the batch: grad(sum over 128) == grad(first 64) + grad(last 64)
     w = rng_tensor(603, (B, 197, 384)).to("cuda:0")

@@ -120,7 +120,7 @@ def test_linear_wgrad(mode, M, N, K):
 
 
 @pytest.mark.parametrize("mode", MODES, ids=IDS)
-@pytest.mark.parametrize("M,K", [(200, 384), (197 * 2, 1536), (64, 768), (197 * 128, 384)])
+@pytest.mark.parametrize("M,K", [(200, 384), (197 * 2, 1536), (64, 768), (197 * 128, 384), (16384 + 77, 1536)])   # > 16,384 rows: two workgroups per CU
 def test_linear_res_ln_fwd(mode, M, K):
     from mfvit import ops
     a, w = rnd((M, K), 6), rnd((384, K), 7, 0.05)
@@ -136,7 +136,7 @@ def test_linear_res_ln_fwd(mode, M, K):
 
 
 @pytest.mark.parametrize("mode", MODES, ids=IDS)
-@pytest.mark.parametrize("M,K", [(200, 1152), (197 * 2, 1536), (197 * 65, 1152)])
+@pytest.mark.parametrize("M,K", [(200, 1152), (197 * 2, 1536), (197 * 65, 1152), (197 * 84 + 13, 1536), (16384 + 64 + 1, 1152)])   # the last two: > 16,384 rows
 def test_linear_dgrad_ln_bwd(mode, M, K):
     from mfvit import ops
     dy, wt = rnd((M, K), 12), rnd((384, K), 13, 0.05)
@@ -155,6 +155,10 @@ def test_linear_dgrad_ln_bwd(mode, M, K):
     es = [rel_err(dx, dx_ref), rel_err(mode.unpack(dx_t), dx_ref), rel_err(dgamma, gd.grad), rel_err(dbeta, bd.grad), rel_err(dcol, dx_ref.sum(0))]
     log(f"linear_dgrad_ln_bwd[{mode.name},{M},{K}] {max(es):.2e}")
     assert es[0] < 5e-5 and es[1] < mode.tol and es[2] < 1e-4 and es[3] < 1e-4 and es[4] < 1e-4
+    if M > 16384:     # the same without the residual-gradient input and without the operand-type copy
+        dx2, none, dg2, db2, dc2 = ops.linear_dgrad_ln_bwd(mode.pack(dy), mode.pack(wt), x.to(dev()), mean.float().to(dev()),
+                                                           rstd.float().to(dev()), gamma.to(dev()), None, want_copy=False, split=mode.split)
+        assert none is None and rel_err(dx2, xd.grad) < 5e-5 and rel_err(dg2, gd.grad) < 1e-4 and rel_err(dc2, xd.grad.sum(0)) < 1e-4
 
 
 def _attn_ref(qkv, heads):

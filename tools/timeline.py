@@ -1,0 +1,38 @@
+"""Concurrency analysis of a rocprofv3 --kernel-trace CSV of bench.py: how many kernels are in flight over time, and how long each
+kernel class takes when it shares the GPU compared with its serialized duration.
+usage: python3 tools/timeline.py <dir with *_kernel_trace.csv> [warmup steps]"""
+import csv, glob, os, sys, collections
+
+d = sys.argv[1]
+f = sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True))[0]
+rows = list(csv.DictReader(open(f)))
+ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")) for r in rows]
+ev.sort()
+# the timed region = from the end of optimizer launch number <warmup> to the end of launch <warmup + steps> (one adam launch per step)
+warm, steps = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3, 8)
+ad = [e for e in ev if "adam_kernel" in e[2]]
+t0, t1 = ad[warm - 1][1], ad[warm + steps - 1][1]
+ev = [e for e in ev if e[0] >= t0 and e[1] <= t1]
+pts = []
+for s, e, n, q in ev:
+    pts.append((s, 1)); pts.append((e, -1))
+pts.sort()
+hist = collections.Counter(); cur = 0; last = t0
+for t, dlt in pts:
+    hist[cur] += t - last; last = t; cur += dlt
+tot = t1 - t0
+print(f"window {tot/1e6:.2f} ms = {steps} steps of {tot/1e6/steps:.2f} ms, {len(ev)} kernels")
+for k in sorted(hist): print(f"  {k} kernels in flight: {100*hist[k]/tot:5.1f} %")
+def cls(n):
+    for key in ("gemm_nt_row_kernel", "gemm_nt_tile_kernel", "gemm_tn_glds_kernel", "gemm_tn_kernel", "attn_bwd", "attn_fwd", "adam", "x_stream"):
+        if key in n:
+            if key == "gemm_nt_row_kernel": return key + ("<bwd>" if ", 1, " in n.split("(")[0] else "<fwd>")
+            return key
+    return "other"
+agg = collections.defaultdict(lambda: [0, 0])
+for s, e, n, q in ev:
+    a = agg[cls(n)]; a[0] += 1; a[1] += e - s
+print("class: launches, avg us (while sharing the GPU), total ms")
+for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]): print(f"  {k:28s} {c:6d} {t/c/1e3:9.1f} {t/1e6:9.2f}")
+print(f"sum of kernel durations / window = {sum(t for c, t in agg.values())/tot:.2f}")
+qs = collections.Counter(q for *_, q in ev); print("queues:", dict(qs))
