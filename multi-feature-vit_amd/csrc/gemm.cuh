@@ -21,6 +21,8 @@
 #define MFVIT_TN_PIPE 1
 #endif
 
+#include <type_traits>
+
 namespace mfvit {
 
 template <typename T> struct MmaTraits;
@@ -397,6 +399,144 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------
+// NT main loop with the register-staged tiles fetched D K-tiles ahead (16-bit element types).
+//
+// Why: per K tile a wave has 0.3 - 0.5 us of MFMAs, a global load under load takes 1.5 - 2 us, and NtLoop keeps ONE tile per
+// workgroup in flight (issued at the top of an iteration, written to LDS at its end): with two workgroups per CU that is 64 KB in
+// flight per CU where bandwidth x latency wants ~200 KB - the measured 26 - 34 % MFMA-busy of the tile GEMMs.  The VGPR file
+// (512 KB per CU) is the only place to land more: D register sets per thread, tile kt + D issued at the top of iteration kt.
+// How: the loads are inline asm (`global_load_dwordx4 v, voff, s[base]`: one scalar base per operand and tile, constant 32-bit
+// per-thread offsets - no address VALU in the loop) and the waits are explicit counted `s_waitcnt vmcnt`, so the compiler neither
+// sinks the loads into the MFMAs nor puts its own conservative vmcnt(0) on the loop-carried register reuse (what defeated the
+// C++-level attempts at a deeper pipeline, see NtLoop).  The K loop is unrolled D times: static register-set indices.
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int D> struct NtLoopDeep {
+    typedef NtLoop<T, BM, BN, BKB, WM, WN> Base;
+    static constexpr int NT = Base::NT, BK = Base::BK, TM = Base::TM, TN = Base::TN;
+    typedef typename Base::TA TA;
+    typedef typename Base::TB TB;
+    static constexpr int STAGE_BYTES = Base::STAGE_BYTES, LDS_BYTES = Base::LDS_BYTES;
+    static constexpr bool HALF = Base::HALF;
+    static constexpr int CPR = BKB / 16;
+    static constexpr int NA = BM * CPR / NT, NB = BN * CPR / NT, NL = NA + NB;      // 16-byte loads per thread and tile
+    static_assert(sizeof(T) == 2 && BM * CPR % NT == 0 && BN * CPR % NT == 0, "16-bit tiles whose chunks divide over the block");
+    static_assert(NL * (D - 1) <= 63, "vmcnt is a 6-bit counter");
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+    static __device__ __forceinline__ void gload(u32x4& dst, const char* sbase, unsigned voff) {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase));
+    }
+    // wait until at most N of this thread's loads are outstanding, then hand the registers of one set back to the compiler
+    template <int N> static __device__ __forceinline__ void wait_set(u32x4 (&r)[NL]) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+#pragma unroll
+        for (int i = 0; i < NL; ++i) asm volatile("" : "+v"(r[i]));
+    }
+    // byte offset of K tile kt inside an operand row
+    static __device__ __forceinline__ long tile_off(int kt) {
+        const int k0 = kt * BK;
+        return (long)(HALF ? (k0 & ~63) + ((k0 >> 5) & 1) * 16 : k0) * (long)sizeof(T);
+    }
+
+    // requires: K tiles a multiple of D (>= D), (rows - 1) * ld * 2 + 128 < 2^32 for both operands (checked by the launcher)
+    static __device__ __forceinline__ void run(const GemmP& p, int m0, int n0, char* lds, f32x16 (&acc)[TM][TN]) {
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int wm = wave / WN, wn = wave % WN;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int nk = p.K * elems_per<T>::value / BK;
+        unsigned va[NA], vb[NB];
+        int ra[NA], rb[NB];        // LDS (row, chunk) of every staged chunk: row in the low bits is implied by q
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int q = tid + i * NT, row = q / CPR, c = q % CPR;
+            int gr = m0 + row;
+            gr = gr < p.M ? gr : p.M - 1;
+            const int co = HALF ? (c >> 1) * 32 + (c & 1) * 8 : c * 8;
+            va[i] = (unsigned)gr * (unsigned)p.lda * 2u + (unsigned)co * 2u;
+            ra[i] = TA::off(row, c);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int q = tid + i * NT, row = q / CPR, c = q % CPR;
+            int gr = n0 + row;
+            gr = gr < p.N ? gr : p.N - 1;
+            const int co = HALF ? (c >> 1) * 32 + (c & 1) * 8 : c * 8;
+            vb[i] = (unsigned)gr * (unsigned)p.ldw * 2u + (unsigned)co * 2u;
+            rb[i] = TA::BYTES + TB::off(row, c);
+        }
+        const char* gA = (const char*)p.A;
+        const char* gW = (const char*)p.W;
+        u32x4 st[D][NL];
+        auto issue = [&](u32x4 (&r)[NL], int kt) {
+            const long off = tile_off(kt);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) gload(r[NA + i], gW + off, vb[i]);
+#pragma unroll
+            for (int i = 0; i < NA; ++i) gload(r[i], gA + off, va[i]);
+        };
+        auto put = [&](const u32x4 (&r)[NL], char* stage) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *(u32x4*)(stage + ra[i]) = r[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *(u32x4*)(stage + rb[i]) = r[NA + i];
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(st[d], d);
+        wait_set<NL*(D - 1)>(st[0]);
+        put(st[0], lds);
+        __syncthreads();
+        int cur = 0;
+        // steady state: tile kt + D exists.  Every wait is ONE straight-line statement with a constant count (with a branch per count
+        // the compiler merges the register sets through copies placed BEFORE the wait, i.e. it reads registers still in flight).
+        int kt0 = 0;
+        for (; kt0 + D < nk; kt0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const char* ta = lds + cur * STAGE_BYTES;
+#ifdef MFVIT_ABLATE
+                const int ab = p.splits;
+                if (!(ab & 1)) issue(st[d], kt0 + d + D);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ab & 16)) Base::compute(ta, ta + TA::BYTES, wm, wn, lane, acc);
+                if (!(ab & 1)) wait_set<NL*(D - 1)>(st[(d + 1) % D]);
+                if (!(ab & 2)) put(st[(d + 1) % D], lds + (cur ^ 1) * STAGE_BYTES);
+                if (!(ab & 4)) __syncthreads();
+                cur ^= 1;
+#else
+                issue(st[d], kt0 + d + D);                   // set d is free: tile kt0 + d went to LDS one iteration ago
+                __builtin_amdgcn_sched_barrier(0);
+                Base::compute(ta, ta + TA::BYTES, wm, wn, lane, acc);
+                wait_set<NL*(D - 1)>(st[(d + 1) % D]);      // outstanding, in order: tiles kt + 1 .. kt + D
+                put(st[(d + 1) % D], lds + (cur ^ 1) * STAGE_BYTES);
+                __syncthreads();
+                cur ^= 1;
+#endif
+            }
+        }
+        // the last D tiles (nk % D == 0: tile nk - D + d sits in set d): nothing left to issue, the counts run down
+        auto tail = [&](auto dc) {
+            constexpr int d = decltype(dc)::value;
+            const char* ta = lds + cur * STAGE_BYTES;
+            Base::compute(ta, ta + TA::BYTES, wm, wn, lane, acc);
+            if constexpr (d + 1 < D) {
+                wait_set<NL*(D - 2 - d)>(st[d + 1]);
+                put(st[d + 1], lds + (cur ^ 1) * STAGE_BYTES);
+            }
+            __syncthreads();
+            cur ^= 1;
+        };
+        tail(std::integral_constant<int, 0>());
+        if constexpr (D > 1) tail(std::integral_constant<int, 1>());
+        if constexpr (D > 2) tail(std::integral_constant<int, 2>());
+        static_assert(D <= 3, "tail written out for D <= 3");
+    }
+};
 
 // ---------------------------------------------------------------------------------------------------
 // bf16 NT main loop with ASYNCHRONOUS global -> LDS copies (global_load_lds_dwordx4, "LDS-DMA"): no VGPR staging, no

@@ -23,7 +23,7 @@ namespace mfvit {
 
 
 // ------------------------------------------------------------------------------------------ tile kernel
-template <typename T, int EPI>
+template <typename T, int EPI, int DEEP = 0>     // DEEP: K tiles kept in flight by the main loop (0: NtLoop's one; 2: NtLoopDeep, 16-bit types)
 __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 workgroups per CU (64 - 68 KB of LDS each): register budget 256 per wave
     constexpr int BM = 128, BN = 128, BKB = 128, WM = 2, WN = 2;
     typedef NtLoop<T, BM, BN, BKB, WM, WN> Loop;
@@ -34,13 +34,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
     const int bid = xcd_remap(blockIdx.x, ntn * ntm);
     const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
     f32x16 acc[Loop::TM][Loop::TN];
-    if constexpr (std::is_same<T, bf16>::value) {
+    if constexpr (DEEP > 0) {
+        NtLoopDeep<T, BM, BN, BKB, WM, WN, DEEP>::run(p, m0, n0, lds, acc);
+    } else if constexpr (std::is_same<T, bf16>::value) {
         if (p.y_f32 == 99) NtLoopGlds<BM, BN, WM, WN, 4>::run(p, m0, n0, lds, acc);   // LDS-DMA main loop (bf16)
         else Loop::run(p, m0, n0, lds, acc);
     } else {
         Loop::run(p, m0, n0, lds, acc);
     }
 
+#ifdef MFVIT_ABLATE
+    if (p.splits & 8) {          // no epilogue: one conditional store keeps the accumulators alive
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < Loop::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < Loop::TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+        if (sum == 12345.678f) ((float*)p.out0)[threadIdx.x] = sum;
+        return;
+    }
+#endif
     // ---- epilogue through LDS: per-element math in registers -> [128][128 + pad] tile in LDS -> 16-byte coalesced stores.
     // Rows >= M replicate row M-1 exactly (the A loads are clamped), so they are stored as identical duplicates: no branches.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -470,6 +485,9 @@ __global__ __launch_bounds__(WM * 256, (WM == 1 && sizeof(T) == 2) ? 2 : 1) void
             Loop::run(p, m0, 0, lds, acc);
         }
     } else {
+        // (NtLoopDeep, two K tiles in flight, measured on the two-workgroups-per-CU variant and not used: 2 - 4 % SLOWER (50.0 -> 52.5,
+        // 148.6 -> 154.2, 132.4 -> 136.5, 173.4 -> 176.3 us), and with the LayerNorm-backward epilogue at the register limit the
+        // allocator spills around the in-flight sets - wrong results.  The row tiles are LDS-read / MFMA paced, not latency paced.)
         Loop::run(p, m0, 0, lds, acc);  // ends with a barrier: the staging LDS is free from here on
     }
 
@@ -871,9 +889,24 @@ template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStrea
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if constexpr (sizeof(T) == 2)
+            (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
     ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
+    if constexpr (sizeof(T) == 2) {
+        // two K tiles in flight per workgroup (NtLoopDeep): needs an even number of K tiles and 32-bit byte offsets inside both operands
+        static const int deep = [] { const char* e = getenv("MFVIT_NT_DEEP"); return e ? atoi(e) : 2; }();      // 0: the one-tile loop (A/B switch)
+        const bool fits = (unsigned long long)(p.M - 1) * p.lda * 2 + 256 < (1ull << 32) && (unsigned long long)(p.N - 1) * p.ldw * 2 + 256 < (1ull << 32);
+#ifdef MFVIT_ABLATE
+        { const char* e = getenv("MFVIT_ABLATE_BITS"); p.splits = e ? atoi(e) : 0; }
+#endif
+        if (deep == 2 && p.y_f32 != 99 && p.K * EP / Loop::BK >= 2 && (p.K * EP / Loop::BK) % 2 == 0 && fits) {
+            MFVIT_LAUNCH((gemm_nt_tile_kernel<T, EPI, 2>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), lds_bytes, st, p);
+            MFVIT_CHECK_LAUNCH();
+            return MFVIT_OK;
+        }
+    }
     MFVIT_LAUNCH((gemm_nt_tile_kernel<T, EPI>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), lds_bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;

@@ -186,3 +186,28 @@ def test_moco_v3_builder_surface():
         assert torch.equal(pb, pm) and not pm.requires_grad
     with pytest.raises(NotImplementedError):
         bv.MoCo_ResNet(None, None)
+
+
+def test_vmem_hazard_checker_flags_reads_of_registers_in_flight(tmp_path):
+    """tools/check_vmem_hazards.py guards the inline-asm load pipeline of the tile GEMM (gemm.cuh::NtLoopDeep) at build time: it must
+    accept a load -> counted wait -> use sequence and reject a copy of a register whose load is still outstanding."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_vmem_hazards.py")
+    good = """_Z4kernv: ; @_Z4kernv
+\tglobal_load_dwordx4 v[2:5], v1, s[0:1]
+\tglobal_load_dwordx4 v[6:9], v1, s[2:3]
+\tv_add_u32_e32 v10, v11, v12
+\ts_waitcnt vmcnt(1)
+\tds_write_b128 v20, v[2:5]
+\ts_waitcnt vmcnt(0)
+\tv_mfma_f32_32x32x16_bf16 v[32:47], v[6:9], v[6:9], v[32:47]
+\ts_endpgm
+"""
+    bad = good.replace("\tv_add_u32_e32 v10, v11, v12\n", "\tv_mov_b32_e32 v10, v7\n")
+    for text, rc in ((good, 0), (bad, 1)):
+        f = tmp_path / f"k{rc}.s"
+        f.write_text(text)
+        r = subprocess.run([sys.executable, tool, str(f), "kern"], capture_output=True, text=True)
+        assert r.returncode == rc, (rc, r.stdout, r.stderr)
+    assert "HAZARD" in r.stdout
