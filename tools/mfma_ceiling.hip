@@ -11,8 +11,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <int NACC>
-__global__ __launch_bounds__(256) void mfma_loop(const bf16x8* __restrict__ in, float* __restrict__ out, int iters) {
+__global__ __launch_bounds__(256) void mfma_loop(const bf16x8* __restrict__ in, float* __restrict__ out, int iters, long long* cyc) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long c0 = __builtin_readcyclecounter();       // s_memtime: shader-clock cycles
     bf16x8 a[NACC], b[NACC];
     f32x16 acc[NACC];
 #pragma unroll
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(256) void mfma_loop(const bf16x8* __restrict__ in, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[gid] = s;
+    if (gid == 0) *cyc = __builtin_readcyclecounter() - c0;  // cycles one wave spent in the loop -> the clock it ran at
 }
 
 int main(int argc, char** argv) {
@@ -45,6 +47,8 @@ int main(int argc, char** argv) {
     const int NACC = argc > 3 ? atoi(argv[3]) : 8;                  // independent accumulators per wave: 8 (default), 4, 2, 1
     bf16x8* in;
     float* out;
+    long long* cyc;
+    hipMalloc(&cyc, 8);
     hipMalloc(&in, 65536 * sizeof(bf16x8));
     hipMalloc(&out, (size_t)blocks * 256 * sizeof(float));
     unsigned short* h = (unsigned short*)malloc(65536 * 16);
@@ -61,10 +65,10 @@ int main(int argc, char** argv) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     auto launch = [&](int it) {
-        if (NACC == 8) hipLaunchKernelGGL(mfma_loop<8>, dim3(blocks), dim3(256), 0, 0, in, out, it);
-        else if (NACC == 4) hipLaunchKernelGGL(mfma_loop<4>, dim3(blocks), dim3(256), 0, 0, in, out, it);
-        else if (NACC == 2) hipLaunchKernelGGL(mfma_loop<2>, dim3(blocks), dim3(256), 0, 0, in, out, it);
-        else hipLaunchKernelGGL(mfma_loop<1>, dim3(blocks), dim3(256), 0, 0, in, out, it);
+        if (NACC == 8) hipLaunchKernelGGL(mfma_loop<8>, dim3(blocks), dim3(256), 0, 0, in, out, it, cyc);
+        else if (NACC == 4) hipLaunchKernelGGL(mfma_loop<4>, dim3(blocks), dim3(256), 0, 0, in, out, it, cyc);
+        else if (NACC == 2) hipLaunchKernelGGL(mfma_loop<2>, dim3(blocks), dim3(256), 0, 0, in, out, it, cyc);
+        else hipLaunchKernelGGL(mfma_loop<1>, dim3(blocks), dim3(256), 0, 0, in, out, it, cyc);
     };
     launch(2000);                                                                                  // warm-up (clock ramp)
     hipDeviceSynchronize();
@@ -78,9 +82,14 @@ int main(int argc, char** argv) {
         if (ms < best) best = ms;
     }
     const double flop = 2.0 * 32 * 32 * 16 * (double)NACC * iters * blocks * 4;
+    long long hc = 0;
+    hipMemcpy(&hc, cyc, 8, hipMemcpyDeviceToHost);
+    // last repetition: cycles wave 0 spent in its loop / the launch time.  With more than one wave per SIMD the oldest wave keeps the
+    // matrix pipe (33 cycles per own MFMA either way) and finishes after 1/wps of the launch: scale accordingly.
+    const double mhz = (double)hc * wps / (ms * 1e-3) / 1e6;
     printf("{\"kernel\": \"pure v_mfma_f32_32x32x16_bf16 loop, %d independent accumulators per wave, %d wave(s) per SIMD, %s operands\", "
-           "\"cus\": %d, \"ms\": %.3f, \"tflops\": %.1f, \"frac_of_2500\": %.3f, \"mfma_cycles_per_instr_at_2400MHz\": %.1f}\n",
+           "\"cus\": %d, \"ms\": %.3f, \"tflops\": %.1f, \"frac_of_2500\": %.3f, \"mfma_cycles_per_instr_at_2400MHz\": %.1f, \"shader_clock_mhz_under_load\": %.0f, \"cycles_per_mfma_at_that_clock\": %.1f}\n",
            NACC, wps, zero ? "zero" : "random", cus, best, flop / best / 1e9, flop / best / 1e9 / 2500.0,
-           best * 1e-3 * 2.4e9 / ((double)NACC * iters * wps));
+           best * 1e-3 * 2.4e9 / ((double)NACC * iters * wps), mhz, (double)hc / ((double)NACC * iters));
     return 0;
 }
