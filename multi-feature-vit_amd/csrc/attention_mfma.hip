@@ -69,11 +69,15 @@ template <typename T> __device__ __forceinline__ typename Vec8<T>::type tr_frag(
 template <typename T> __device__ __forceinline__ void pack8(const f32x16& v, int s, typename Vec8<T>::type& hi, typename Vec8<T>::type& lo) {
     typedef typename Vec4<T>::elem E;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = v[8 * s + j];
-        const E h = (E)x;
-        hi[j] = h;
-        if constexpr (is_split<T>::value) lo[j] = (E)(x - (float)h);
+    for (int j = 0; j < 8; j += 2) {
+        E h0, h1, l0, l1;
+        cvt_pair<E, is_split<T>::value>(v[8 * s + j], v[8 * s + j + 1], h0, h1, l0, l1);
+        hi[j] = h0;
+        hi[j + 1] = h1;
+        if constexpr (is_split<T>::value) {
+            lo[j] = l0;
+            lo[j + 1] = l1;
+        }
     }
 }
 // acc += A (x) B as one MFMA (plain) or three (split: a_hi b_hi + a_lo b_hi + a_hi b_lo)
@@ -94,11 +98,15 @@ template <typename T> __device__ __forceinline__ void store_tile_T(typename Vec4
     for (int g = 0; g < 4; ++g) {
         V4 o, l;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float x = acc[4 * g + j] * mul;
-            const E h = (E)x;
-            o[j] = h;
-            if constexpr (is_split<T>::value) l[j] = (E)(x - (float)h);
+        for (int j = 0; j < 4; j += 2) {
+            E h0, h1, l0, l1;
+            cvt_pair<E, is_split<T>::value>(acc[4 * g + j] * mul, acc[4 * g + j + 1] * mul, h0, h1, l0, l1);
+            o[j] = h0;
+            o[j + 1] = h1;
+            if constexpr (is_split<T>::value) {
+                l[j] = l0;
+                l[j + 1] = l1;
+            }
         }
         *(V4*)(row_ptr + 8 * g + 4 * (lane >> 5)) = o;
         if constexpr (is_split<T>::value) *(V4*)(row_ptr + 32 + 8 * g + 4 * (lane >> 5)) = l;

@@ -2,6 +2,8 @@
 // gfx950 only: no CUDA / multi-backend paths.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -42,6 +44,22 @@ __device__ __forceinline__ void split2(float x, bf16& hi, bf16& lo) {
     hi = (bf16)x;
     lo = (bf16)(x - (float)hi);
 }
+// Two values at once: hi = E(x), lo = E(x - hi) as ONE packed conversion each (v_cvt_pk_bf16_f32 / v_cvt_pkrtz-free f16 pair).  Element
+// by element every conversion is a packed instruction with half of it unused (the attention files are built without SLP
+// vectorisation): 66 of the ~200 VALU instructions per 24 MFMAs of the attention backward's inner loop before this helper.
+template <typename E, bool SPLIT> __device__ __forceinline__ void cvt_pair(float x0, float x1, E& h0, E& h1, E& l0, E& l1) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef E ex2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t x = {x0, x1};
+    const ex2_t h = __builtin_convertvector(x, ex2_t);
+    h0 = h[0];
+    h1 = h[1];
+    if constexpr (SPLIT) {
+        const ex2_t l = __builtin_convertvector(x - __builtin_convertvector(h, f32x2_t), ex2_t);
+        l0 = l[0];
+        l1 = l[1];
+    }
+}
 // 8 x 16-bit MFMA operand fragment of element type T
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16> { typedef bf16x8 type; };
@@ -69,6 +87,27 @@ template <> __device__ __forceinline__ void store_elem<sbf16>(sbf16* row, int n,
     bf16* r = (bf16*)row + split_col(n);
     r[0] = hi;
     r[32] = lo;
+}
+// the same for two values that go to column n of two different rows: one packed conversion per part instead of one per element
+template <typename T> __device__ __forceinline__ void store_elem_pair(T* row0, T* row1, int n, float v0, float v1) {
+    if constexpr (std::is_same<T, float>::value) {
+        row0[n] = v0;
+        row1[n] = v1;
+    } else if constexpr (is_split<T>::value) {
+        bf16 h0, h1, l0, l1;
+        cvt_pair<bf16, true>(v0, v1, h0, h1, l0, l1);
+        bf16* r0 = (bf16*)row0 + split_col(n);
+        bf16* r1 = (bf16*)row1 + split_col(n);
+        r0[0] = h0;
+        r0[32] = l0;
+        r1[0] = h1;
+        r1[32] = l1;
+    } else {
+        T h0, h1, l0, l1;
+        cvt_pair<T, false>(v0, v1, h0, h1, l0, l1);
+        row0[n] = h0;
+        row1[n] = h1;
+    }
 }
 template <typename T> __device__ __forceinline__ float load_elem(const T* row, int n) { return to_f32(row[n]); }
 template <> __device__ __forceinline__ float load_elem<sbf16>(const sbf16* row, int n) {

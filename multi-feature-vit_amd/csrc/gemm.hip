@@ -105,24 +105,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
 #pragma unroll
         for (int i = 0; i < Loop::TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] + bj[j];
-                T* e = erow(i, r);
+            for (int r = 0; r < 16; r += 2) {     // two rows at a time: one packed conversion per pair of values
+                float v0 = acc[i][j][r] + bj[j], v1 = acc[i][j][r + 1] + bj[j];
+                T* e0 = erow(i, r);
+                T* e1 = erow(i, r + 1);
                 if (EPI == EPI_BIAS_GELU) {
-                    float gv, dgv;
-                    gelu_both_t<T>(v, gv, dgv);                         // one erf / exp evaluation for both outputs
-                    acc[i][j][r] = gv;                                  // gelu(pre): the second output, stored below
-                    store_elem<T>(e, ecol(j), dgv);                     // out0 = gelu'(pre): all the backward needs
+                    float g0, g1, d0, d1;
+                    gelu_both_t<T>(v0, g0, d0);                         // one erf / exp evaluation for both outputs
+                    gelu_both_t<T>(v1, g1, d1);
+                    acc[i][j][r] = g0;                                  // gelu(pre): the second output, stored below
+                    acc[i][j][r + 1] = g1;
+                    store_elem_pair<T>(e0, e1, ecol(j), d0, d1);        // out0 = gelu'(pre): all the backward needs
                 } else if (EPI == EPI_BIAS_RELU) {
-                    acc[i][j][r] = v;
-                    store_elem<T>(e, ecol(j), v > 0.f ? 1.f : 0.f);     // out0 = relu'(pre) (fuseattention.py:69: nn.ReLU)
+                    acc[i][j][r] = v0;
+                    acc[i][j][r + 1] = v1;
+                    store_elem_pair<T>(e0, e1, ecol(j), v0 > 0.f ? 1.f : 0.f, v1 > 0.f ? 1.f : 0.f);     // out0 = relu'(pre) (fuseattention.py:69: nn.ReLU)
                 } else if (EPI == EPI_GELU_BWD) {
-                    v *= load_elem<T>(e, ecol(j));
-                    store_elem<T>(e, ecol(j), v);
-                    const bool ok = m0 + (wm * Loop::TM + i) * 32 + acc_row(r, lane) < p.M;
-                    csum += ok ? v : 0.f;
+                    v0 *= load_elem<T>(e0, ecol(j));
+                    v1 *= load_elem<T>(e1, ecol(j));
+                    store_elem_pair<T>(e0, e1, ecol(j), v0, v1);
+                    const int mrow = m0 + (wm * Loop::TM + i) * 32;
+                    csum += (mrow + acc_row(r, lane) < p.M ? v0 : 0.f) + (mrow + acc_row(r + 1, lane) < p.M ? v1 : 0.f);
                 } else {
-                    store_elem<T>(e, ecol(j), v);
+                    store_elem_pair<T>(e0, e1, ecol(j), v0, v1);
                 }
             }
         if (EPI == EPI_GELU_BWD && p.cs0) {
@@ -149,8 +154,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
 #pragma unroll
             for (int i = 0; i < Loop::TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    store_elem<T>(erow(i, r), ecol(j), EPI == EPI_BIAS_RELU ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r]);
+                for (int r = 0; r < 16; r += 2)
+                    store_elem_pair<T>(erow(i, r), erow(i, r + 1), ecol(j), EPI == EPI_BIAS_RELU ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r],
+                                       EPI == EPI_BIAS_RELU ? fmaxf(acc[i][j][r + 1], 0.f) : acc[i][j][r + 1]);
         store_tile(p.out1, p.ldo1);
     }
 }
@@ -195,7 +201,9 @@ __device__ __forceinline__ void row_reduce(float (&p)[TM][16], float* red, float
 // LayerNorm backward recomputes the normalised input from a second read of x (L2: this workgroup fetched it a moment ago) instead of
 // keeping it in 96 registers, and global loads are issued in batches of 24 - 48 with the arithmetic behind a scheduling barrier.
 constexpr int ROW_LEAN_LDS = 2 * 64 * ROW_RS * 4 + 4 * 64 * 4;
-template <typename T, int REPI, int BM, int TM, int TN>
+// REMAP: the patch-embedding launch only (output rows re-indexed past the cls row, residual = pos_embed[row % patches]); everything
+// else gets straight-line code without the per-row `orow_in ? ... : m` selects and their integer divisions
+template <typename T, int REPI, int BM, int TM, int TN, bool REMAP>
 __device__ __forceinline__ void row_epilogue_lean(const GemmP& p, int m0, f32x16 (&acc)[TM][TN], char* lds) {
     static_assert(BM == 64 && TM == 2, "one row of four waves over a 64-row tile");
     constexpr int BN = ROW_BN;
@@ -250,7 +258,7 @@ __device__ __forceinline__ void row_epilogue_lean(const GemmP& p, int m0, f32x16
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + lrow(i, r);
                     const int mm = m < p.M ? m : p.M - 1;
-                    const long rrow = p.res_mod ? (mm % p.res_mod) + p.res_off : out_row(p, mm);
+                    const long rrow = !REMAP ? mm : (p.res_mod ? (mm % p.res_mod) + p.res_off : out_row(p, mm));
 #pragma unroll
                     for (int j = 0; j < TN; ++j) t[r][j] = resp[rrow * p.ldres + ncol[j]];
                 }
@@ -297,27 +305,38 @@ __device__ __forceinline__ void row_epilogue_lean(const GemmP& p, int m0, f32x16
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {       // stores only; padded rows replicate row M-1 -> identical duplicate stores
-                const int mraw = m0c + lrow(i, r);
-                const int m = mraw < p.M ? mraw : p.M - 1;
-                const int orow = out_row(p, m);
-                const float mu = tot1[lrow(i, r)] * invN;
-                const float rs = rsqrtf(tot2[lrow(i, r)] * invN + p.eps);
-                if (wn == 0 && (lane & 31) == 0 && p.mean) {
-                    p.mean[orow] = mu;
-                    p.rstd[orow] = rs;
+            for (int r = 0; r < 16; r += 2) {    // stores only, two rows at a time (one packed conversion per pair); padded rows replicate row M-1
+                int orow[2];
+                float mu[2], rs[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int mraw = m0c + lrow(i, r + e);
+                    const int m = mraw < p.M ? mraw : p.M - 1;
+                    orow[e] = REMAP ? out_row(p, m) : m;
+                    mu[e] = tot1[lrow(i, r + e)] * invN;
+                    rs[e] = rsqrtf(tot2[lrow(i, r + e)] * invN + p.eps);
+                    if (wn == 0 && (lane & 31) == 0 && p.mean) {
+                        p.mean[orow[e]] = mu[e];
+                        p.rstd[orow[e]] = rs[e];
+                    }
                 }
                 if (xo) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) xo[(long)orow * p.ldo0 + ncol[j]] = acc[i][j][r];
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) xo[(long)orow[e] * p.ldo0 + ncol[j]] = acc[i][j][r + e];
                 }
                 if (p.y_f32) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) ((float*)p.out1)[(long)orow * p.ldo1 + ncol[j]] = (acc[i][j][r] - mu) * rs * gj[j] + btj[j];
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            ((float*)p.out1)[(long)orow[e] * p.ldo1 + ncol[j]] = (acc[i][j][r + e] - mu[e]) * rs[e] * gj[j] + btj[j];
                 } else {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        store_elem<T>((T*)p.out1 + (long)orow * p.ldo1, ncol[j], (acc[i][j][r] - mu) * rs * gj[j] + btj[j]);
+                        store_elem_pair<T>((T*)p.out1 + (long)orow[0] * p.ldo1, (T*)p.out1 + (long)orow[1] * p.ldo1, ncol[j],
+                                           (acc[i][j][r] - mu[0]) * rs[0] * gj[j] + btj[j], (acc[i][j][r + 1] - mu[1]) * rs[1] * gj[j] + btj[j]);
                 }
             }
     } else {  // REPI_LNBWD_RES: acc = dL/dy (y = LN output); aux = saved LN input x (f32)
@@ -431,14 +450,19 @@ __device__ __forceinline__ void row_epilogue_lean(const GemmP& p, int m0, f32x16
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {       // stores only
-                const int mraw = m0c + lrow(i, r);
-                const int m = mraw < p.M ? mraw : p.M - 1;
+            for (int r = 0; r < 16; r += 2) {    // stores only, two rows at a time (one packed conversion per pair)
+                int m[2];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) dxo[(long)m * p.ldo0 + ncol[j]] = acc[i][j][r];
+                for (int e = 0; e < 2; ++e) {
+                    const int mraw = m0c + lrow(i, r + e);
+                    m[e] = mraw < p.M ? mraw : p.M - 1;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) dxo[(long)m[e] * p.ldo0 + ncol[j]] = acc[i][j][r + e];
+                }
                 if (dxt) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) store_elem<T>(dxt + (long)m * p.ldo1, ncol[j], acc[i][j][r]);
+                    for (int j = 0; j < TN; ++j)
+                        store_elem_pair<T>(dxt + (long)m[0] * p.ldo1, dxt + (long)m[1] * p.ldo1, ncol[j], acc[i][j][r], acc[i][j][r + 1]);
                 }
             }
         // column sums: red1 is free (the totals live behind red2); [3][BN] scratch
@@ -497,7 +521,8 @@ __global__ __launch_bounds__(WM * 256, (WM == 1 && sizeof(T) == 2) ? 2 : 1) void
 
     constexpr bool LEAN = WM == 1 && sizeof(T) == 2 && BM == 64;      // the two-workgroups-per-CU variant: 256 registers
     if constexpr (LEAN) {
-        row_epilogue_lean<T, REPI, BM, TM, TN>(p, m0, acc, lds);
+        if (REPI == REPI_RES_LN && (p.orow_in || p.res_mod)) row_epilogue_lean<T, REPI, BM, TM, TN, true>(p, m0, acc, lds);
+        else row_epilogue_lean<T, REPI, BM, TM, TN, false>(p, m0, acc, lds);
         return;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

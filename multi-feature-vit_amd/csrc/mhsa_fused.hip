@@ -58,12 +58,18 @@ __device__ __forceinline__ int f_acc_row(int r, int lane) { return (r & 3) + 8 *
 template <typename T> __device__ __forceinline__ void f_pack8(const f32x16& v, int s, typename Vec8<T>::type& hi, typename Vec8<T>::type& lo) {
     typedef typename Vec4<T>::elem E;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = v[8 * s + j];
-        const E h = (E)x;
-        hi[j] = h;
-        if constexpr (is_split<T>::value) lo[j] = (E)(x - (float)h);
-        else lo[j] = h;
+    for (int j = 0; j < 8; j += 2) {
+        E h0, h1, l0, l1;
+        cvt_pair<E, is_split<T>::value>(v[8 * s + j], v[8 * s + j + 1], h0, h1, l0, l1);
+        hi[j] = h0;
+        hi[j + 1] = h1;
+        if constexpr (is_split<T>::value) {
+            lo[j] = l0;
+            lo[j + 1] = l1;
+        } else {
+            lo[j] = h0;
+            lo[j + 1] = h1;
+        }
     }
 }
 // K-image fragment in ACCUMULATOR k order: row (rowbase + lane & 31), element j = column 16 s + 8 (j >> 2) + 4 (lane >> 5) + (j & 3)
@@ -93,11 +99,15 @@ template <typename T, typename PTR> __device__ __forceinline__ void f_store_tile
     for (int g = 0; g < 4; ++g) {
         V4 o, l;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float x = acc[4 * g + j] * mul;
-            const E h = (E)x;
-            o[j] = h;
-            if constexpr (is_split<T>::value) l[j] = (E)(x - (float)h);
+        for (int j = 0; j < 4; j += 2) {
+            E h0, h1, l0, l1;
+            cvt_pair<E, is_split<T>::value>(acc[4 * g + j] * mul, acc[4 * g + j + 1] * mul, h0, h1, l0, l1);
+            o[j] = h0;
+            o[j + 1] = h1;
+            if constexpr (is_split<T>::value) {
+                l[j] = l0;
+                l[j + 1] = l1;
+            }
         }
         *(V4*)(row_ptr + 8 * g + 4 * (lane >> 5)) = o;
         if constexpr (is_split<T>::value) *(V4*)(row_ptr + 32 + 8 * g + 4 * (lane >> 5)) = l;
