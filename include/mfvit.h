@@ -113,13 +113,15 @@ int mfvit_gpt_backward(const mfvit_vit_cfg* cfg, const float* params, const void
  * Single ops (exposed for parity tests and for the MoCo projector / predictor path).
  * ------------------------------------------------------------------------------------------------------------ */
 /* y[M][N] = x[M][K] W[N][K]^T + bias   (nn.Linear forward; x, W, y of `dtype`; epilogue 0 bias, 1 bias+GELU(erf)
- * writing gelu'(pre-activation) to y (what the backward needs) and the activation to y2, 3 none).  N % 128 == 0, K % 64 == 0. */
+ * writing gelu'(pre-activation) to y (what the backward needs) and the activation to y2, 3 none).  N % 128 == 0, K % 64 == 0.
+ * Epilogue 1: y may be NULL (no-grad forward: the derivative is not computed); for MFVIT_BF16X3 y is PLAIN fp16 [M][N] (ldy in
+ * fp16 elements) - the derivative only ever multiplies a gradient, the split copy cost 155 MB of stores per fc1 launch. */
 int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                      int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream);
 /* Experimental second implementation of the same linear (bf16 only; N % 128 == 0, N <= 1536, K % 32 == 0, K >= 128, M >= 1024):
  * persistent 256x128-tile kernel with an LDS-DMA ring pipelined across tiles (csrc/gemm_pers.hip).  Same results; opt-in
  * for the encoder with MFVIT_PERS=1.  epilogue + 100 selects the split-bf16 instantiation (MFVIT_BF16X3 operands and outputs in the I32
- * layout, leading dimensions in storage elements; K % 32 == 0; opt-in for the encoder with MFVIT_PERS_SPLIT=1). */
+ * layout, leading dimensions in storage elements; K % 32 == 0; epilogues 0 and 3 only; opt-in for the encoder with MFVIT_PERS_SPLIT=1). */
 int mfvit_linear_fwd_persistent(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                                 int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream);
 /* Experimental third implementation (bf16; N % 128 == 0, N <= 1536, K % 64 == 0, K >= 128, M >= 1024): warp-specialised

@@ -60,6 +60,9 @@ template <typename E, bool SPLIT> __device__ __forceinline__ void cvt_pair(float
         l1 = l[1];
     }
 }
+// storage type of a saved activation derivative (gelu' / relu'): the tensor's own type, plain fp16 for split tensors (gemm.hip)
+template <typename T> struct act_grad_type { typedef T type; };
+template <> struct act_grad_type<sbf16> { typedef f16 type; };
 // 8 x 16-bit MFMA operand fragment of element type T
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16> { typedef bf16x8 type; };

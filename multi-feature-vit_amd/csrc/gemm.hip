@@ -58,40 +58,43 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
 #endif
     // ---- epilogue through LDS: per-element math in registers -> [128][128 + pad] tile in LDS -> 16-byte coalesced stores.
     // Rows >= M replicate row M-1 exactly (the A loads are clamped), so they are stored as identical duplicates: no branches.
+    // The activation derivative (out0 of the GELU / ReLU epilogues, aux of EPI_GELU_BWD) is kept in AX: the tensor's own type for bf16 /
+    // fp16 / f32, plain fp16 for split tensors - it only ever multiplies a gradient (2^-11 relative on values in [-0.13, 1.13], 1e-5 after
+    // the k-sums of the following GEMMs), and the split copy was 155 MB of stores in fc1 and as many loads in the fc2 dgrad per launch.
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    typedef typename act_grad_type<T>::type AX;
     constexpr int EP = elems_per<T>::value;             // storage elements per logical element (2 for split tensors)
     constexpr int ROWB = BN * (int)sizeof(T) * EP;      // bytes of one tile row in the output tensor
-    constexpr int PITCH = ROWB + 16;
-    constexpr int CPRO = ROWB / 16;                     // 16-byte chunks per tile row
-    constexpr int NCHO = BM * CPRO / 256;
+    constexpr int AROWB = BN * (int)sizeof(AX);         // ... in the activation-derivative tensor
     char* tile = lds;                                   // the staging buffers are free after the main loop's last barrier
-    auto erow = [&](int i, int r) -> T* { return (T*)(tile + ((wm * Loop::TM + i) * 32 + acc_row(r, lane)) * PITCH); };
+    auto trow = [&](int i, int r, int pitch) -> char* { return tile + ((wm * Loop::TM + i) * 32 + acc_row(r, lane)) * pitch; };
     auto ecol = [&](int j) -> int { return (wn * Loop::TN + j) * 32 + (lane & 31); };   // LOGICAL column inside the tile
-    auto store_tile = [&](void* out, long ldo) {
-        __syncthreads();
+    // tile rows of RB bytes (LDS pitch RB + 16)  <->  global rows (ld_bytes apart, the tile's columns start col_bytes into the row)
+    auto copy_tile = [&](auto rb_c, auto to_global_c, char* g, long ld_bytes, long col_bytes) {
+        constexpr int RB = decltype(rb_c)::value, CP = RB / 16, NC = BM * CP / 256;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < NCHO; ++i) {
-            const int q = tid + i * 256, row = q / CPRO, c = q % CPRO;
+        for (int i = 0; i < NC; ++i) {
+            const int q = tid + i * 256, row = q / CP, c = q % CP;
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            u32x4* dst = (u32x4*)((char*)out + ((long)m * ldo + n0 * EP) * sizeof(T) + 16 * c);
-            const u32x4 v = *(const u32x4*)(tile + row * PITCH + 16 * c);
-            if (p.rows_per_wg == 1) __builtin_nontemporal_store(v, dst);   // (field unused by the tile kernel otherwise) streaming output:
-            else *dst = v;                                                  // keeps the operand tiles in L2, see launch_tile
+            u32x4* gp = (u32x4*)(g + (long)m * ld_bytes + col_bytes + 16 * c);
+            u32x4* lp = (u32x4*)(tile + row * (RB + 16) + 16 * c);
+            if constexpr (decltype(to_global_c)::value) {
+                if (p.rows_per_wg == 1) __builtin_nontemporal_store(*lp, gp);   // (field unused by the tile kernel otherwise) streaming output:
+                else *gp = *lp;                                                  // keeps the operand tiles in L2, see launch_tile
+            } else {
+                *lp = *gp;
+            }
         }
     };
-    if (EPI == EPI_GELU_BWD) {   // aux = gelu'(pre-activation) saved by the forward: load its tile with 16-byte reads
-#pragma unroll
-        for (int i = 0; i < NCHO; ++i) {
-            const int q = tid + i * 256, row = q / CPRO, c = q % CPRO;
-            int m = m0 + row;
-            m = m < p.M ? m : p.M - 1;
-            *(uint4*)(tile + row * PITCH + 16 * c) = *(const uint4*)((const char*)p.aux + ((long)m * p.ldaux + n0 * EP) * sizeof(T) + 16 * c);
-        }
+    constexpr std::integral_constant<int, ROWB> rb_t{};
+    constexpr std::integral_constant<int, AROWB> rb_a{};
+    auto store_tile = [&](void* out, long ldo) {
         __syncthreads();
-    }
+        copy_tile(rb_t, std::true_type(), (char*)out, ldo * (long)sizeof(T), (long)n0 * EP * (long)sizeof(T));
+    };
     float bj[Loop::TN], csums[Loop::TN];
 #pragma unroll
     for (int j = 0; j < Loop::TN; ++j) {
@@ -99,44 +102,73 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
         const int n = n0 + (wn * Loop::TN + j) * 32 + (lane & 31);
         bj[j] = ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) && p.bias) ? p.bias[n] : 0.f;
     }
+    if constexpr (EPI == EPI_GELU_BWD) {
+        // aux = act'(pre-activation) saved by the forward: its tile comes in with 16-byte reads, every lane multiplies its accumulators in
+        // place, and only then (barrier) the product goes into the same LDS as a tile of T
+        copy_tile(rb_a, std::false_type(), (char*)const_cast<void*>(p.aux), p.ldaux * (long)sizeof(AX), (long)n0 * (long)sizeof(AX));
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < Loop::TN; ++j) {
-        float csum = 0.f;
+        for (int j = 0; j < Loop::TN; ++j) {
+            float csum = 0.f;
 #pragma unroll
-        for (int i = 0; i < Loop::TM; ++i)
+            for (int i = 0; i < Loop::TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {     // two rows at a time: one packed conversion per pair of values
-                float v0 = acc[i][j][r] + bj[j], v1 = acc[i][j][r + 1] + bj[j];
-                T* e0 = erow(i, r);
-                T* e1 = erow(i, r + 1);
-                if (EPI == EPI_BIAS_GELU) {
-                    float g0, g1, d0, d1;
-                    gelu_both_t<T>(v0, g0, d0);                         // one erf / exp evaluation for both outputs
-                    gelu_both_t<T>(v1, g1, d1);
-                    acc[i][j][r] = g0;                                  // gelu(pre): the second output, stored below
-                    acc[i][j][r + 1] = g1;
-                    store_elem_pair<T>(e0, e1, ecol(j), d0, d1);        // out0 = gelu'(pre): all the backward needs
-                } else if (EPI == EPI_BIAS_RELU) {
-                    acc[i][j][r] = v0;
-                    acc[i][j][r + 1] = v1;
-                    store_elem_pair<T>(e0, e1, ecol(j), v0 > 0.f ? 1.f : 0.f, v1 > 0.f ? 1.f : 0.f);     // out0 = relu'(pre) (fuseattention.py:69: nn.ReLU)
-                } else if (EPI == EPI_GELU_BWD) {
-                    v0 *= load_elem<T>(e0, ecol(j));
-                    v1 *= load_elem<T>(e1, ecol(j));
-                    store_elem_pair<T>(e0, e1, ecol(j), v0, v1);
-                    const int mrow = m0 + (wm * Loop::TM + i) * 32;
-                    csum += (mrow + acc_row(r, lane) < p.M ? v0 : 0.f) + (mrow + acc_row(r + 1, lane) < p.M ? v1 : 0.f);
-                } else {
-                    store_elem_pair<T>(e0, e1, ecol(j), v0, v1);
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r] * load_elem<AX>((const AX*)trow(i, r, AROWB + 16), ecol(j));
+                    acc[i][j][r] = v;
+                    csum += m0 + (wm * Loop::TM + i) * 32 + acc_row(r, lane) < p.M ? v : 0.f;
                 }
+            if (p.cs0) {
+                csum += __shfl_xor(csum, 32, 64);
+                if (p.cpart) csums[j] = csum;
+                else if (lane < 32) atomicAdd(p.cs0 + n0 + (wn * Loop::TN + j) * 32 + lane, csum);
             }
-        if (EPI == EPI_GELU_BWD && p.cs0) {
-            csum += __shfl_xor(csum, 32, 64);
-            if (p.cpart) csums[j] = csum;
-            else if (lane < 32) atomicAdd(p.cs0 + n0 + (wn * Loop::TN + j) * 32 + lane, csum);
         }
+        __syncthreads();
     }
-    store_tile(p.out0, p.ldo0);
+    const bool want_grad = p.out0 != nullptr;           // GELU / ReLU epilogues: no-grad forwards pass out0 = NULL and skip the derivative
+    if ((EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) ? want_grad : true) {
+#pragma unroll
+        for (int j = 0; j < Loop::TN; ++j)
+#pragma unroll
+            for (int i = 0; i < Loop::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {     // two rows at a time: one packed conversion per pair of values
+                    const float v0 = acc[i][j][r] + bj[j], v1 = acc[i][j][r + 1] + bj[j];
+                    if (EPI == EPI_BIAS_GELU) {
+                        float g0, g1, d0, d1;
+                        gelu_both_t<T>(v0, g0, d0);                         // one erf / exp evaluation for both outputs
+                        gelu_both_t<T>(v1, g1, d1);
+                        acc[i][j][r] = g0;                                  // gelu(pre): the second output, stored below
+                        acc[i][j][r + 1] = g1;
+                        store_elem_pair<AX>((AX*)trow(i, r, AROWB + 16), (AX*)trow(i, r + 1, AROWB + 16), ecol(j), d0, d1);   // out0 = gelu'(pre)
+                    } else if (EPI == EPI_BIAS_RELU) {
+                        acc[i][j][r] = fmaxf(v0, 0.f);
+                        acc[i][j][r + 1] = fmaxf(v1, 0.f);
+                        store_elem_pair<AX>((AX*)trow(i, r, AROWB + 16), (AX*)trow(i, r + 1, AROWB + 16), ecol(j), v0 > 0.f ? 1.f : 0.f,
+                                            v1 > 0.f ? 1.f : 0.f);         // out0 = relu'(pre) (fuseattention.py:69: nn.ReLU)
+                    } else {
+                        store_elem_pair<T>((T*)trow(i, r, ROWB + 16), (T*)trow(i, r + 1, ROWB + 16), ecol(j), v0, v1);
+                    }
+                }
+        if (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) {
+            __syncthreads();
+            copy_tile(rb_a, std::true_type(), (char*)p.out0, p.ldo0 * (long)sizeof(AX), (long)n0 * (long)sizeof(AX));
+        } else {
+            store_tile(p.out0, p.ldo0);
+        }
+    } else {
+        // activation only (no-grad forward)
+#pragma unroll
+        for (int j = 0; j < Loop::TN; ++j)
+#pragma unroll
+            for (int i = 0; i < Loop::TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r] + bj[j];
+                    acc[i][j][r] = EPI == EPI_BIAS_RELU ? fmaxf(v, 0.f) : gelu_t<T>(v);
+                }
+    }
     if (EPI == EPI_GELU_BWD && p.cs0 && p.cpart) {   // per-workgroup partial column sums: [m-tile][N], plain stores
         __syncthreads();
         float* sc = (float*)tile;                       // [WM][BN]
@@ -155,8 +187,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
             for (int i = 0; i < Loop::TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2)
-                    store_elem_pair<T>(erow(i, r), erow(i, r + 1), ecol(j), EPI == EPI_BIAS_RELU ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r],
-                                       EPI == EPI_BIAS_RELU ? fmaxf(acc[i][j][r + 1], 0.f) : acc[i][j][r + 1]);
+                    store_elem_pair<T>((T*)trow(i, r, ROWB + 16), (T*)trow(i, r + 1, ROWB + 16), ecol(j), acc[i][j][r], acc[i][j][r + 1]);
         store_tile(p.out1, p.ldo1);
     }
 }

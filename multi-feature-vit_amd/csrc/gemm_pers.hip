@@ -461,6 +461,8 @@ bool gemm_nt_pers_supported(int dtype, int epi, const GemmP& p, bool force) {
     if ((!(ep == 2 ? on_split : on) && !force) || p.nb > 1 || p.M < 1024) return false;
     if (p.N % PBN || p.N > PMAXN || (ep == 2 ? p.K % 32 : p.K % 32) || p.K < 128) return false;   // split: whole 32-wide k groups
     if (epi == EPI_BIAS_RELU) return false;                    // ReLU MLP (TransFuser-GPT): 128x128 kernel only
+    if (epi == EPI_BIAS_GELU && !p.out0) return false;         // no-grad forward without the saved derivative: 128x128 kernel only
+    if (ep == 2 && (epi == EPI_BIAS_GELU || epi == EPI_GELU_BWD)) return false;   // split tensors keep gelu' as plain fp16 (gemm.hip)
     if (epi == EPI_GELU_BWD && p.cs0) return false;            // column sums stay with the 128x128 kernel
     if ((long)p.M * p.lda * 2 >= (1L << 32) || (long)p.N * p.ldw * 2 >= (1L << 32)) return false;   // 32-bit byte offsets
     if (p.lda % 8 || p.ldw % 8 || p.ldo0 % 8 || (p.out1 && p.ldo1 % 8) || (p.aux && p.ldaux % 8)) return false;

@@ -280,6 +280,7 @@ bool gemm_nt_ws_supported(int dtype, int epi, const GemmP& p, bool force) {
     if ((!on && !force) || dtype != MFVIT_BF16 || p.nb > 1 || p.M < 1024) return false;
     if (p.N % WBN || p.N > WMAXN || p.K % WBK || p.K < 2 * WBK) return false;
     if (epi == EPI_BIAS_RELU) return false;                    // ReLU MLP (TransFuser-GPT): 128x128 kernel only
+    if (epi == EPI_BIAS_GELU && !p.out0) return false;         // no-grad forward without the saved derivative: 128x128 kernel only
     if (epi == EPI_GELU_BWD && p.cs0) return false;
     if ((long)p.M * p.lda * 2 >= (1L << 32) || (long)p.N * p.ldw * 2 >= (1L << 32)) return false;
     if (p.lda % 8 || p.ldw % 8 || p.ldo0 % 8 || (p.out1 && p.ldo1 % 8) || (p.aux && p.ldaux % 4)) return false;

@@ -145,7 +145,7 @@ WsLayout ws_layout(const Dims& d) {
     W.xmid = b; b += align256(M * D * 4);
     W.st2 = b; b += align256(2 * M * 4);
     W.y2 = b; b += align256(M * D * es);
-    W.hpre = b; b += align256(M * F * es);
+    W.hpre = b; b += d.save ? align256(M * F * (d.dtype == MFVIT_BF16X3 ? 2 : es)) : 0;   // act'(pre): plain fp16 for split tensors; not kept by no-grad forwards
     W.hact = b; b += align256(M * F * es);
     W.blk_stride = b;
     o += b * nl;
@@ -376,7 +376,7 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
             p.W = hw ? (const void*)(sb + S.fc1_w) : (const void*)(pb + L.fc1_w); p.ldw = D * e;
             p.M = d.M; p.N = d.F; p.K = d.D;
             p.bias = pb + L.fc1_b;
-            p.out0 = b + W.hpre; p.ldo0 = F * e;
+            p.out0 = d.save ? b + W.hpre : nullptr; p.ldo0 = F;      // act'(pre) in act_grad_type<T> (gemm.hip): F elements per row
             p.out1 = b + W.hact; p.ldo1 = F * e;
             MFVIT_TRY(gemm_nt_tile(d.dtype, d.act == 1 ? EPI_BIAS_RELU : EPI_BIAS_GELU, p, st));
         }
@@ -481,7 +481,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 GemmP p = zero_gemm();
                 p.A = gxT; p.lda = D * e; p.W = sb + S.fc2_t; p.ldw = D * e;
                 p.M = d.M; p.N = d.F; p.K = d.D;
-                p.aux = b + W.hpre; p.ldaux = F * e;
+                p.aux = b + W.hpre; p.ldaux = F;
                 p.out0 = dhpre; p.ldo0 = F * e;
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_GELU_BWD, p, st));
             }
@@ -613,7 +613,7 @@ int mfvit_eval_counts(const float* scores, int64_t ld, const int64_t* labels, in
 }
 int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                      int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream) {
-    if (!x || !w || !y) return MFVIT_EINVAL;
+    if (!x || !w || (!y && epilogue != EPI_BIAS_GELU)) return MFVIT_EINVAL;      // GELU: y = NULL skips the saved derivative
     if (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU && epilogue != EPI_NONE) return MFVIT_EINVAL;
     if (epilogue == EPI_BIAS_GELU && !y2) return MFVIT_EINVAL;
     GemmP p = zero_gemm();

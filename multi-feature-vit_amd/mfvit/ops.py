@@ -44,28 +44,32 @@ def split_unpack(s):
     return (g[..., 0, :] + g[..., 1, :]).reshape(*lead, N2 // 2)
 
 
-def linear_fwd(x, w, bias=None, gelu=False, persistent=False, split=False):
-    """y = x @ w.T + bias (x [M,K], w [N,K] of the same dtype).  gelu=True returns (gelu'(y), gelu(y)).
-    persistent=True runs the experimental persistent 256x128 kernel (bf16 only).  split=True: x, w and the results are split-bf16
-    storage ([M,2K], [N,2K] -> [M,2N])."""
+def linear_fwd(x, w, bias=None, gelu=False, persistent=False, split=False, want_grad=True):
+    """y = x @ w.T + bias (x [M,K], w [N,K] of the same dtype).  gelu=True returns (gelu'(y), gelu(y)); want_grad=False skips the
+    derivative (returns (None, gelu(y))).  persistent=True runs the experimental persistent 256x128 kernel (bf16; split bf16 without
+    GELU), persistent="ws" the warp-specialised one (bf16).  split=True: x, w and the results are split-bf16 storage ([M,2K], [N,2K] ->
+    [M,2N]) - except gelu'(y), which the library keeps as plain fp16 [M,N] for split tensors (it only ever multiplies a gradient)."""
     require_cuda(x, w, bias)
     code = _code_of(x, split)
     e = 2 if split else 1
     M, K = x.shape[0], x.shape[1] // e
     N = w.shape[0]
-    y = torch.empty(M, N * e, device=x.device, dtype=x.dtype)
-    y2 = torch.empty_like(y) if gelu else None
     epi = EPI_BIAS_GELU if gelu else (EPI_BIAS if bias is not None else EPI_NONE)
+    if gelu:
+        y2 = torch.empty(M, N * e, device=x.device, dtype=x.dtype)
+        y = torch.empty(M, N, device=x.device, dtype=torch.float16 if split else x.dtype) if want_grad else None
+        ldy = N
+    else:
+        y, y2, ldy = torch.empty(M, N * e, device=x.device, dtype=x.dtype), None, N * e
     if persistent == "ws":
-        check(lib().mfvit_linear_fwd_ws(epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N, ptr(y2), N, M, N, K,
+        check(lib().mfvit_linear_fwd_ws(epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), ldy, ptr(y2), N, M, N, K,
                                         stream()), "mfvit_linear_fwd_ws")
-        return (y, y2) if gelu else y
-    if persistent:
-        check(lib().mfvit_linear_fwd_persistent(epi + (100 if split else 0), ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N * e,
+    elif persistent:
+        check(lib().mfvit_linear_fwd_persistent(epi + (100 if split else 0), ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), ldy,
                                                 ptr(y2), N * e, M, N, K, stream()), "mfvit_linear_fwd_persistent")
-        return (y, y2) if gelu else y
-    check(lib().mfvit_linear_fwd(code, epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), N * e, ptr(y2), N * e, M, N, K,
-                                 stream()), "mfvit_linear_fwd")
+    else:
+        check(lib().mfvit_linear_fwd(code, epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), ldy, ptr(y2), N * e, M, N, K,
+                                     stream()), "mfvit_linear_fwd")
     return (y, y2) if gelu else y
 
 

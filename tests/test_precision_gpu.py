@@ -99,9 +99,13 @@ def test_linear_fwd(mode, M, N, K):
     dact, act = ops.linear_fwd(mode.pack(x), mode.pack(w), b.to(dev()), gelu=True, split=mode.split)
     rg = ref.clone().requires_grad_(True)
     torch.nn.functional.gelu(rg).sum().backward()
-    e1, e2 = rel_err(mode.unpack(dact), rg.grad), rel_err(mode.unpack(act), torch.nn.functional.gelu(ref))
+    # gelu' is kept as plain fp16 in both modes (split tensors: it only ever multiplies a gradient; include/mfvit.h)
+    assert dact.dtype == torch.float16 and tuple(dact.shape) == (M, N)
+    e1, e2 = rel_err(dact.float().cpu(), rg.grad), rel_err(mode.unpack(act), torch.nn.functional.gelu(ref))
     log(f"linear_fwd[{mode.name},{M},{N},{K}] {e:.2e} gelu' {e1:.2e} gelu {e2:.2e}")
-    assert e < mode.tol and e1 < mode.tol and e2 < mode.tol
+    assert e < mode.tol and e1 < F16_TOL and e2 < mode.tol
+    none, act2 = ops.linear_fwd(mode.pack(x), mode.pack(w), b.to(dev()), gelu=True, split=mode.split, want_grad=False)     # no-grad forward
+    assert none is None and rel_err(mode.unpack(act2), torch.nn.functional.gelu(ref)) < mode.tol
 
 
 @pytest.mark.parametrize("mode", MODES, ids=IDS)
@@ -460,7 +464,8 @@ def test_encoder_with_fused_mhsa_matches_unfused(precision, tmp_path):
 @pytest.mark.parametrize("M,N,K", [(197 * 128, 1152, 384), (197 * 33 + 5, 1536, 384), (1100, 384, 1536), (4096, 128, 128)])
 def test_split_linear_fwd_persistent(M, N, K):
     """The persistent 256x128 LDS-DMA kernel (csrc/gemm_pers.hip) in its split-bf16 instantiation: against float64 math and, bit for
-    bit, against the default 128x128 split kernel (same products in the same order per output element), all three epilogues."""
+    bit, against the default 128x128 split kernel (same products in the same order per output element); bias and plain epilogues (the
+    GELU epilogue of split tensors keeps gelu' as plain fp16 and lives in the 128x128 kernel only)."""
     from mfvit import ops
     mode = MODES[0]
     x, w, b = rnd((M, K), 1), rnd((N, K), 2, 0.05), rnd((N,), 3)
@@ -471,7 +476,6 @@ def test_split_linear_fwd_persistent(M, N, K):
     log(f"split linear_fwd_persistent[{M},{N},{K}] {e:.2e}")
     assert e < SPLIT_TOL
     assert torch.equal(y, ops.linear_fwd(xd, wd, bd, split=True))
-    dact, act = ops.linear_fwd(xd, wd, bd, gelu=True, persistent=True, split=True)
-    dact0, act0 = ops.linear_fwd(xd, wd, bd, gelu=True, split=True)
-    assert torch.equal(dact, dact0) and torch.equal(act, act0)
+    with pytest.raises(RuntimeError):
+        ops.linear_fwd(xd, wd, bd, gelu=True, persistent=True, split=True)
     assert torch.equal(ops.linear_fwd(xd, wd, None, persistent=True, split=True), ops.linear_fwd(xd, wd, None, split=True))
