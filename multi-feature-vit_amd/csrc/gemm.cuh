@@ -208,6 +208,7 @@ struct GemmP {
     void* out1; long ldo1;
     const void* aux; long ldaux;
     const float* res; long ldres;
+    const void* res_t; long ldres_t;   // LayerNorm-backward row kernels: the residual gradient in the operand type T instead of f32 (see vit.hip)
     int res_mod, res_off;
     int orow_in, orow_out, orow_off;
     const float* gamma; const float* beta; float eps;

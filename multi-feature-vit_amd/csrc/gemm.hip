@@ -232,6 +232,9 @@ __device__ __forceinline__ void row_reduce(float (&p)[TM][16], float* red, float
 // LayerNorm backward recomputes the normalised input from a second read of x (L2: this workgroup fetched it a moment ago) instead of
 // keeping it in 96 registers, and global loads are issued in batches of 24 - 48 with the arithmetic behind a scheduling barrier.
 constexpr int ROW_LEAN_LDS = 2 * 64 * ROW_RS * 4 + 4 * 64 * 4;
+// (Measured and not kept: staging each wave's 32 x 96 output block in a wave-private LDS slice and writing it with 16-byte stores instead of
+// the 96 four-byte + 192 two-byte stores per thread below - proj + LN 50 -> 53.5 us, fc2 + LN 155 -> 162, LayerNorm-backward 130 -> 129 /
+// 174 -> 160: the stores cost their BYTES, not their instruction count; what pays is not writing a tensor at all, see `res_t`.)
 // REMAP: the patch-embedding launch only (output rows re-indexed past the cls row, residual = pos_embed[row % patches]); everything
 // else gets straight-line code without the per-row `orow_in ? ... : m` selects and their integer divisions
 template <typename T, int REPI, int BM, int TM, int TN, bool REMAP>
@@ -432,8 +435,9 @@ __device__ __forceinline__ void row_epilogue_lean(const GemmP& p, int m0, f32x16
             gj2[j] = gj[j];
             asm volatile("" : "+v"(gj2[j]));
         }
+        const T* __restrict__ rest = (const T*)p.res_t;      // residual gradient in the operand type (hi + lo = the f32 value to 2^-17)
         auto phase2 = [&](auto has_res) {
-            constexpr bool RES = decltype(has_res)::value;
+            constexpr int RES = decltype(has_res)::value;     // 0 none, 1 f32, 2 operand type
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -446,7 +450,8 @@ __device__ __forceinline__ void row_epilogue_lean(const GemmP& p, int m0, f32x16
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             xv[e][j] = x2[(long)mm * p.ldaux + ncol[j]];
-                            if constexpr (RES) rv[e][j] = resp[(long)mm * p.ldres + ncol[j]];
+                            if constexpr (RES == 1) rv[e][j] = resp[(long)mm * p.ldres + ncol[j]];
+                            if constexpr (RES == 2) rv[e][j] = load_elem<T>(rest + (long)mm * p.ldres_t, ncol[j]);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -469,9 +474,11 @@ __device__ __forceinline__ void row_epilogue_lean(const GemmP& p, int m0, f32x16
                 }
         };
         if (resp)
-            phase2(std::true_type());
+            phase2(std::integral_constant<int, 1>());
+        else if (rest)
+            phase2(std::integral_constant<int, 2>());
         else
-            phase2(std::false_type());
+            phase2(std::integral_constant<int, 0>());
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(cs_x[j]));
         int m0c = m0;
@@ -487,8 +494,10 @@ __device__ __forceinline__ void row_epilogue_lean(const GemmP& p, int m0, f32x16
                 for (int e = 0; e < 2; ++e) {
                     const int mraw = m0c + lrow(i, r + e);
                     m[e] = mraw < p.M ? mraw : p.M - 1;
+                    if (dxo) {       // the f32 copy is optional: inside the encoder only the embedding stage reads it (dropping it: -14 % per launch)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) dxo[(long)m[e] * p.ldo0 + ncol[j]] = acc[i][j][r + e];
+                        for (int j = 0; j < TN; ++j) dxo[(long)m[e] * p.ldo0 + ncol[j]] = acc[i][j][r + e];
+                    }
                 }
                 if (dxt) {
 #pragma unroll
@@ -695,6 +704,10 @@ __global__ __launch_bounds__(WM * 256, (WM == 1 && sizeof(T) == 2) ? 2 : 1) void
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j][r] = rs * (acc[i][j][r] * gj[j] - c1 - xh[i][j][r] * c2) + resp[(long)m * p.ldres + ncol[j]];
+                } else if (p.res_t) {            // ... residual gradient kept in the operand type
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j][r] = rs * (acc[i][j][r] * gj[j] - c1 - xh[i][j][r] * c2) + load_elem<T>((const T*)p.res_t + (long)m * p.ldres_t, ncol[j]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j][r] = rs * (acc[i][j][r] * gj[j] - c1 - xh[i][j][r] * c2);
@@ -711,8 +724,10 @@ __global__ __launch_bounds__(WM * 256, (WM == 1 && sizeof(T) == 2) ? 2 : 1) void
             for (int r = 0; r < 16; ++r) {       // stores only
                 const int mraw = m0 + (wm * TM + i) * 32 + acc_row(r, lane);
                 const int m = mraw < p.M ? mraw : p.M - 1;
+                if (dxo) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) dxo[(long)m * p.ldo0 + ncol[j]] = acc[i][j][r];
+                    for (int j = 0; j < TN; ++j) dxo[(long)m * p.ldo0 + ncol[j]] = acc[i][j][r];
+                }
                 if (dxt) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) store_elem<T>(dxt + (long)m * p.ldo1, ncol[j], acc[i][j][r]);

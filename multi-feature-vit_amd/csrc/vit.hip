@@ -450,6 +450,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
         return hipStreamWaitEvent(st, ss.done[l & 63], 0) == hipSuccess ? MFVIT_OK : MFVIT_ELAUNCH;
     };
 
+    const bool lean_grad = d.dtype != MFVIT_F32;
     for (int s = stage_hi; s >= stage_lo; --s) {
         if (s == d.depth) {
             // final LayerNorm backward: dfeatures -> gx (grad of x_depth); dcol = d fc2_b of the last block
@@ -502,8 +503,11 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.aux = b + W.xmid; p.ldaux = D;
                 p.mean = (float*)(b + W.st2); p.rstd = (float*)(b + W.st2) + d.M;
                 p.gamma = pb + L.ln2_w;
-                p.res = gx; p.ldres = D;
-                p.out0 = gmid; p.ldo0 = D; p.out1 = gmidT; p.ldo1 = D * e;
+                // 16-bit modes: the residual gradient travels in the operand-type copy alone (gxT / gmidT: hi + lo = the f32 value to 2^-17);
+                // the f32 copies gx / gmid were a second 38.7 MB store per launch (14 % of it) read by nobody else but the embedding stage
+                if (lean_grad) { p.res_t = gxT; p.ldres_t = D * e; p.out0 = nullptr; }
+                else { p.res = gx; p.ldres = D; p.out0 = gmid; }
+                p.ldo0 = D; p.out1 = gmidT; p.ldo1 = D * e;
                 p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = gb + L.proj_b; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
@@ -545,8 +549,9 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.aux = xbuf(l); p.ldaux = D;
                 p.mean = stat(l); p.rstd = stat(l) + d.M;
                 p.gamma = pb + L.ln1_w;
-                p.res = gmid; p.ldres = D;
-                p.out0 = gx; p.ldo0 = D; p.out1 = pp(W.gxT, l - 1); p.ldo1 = D * e;
+                if (lean_grad) { p.res_t = gmidT; p.ldres_t = D * e; p.out0 = l == 0 ? gx : nullptr; }     // (the embedding stage reads gx)
+                else { p.res = gmid; p.ldres = D; p.out0 = gx; }
+                p.ldo0 = D; p.out1 = pp(W.gxT, l - 1); p.ldo1 = D * e;
                 p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = l > 0 ? gblk(l - 1) + L.fc2_b : colscr; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
