@@ -151,6 +151,16 @@ int mfvit_linear_dgrad_ln_bwd(int dtype, const void* dy, int64_t lddy, const voi
 int mfvit_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int head_dim, mfvit_stream_t stream);
 int mfvit_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias_qkv,
                         int B, int T, int H, int head_dim, mfvit_stream_t stream);
+/* The same with dropout on the attention probabilities (TransFuser GPT, fuseattention.py:52 `att = self.attn_drop(att)`), streaming kernels
+ * (16-bit dtypes; head_dim 32 / 64 / 96; B * H * T * T < 2^32).  The keep mask is a counter-based hash of (seed, site, element index
+ * ((b * H + h) * T + i) * T + j) >= p * 2^32, regenerated by the backward - nothing is stored; kept values are scaled by 1 / (1 - p).
+ * p = 0 is plain attention.  mfvit_dropout_mask writes the keep bytes (1 / 0) of the first n elements of a site: what the parity tests
+ * feed the reference arithmetic with (the reference's own torch RNG stream cannot be reproduced). */
+int mfvit_attention_drop_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int head_dim, float p, uint64_t seed,
+                             uint32_t site, mfvit_stream_t stream);
+int mfvit_attention_drop_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T, int H,
+                             int head_dim, float p, uint64_t seed, uint32_t site, mfvit_stream_t stream);
+int mfvit_dropout_mask(float p, uint64_t seed, uint32_t site, int64_t n, uint8_t* keep, mfvit_stream_t stream);
 /* FUSED multi-head self-attention forward (timm Attention.forward up to the output projection: qkv Linear -> softmax(q k^T / sqrt(d)) v;
  * the "fused-attention kernel" of the north star): one workgroup per (image, head) computes the head's q, k, v from the LayerNorm-ed
  * tokens x [B][T][D] and the packed weight wqkv [3D][D] (+ bias [3D] f32), keeps them on chip and runs the attention core.

@@ -137,9 +137,11 @@ __device__ __forceinline__ void tl_ids(int H, int nblk, int& b, int& h, int& blk
     h = bh % H;
 }
 
-template <typename T, int NB>
+// DROP: attention dropout (fuseattention.py:52 `att = self.attn_drop(att)`): the mask multiplies the PV operand only - the row sum that
+// normalises the output stays the sum of the unmasked probabilities
+template <typename T, int NB, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_tiled_fwd_kernel(const typename Vec4<T>::elem* __restrict__ qkv, typename Vec4<T>::elem* __restrict__ out,
-                                                             float* __restrict__ lse, int Tn, int H, float scale) {
+                                                             float* __restrict__ lse, int Tn, int H, float scale, DropP drop) {
     typedef TG<T, NB> G;
     typedef typename G::E E;
     typedef typename G::frag_t frag_t;
@@ -206,8 +208,11 @@ __global__ __launch_bounds__(256) void attn_tiled_fwd_kernel(const typename Vec4
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(fmaf(sc[t][r], c, -m2));
-                sc[t][r] = p;
                 lsum += p;
+                if constexpr (DROP)
+                    sc[t][r] = p * drop_mul(drop, (unsigned)((((long)b * H + h) * Tn + qc) * Tn + k0 + t * 32 + tl_acc_row(r, lane)));
+                else
+                    sc[t][r] = p;
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -229,10 +234,10 @@ __global__ __launch_bounds__(256) void attn_tiled_fwd_kernel(const typename Vec4
 }
 
 // dQ: wave = 32 queries; K and V stream through LDS.
-template <typename T, int NB>
+template <typename T, int NB, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_tiled_bwd_dq_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename Vec4<T>::elem* __restrict__ out,
                                                                 const typename Vec4<T>::elem* __restrict__ dout, const float* __restrict__ lse,
-                                                                typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale) {
+                                                                typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale, DropP drop) {
     typedef TG<T, NB> G;
     typedef typename G::E E;
     typedef typename G::frag_t frag_t;
@@ -291,8 +296,14 @@ __global__ __launch_bounds__(256) void attn_tiled_bwd_dq_kernel(const typename V
                 dp = tl_mma3<T>(tl_row_frag<T, NB>(Vs, t * 32, s, lane, 0), tl_row_frag<T, NB>(Vs, t * 32, s, lane, LO), dof[s], dol[s], dp);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r)   // dS^T / scale (keys past the end: K rows are zero, so their dQ contribution vanishes)
-                st[r] = __builtin_amdgcn_exp2f(st[r] * c) * dp[r];
+            for (int r = 0; r < 16; ++r) {  // dS^T / scale (keys past the end: K rows are zero, so their dQ contribution vanishes)
+                if constexpr (DROP) {       // dP = (dO . v) * mask / (1 - p); dp holds (dO . v) - D
+                    const float mk = drop_mul(drop, (unsigned)((((long)b * H + h) * Tn + qc) * Tn + k0 + t * 32 + tl_acc_row(r, lane)));
+                    st[r] = __builtin_amdgcn_exp2f(st[r] * c) * fmaf(dp[r] - Dq, mk, Dq);
+                } else {
+                    st[r] = __builtin_amdgcn_exp2f(st[r] * c) * dp[r];
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 frag_t sh, sl;
@@ -310,10 +321,10 @@ __global__ __launch_bounds__(256) void attn_tiled_bwd_dq_kernel(const typename V
 }
 
 // dK, dV: wave = 32 keys; Q, dO and the per-query -lse/scale, -D stream through LDS.
-template <typename T, int NB>
+template <typename T, int NB, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_tiled_bwd_dkv_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename Vec4<T>::elem* __restrict__ out,
                                                                  const typename Vec4<T>::elem* __restrict__ dout, const float* __restrict__ lse,
-                                                                 typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale) {
+                                                                 typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale, DropP drop) {
     typedef TG<T, NB> G;
     typedef typename G::E E;
     typedef typename G::frag_t frag_t;
@@ -386,6 +397,8 @@ __global__ __launch_bounds__(256) void attn_tiled_bwd_dkv_kernel(const typename 
                 sm[4 * g] = L4.x, sm[4 * g + 1] = L4.y, sm[4 * g + 2] = L4.z, sm[4 * g + 3] = L4.w;
                 dp[4 * g] = D4.x, dp[4 * g + 1] = D4.y, dp[4 * g + 2] = D4.z, dp[4 * g + 3] = D4.w;
             }
+            f32x16 dneg;                   // DROP: the -D each dp register started from
+            if constexpr (DROP) dneg = dp;
 #pragma unroll
             for (int s = 0; s < G::KSTEPS; ++s) {
                 sm = tl_mma3<T>(tl_row_frag<T, NB>(Qs, t * 32, s, lane, 0), tl_row_frag<T, NB>(Qs, t * 32, s, lane, LO), kf[s], kl[s], sm);    // S[q][key] - lse[q]/scale
@@ -393,8 +406,16 @@ __global__ __launch_bounds__(256) void attn_tiled_bwd_dkv_kernel(const typename 
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sm[r] = __builtin_amdgcn_exp2f(sm[r] * c);
-                dp[r] *= sm[r];
+                const float pr = __builtin_amdgcn_exp2f(sm[r] * c);
+                if constexpr (DROP) {       // dV takes P * mask / (1 - p), dS = P * ((dO . v) * mask / (1 - p) - D)
+                    const int qq = q0 + t * 32 + tl_acc_row(r, lane);
+                    const float mk = drop_mul(drop, (unsigned)((((long)b * H + h) * Tn + (qq < Tn ? qq : Tn - 1)) * Tn + kc));
+                    sm[r] = pr * mk;
+                    dp[r] = pr * fmaf(dp[r] - dneg[r], mk, dneg[r]);
+                } else {
+                    sm[r] = pr;
+                    dp[r] *= pr;
+                }
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -418,37 +439,56 @@ __global__ __launch_bounds__(256) void attn_tiled_bwd_dkv_kernel(const typename 
     }
 }
 
-template <typename T, int NB> int tl_launch_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
+template <typename T, int NB> int tl_launch_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st, DropP drop) {
     typedef TG<T, NB> G;
     typedef typename G::E E;
     const int bytes = 2 * TL_CH * G::PITCH;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_tiled_fwd_kernel<T, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); attr = true; }
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)attn_tiled_fwd_kernel<T, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute((const void*)attn_tiled_fwd_kernel<T, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr = true;
+    }
     const int nblk = (Tn + TL_BLK - 1) / TL_BLK;
     ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * G::HD, 0, st);
-    MFVIT_LAUNCH((attn_tiled_fwd_kernel<T, NB>), dim3(B * H * nblk), dim3(256), bytes, st, (const E*)qkv, (E*)out, lse, Tn, H, 1.0f / sqrtf((float)G::HD));
+    if (drop.thr)
+        MFVIT_LAUNCH((attn_tiled_fwd_kernel<T, NB, true>), dim3(B * H * nblk), dim3(256), bytes, st, (const E*)qkv, (E*)out, lse, Tn, H,
+                     1.0f / sqrtf((float)G::HD), drop);
+    else
+        MFVIT_LAUNCH((attn_tiled_fwd_kernel<T, NB, false>), dim3(B * H * nblk), dim3(256), bytes, st, (const E*)qkv, (E*)out, lse, Tn, H,
+                     1.0f / sqrtf((float)G::HD), drop);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
 template <typename T, int NB> int tl_launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int Tn, int H,
-                                                hipStream_t st) {
+                                                hipStream_t st, DropP drop) {
     typedef TG<T, NB> G;
     typedef typename G::E E;
     const int bytes_q = 2 * TL_CH * G::PITCH, bytes_kv = 2 * TL_CH * G::PITCH + 2 * TL_CH * 4;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attn_tiled_bwd_dq_kernel<T, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_q);
-        (void)hipFuncSetAttribute((const void*)attn_tiled_bwd_dkv_kernel<T, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_kv);
+        (void)hipFuncSetAttribute((const void*)attn_tiled_bwd_dq_kernel<T, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_q);
+        (void)hipFuncSetAttribute((const void*)attn_tiled_bwd_dkv_kernel<T, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_kv);
+        (void)hipFuncSetAttribute((const void*)attn_tiled_bwd_dq_kernel<T, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_q);
+        (void)hipFuncSetAttribute((const void*)attn_tiled_bwd_dkv_kernel<T, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_kv);
         attr = true;
     }
     const int nblk = (Tn + TL_BLK - 1) / TL_BLK;
     const float scale = 1.0f / sqrtf((float)G::HD);
     ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * G::HD, 0, st);
-    MFVIT_LAUNCH((attn_tiled_bwd_dq_kernel<T, NB>), dim3(B * H * nblk), dim3(256), bytes_q, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
-                 (E*)dqkv, Tn, H, scale);
-    MFVIT_CHECK_LAUNCH();
-    MFVIT_LAUNCH((attn_tiled_bwd_dkv_kernel<T, NB>), dim3(B * H * nblk), dim3(256), bytes_kv, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
-                 (E*)dqkv, Tn, H, scale);
+    if (drop.thr) {
+        MFVIT_LAUNCH((attn_tiled_bwd_dq_kernel<T, NB, true>), dim3(B * H * nblk), dim3(256), bytes_q, st, (const E*)qkv, (const E*)out, (const E*)dout,
+                     lse, (E*)dqkv, Tn, H, scale, drop);
+        MFVIT_CHECK_LAUNCH();
+        MFVIT_LAUNCH((attn_tiled_bwd_dkv_kernel<T, NB, true>), dim3(B * H * nblk), dim3(256), bytes_kv, st, (const E*)qkv, (const E*)out,
+                     (const E*)dout, lse, (E*)dqkv, Tn, H, scale, drop);
+    } else {
+        MFVIT_LAUNCH((attn_tiled_bwd_dq_kernel<T, NB, false>), dim3(B * H * nblk), dim3(256), bytes_q, st, (const E*)qkv, (const E*)out, (const E*)dout,
+                     lse, (E*)dqkv, Tn, H, scale, drop);
+        MFVIT_CHECK_LAUNCH();
+        MFVIT_LAUNCH((attn_tiled_bwd_dkv_kernel<T, NB, false>), dim3(B * H * nblk), dim3(256), bytes_kv, st, (const E*)qkv, (const E*)out,
+                     (const E*)dout, lse, (E*)dqkv, Tn, H, scale, drop);
+    }
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -459,31 +499,41 @@ bool attn_tiled_supported(int dtype, int Tn, int HDim) {
     return (dtype == MFVIT_BF16 || dtype == MFVIT_BF16X3 || dtype == MFVIT_F16) && (HDim == 32 || HDim == 64 || HDim == 96) && Tn >= 1;
 }
 
-template <typename T> static int tl_fwd_by_hd(const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, hipStream_t st) {
-    if (HDim == 32) return tl_launch_fwd<T, 1>(qkv, out, lse, B, Tn, H, st);
-    if (HDim == 64) return tl_launch_fwd<T, 2>(qkv, out, lse, B, Tn, H, st);
-    if (HDim == 96) return tl_launch_fwd<T, 3>(qkv, out, lse, B, Tn, H, st);
+template <typename T> static int tl_fwd_by_hd(const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, hipStream_t st, DropP drop) {
+    if (HDim == 32) return tl_launch_fwd<T, 1>(qkv, out, lse, B, Tn, H, st, drop);
+    if (HDim == 64) return tl_launch_fwd<T, 2>(qkv, out, lse, B, Tn, H, st, drop);
+    if (HDim == 96) return tl_launch_fwd<T, 3>(qkv, out, lse, B, Tn, H, st, drop);
     return MFVIT_EINVAL;
 }
 template <typename T> static int tl_bwd_by_hd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int Tn, int H,
-                                              int HDim, hipStream_t st) {
-    if (HDim == 32) return tl_launch_bwd<T, 1>(qkv, out, dout, lse, dqkv, B, Tn, H, st);
-    if (HDim == 64) return tl_launch_bwd<T, 2>(qkv, out, dout, lse, dqkv, B, Tn, H, st);
-    if (HDim == 96) return tl_launch_bwd<T, 3>(qkv, out, dout, lse, dqkv, B, Tn, H, st);
+                                              int HDim, hipStream_t st, DropP drop) {
+    if (HDim == 32) return tl_launch_bwd<T, 1>(qkv, out, dout, lse, dqkv, B, Tn, H, st, drop);
+    if (HDim == 64) return tl_launch_bwd<T, 2>(qkv, out, dout, lse, dqkv, B, Tn, H, st, drop);
+    if (HDim == 96) return tl_launch_bwd<T, 3>(qkv, out, dout, lse, dqkv, B, Tn, H, st, drop);
+    return MFVIT_EINVAL;
+}
+// drop: attention dropout of the TransFuser GPT (make_drop; thr == 0: none).  Needs B * H * Tn * Tn < 2^32 mask indices.
+int attn_fwd_tiled_drop(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, DropP drop, hipStream_t st) {
+    if (drop.thr && (double)B * H * Tn * Tn >= 4294967296.0) return MFVIT_EINVAL;
+    if (dtype == MFVIT_BF16) return tl_fwd_by_hd<bf16>(qkv, out, lse, B, Tn, H, HDim, st, drop);
+    if (dtype == MFVIT_BF16X3) return tl_fwd_by_hd<sbf16>(qkv, out, lse, B, Tn, H, HDim, st, drop);
+    if (dtype == MFVIT_F16) return tl_fwd_by_hd<f16>(qkv, out, lse, B, Tn, H, HDim, st, drop);
+    return MFVIT_EINVAL;
+}
+int attn_bwd_tiled_drop(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int Tn, int H, int HDim,
+                        DropP drop, hipStream_t st) {
+    if (drop.thr && (double)B * H * Tn * Tn >= 4294967296.0) return MFVIT_EINVAL;
+    if (dtype == MFVIT_BF16) return tl_bwd_by_hd<bf16>(qkv, out, dout, lse, dqkv, B, Tn, H, HDim, st, drop);
+    if (dtype == MFVIT_BF16X3) return tl_bwd_by_hd<sbf16>(qkv, out, dout, lse, dqkv, B, Tn, H, HDim, st, drop);
+    if (dtype == MFVIT_F16) return tl_bwd_by_hd<f16>(qkv, out, dout, lse, dqkv, B, Tn, H, HDim, st, drop);
     return MFVIT_EINVAL;
 }
 int attn_fwd_tiled(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, hipStream_t st) {
-    if (dtype == MFVIT_BF16) return tl_fwd_by_hd<bf16>(qkv, out, lse, B, Tn, H, HDim, st);
-    if (dtype == MFVIT_BF16X3) return tl_fwd_by_hd<sbf16>(qkv, out, lse, B, Tn, H, HDim, st);
-    if (dtype == MFVIT_F16) return tl_fwd_by_hd<f16>(qkv, out, lse, B, Tn, H, HDim, st);
-    return MFVIT_EINVAL;
+    return attn_fwd_tiled_drop(dtype, qkv, out, lse, B, Tn, H, HDim, make_drop(0.f, 0, 0), st);
 }
 int attn_bwd_tiled(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int Tn, int H, int HDim,
                    hipStream_t st) {
-    if (dtype == MFVIT_BF16) return tl_bwd_by_hd<bf16>(qkv, out, dout, lse, dqkv, B, Tn, H, HDim, st);
-    if (dtype == MFVIT_BF16X3) return tl_bwd_by_hd<sbf16>(qkv, out, dout, lse, dqkv, B, Tn, H, HDim, st);
-    if (dtype == MFVIT_F16) return tl_bwd_by_hd<f16>(qkv, out, dout, lse, dqkv, B, Tn, H, HDim, st);
-    return MFVIT_EINVAL;
+    return attn_bwd_tiled_drop(dtype, qkv, out, dout, lse, dqkv, B, Tn, H, HDim, make_drop(0.f, 0, 0), st);
 }
 
 }  // namespace mfvit

@@ -60,6 +60,25 @@ template <typename E, bool SPLIT> __device__ __forceinline__ void cvt_pair(float
         l1 = l[1];
     }
 }
+// ---- dropout (TransFuser GPT, fuseattention.py:33-34,71,112): counter-based masks, regenerated in the backward from (seed, site, element
+// index) - nothing is stored.  keep(idx) = lowbias32(idx ^ key) >= thr with thr = p * 2^32 and key = hash of (seed, site); kept values are
+// multiplied by 1 / (1 - p).  thr == 0 switches a site off.  (A two-round multiply-xorshift hash, not Philox: the masks need to be
+// reproducible and well mixed, not cryptographic; mfvit_dropout_mask exports them so that the parity tests use the very same masks.)
+struct DropP { unsigned thr; float scale; unsigned key; };
+__host__ __device__ inline unsigned lowbias32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float drop_mul(const DropP& d, unsigned idx) { return lowbias32(idx ^ d.key) >= d.thr ? d.scale : 0.f; }
+inline DropP make_drop(float p, unsigned long long seed, unsigned site) {
+    DropP d;
+    if (!(p > 0.f)) { d.thr = 0; d.scale = 1.f; d.key = 0; return d; }
+    const double t = (double)p * 4294967296.0;
+    d.thr = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    d.scale = 1.0f / (1.0f - p);
+    d.key = lowbias32((unsigned)seed ^ lowbias32((unsigned)(seed >> 32) + 0x9E3779B9u * (site + 1u)));
+    return d;
+}
 // storage type of a saved activation derivative (gelu' / relu'): the tensor's own type, plain fp16 for split tensors (gemm.hip)
 template <typename T> struct act_grad_type { typedef T type; };
 template <> struct act_grad_type<sbf16> { typedef f16 type; };

@@ -411,4 +411,15 @@ int batch_sum(const float* x, float* out, int B, long n, hipStream_t st) {
     return MFVIT_OK;
 }
 
+__global__ __launch_bounds__(256) void dropout_mask_kernel(DropP drop, long n, unsigned char* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = drop_mul(drop, (unsigned)i) != 0.f;
+}
+int dropout_mask(DropP drop, long n, unsigned char* out, hipStream_t st) {
+    if (n <= 0 || n >= (1L << 32)) return MFVIT_EINVAL;
+    MFVIT_LAUNCH(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, drop, n, out);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
 }  // namespace mfvit

@@ -55,4 +55,11 @@ int axpy(float* y, const float* x, float a, long n, hipStream_t st);
 int colsum_rows(const float* x, long ld, float* out, int rows, int row_stride, int row_off, int N, hipStream_t st);
 int batch_sum(const float* x, float* out, int B, long n, hipStream_t st);   // out[i] += sum_b x[b * n + i]
 
+// attention with dropout on the probabilities (TransFuser GPT); streaming kernels only (attention_tiled.hip)
+int attn_fwd_tiled_drop(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, DropP drop, hipStream_t st);
+int attn_bwd_tiled_drop(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int Tn, int H, int HDim,
+                        DropP drop, hipStream_t st);
+bool attn_tiled_supported(int dtype, int Tn, int HDim);
+// elementwise.hip: the keep mask (1 / 0 bytes) of n elements of one dropout site - what the kernels regenerate from (seed, site, index)
+int dropout_mask(DropP drop, long n, unsigned char* out, hipStream_t st);
 }  // namespace mfvit

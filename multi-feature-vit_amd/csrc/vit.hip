@@ -705,6 +705,22 @@ int mfvit_attention_bwd(int dtype, const void* qkv, const void* out, const void*
     if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || T <= 0 || H <= 0) return MFVIT_EINVAL;
     return attn_bwd(dtype, qkv, out, dout, lse, dqkv, dbias_qkv, B, T, H, head_dim, (hipStream_t)stream);
 }
+int mfvit_attention_drop_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int head_dim, float p, uint64_t seed,
+                             uint32_t site, mfvit_stream_t stream) {
+    if (!qkv || !out || !lse || B <= 0 || T <= 0 || H <= 0 || !(p >= 0.f && p < 1.f)) return MFVIT_EINVAL;
+    if (!attn_tiled_supported(dtype, T, head_dim)) return MFVIT_ENOSYS;
+    return attn_fwd_tiled_drop(dtype, qkv, out, lse, B, T, H, head_dim, make_drop(p, seed, site), (hipStream_t)stream);
+}
+int mfvit_attention_drop_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T, int H,
+                             int head_dim, float p, uint64_t seed, uint32_t site, mfvit_stream_t stream) {
+    if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || T <= 0 || H <= 0 || !(p >= 0.f && p < 1.f)) return MFVIT_EINVAL;
+    if (!attn_tiled_supported(dtype, T, head_dim)) return MFVIT_ENOSYS;
+    return attn_bwd_tiled_drop(dtype, qkv, out, dout, lse, dqkv, B, T, H, head_dim, make_drop(p, seed, site), (hipStream_t)stream);
+}
+int mfvit_dropout_mask(float p, uint64_t seed, uint32_t site, int64_t n, uint8_t* keep, mfvit_stream_t stream) {
+    if (!keep || !(p >= 0.f && p < 1.f)) return MFVIT_EINVAL;
+    return dropout_mask(make_drop(p, seed, site), n, keep, (hipStream_t)stream);
+}
 int mfvit_layernorm_fwd(int dtype, const float* x, void* y, int y_f32, const float* gamma, const float* beta, float eps, float* mean,
                         float* rstd, int rows, int N, mfvit_stream_t stream) {
     if (!x || !y || !gamma || !beta) return MFVIT_EINVAL;

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  MUST precede loading libmfvit_hip.so: torch bundles its own libamdhip64.so.7 / libhsa-runtime64;
 #                      whichever copy of that SONAME is mapped first serves the whole process, and mixing the system
 #                      runtime with torch's bundled HSA layer leaves the extension with "no ROCm-capable device"
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MFVIT_LIB") or os.path.join(_HERE, "libmfvit_hip.so")   # MFVIT_LIB: experiment builds
@@ -57,6 +57,9 @@ SIGNATURES = {
     "mfvit_attention_fwd": (I, [I, P, P, P, I, I, I, I, P]),
     "mfvit_attention_bwd": (I, [I, P, P, P, P, P, P, I, I, I, I, P]),
     "mfvit_mhsa_fused_fwd": (I, [I, P, L, P, L, P, P, P, P, I, I, I, I, I, P]),
+    "mfvit_attention_drop_fwd": (I, [I, P, P, P, I, I, I, I, F, c_uint64, c_uint32, P]),
+    "mfvit_attention_drop_bwd": (I, [I, P, P, P, P, P, I, I, I, I, F, c_uint64, c_uint32, P]),
+    "mfvit_dropout_mask": (I, [F, c_uint64, c_uint32, L, P, P]),
     "mfvit_layernorm_fwd": (I, [I, P, P, I, P, P, F, P, P, I, I, P]),
     "mfvit_layernorm_bwd": (I, [I, P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
     "mfvit_cast_transpose": (I, [I, P, P, P, I, I, P]),

@@ -173,6 +173,40 @@ def attention_bwd(qkv, out, dout, lse, heads, want_dbias=True, split=False):
     return dqkv, dbias
 
 
+def attention_drop_fwd(qkv, heads, p, seed, site, split=False):
+    """attention_fwd with dropout on the probabilities (streaming kernels; TransFuser GPT): the keep mask is a counter-based hash of
+    (seed, site, ((b * H + h) * T + i) * T + j), see include/mfvit.h."""
+    require_cuda(qkv)
+    code = _code_of(qkv, split)
+    e = 2 if split else 1
+    B, T, D3 = qkv.shape
+    D = D3 // (3 * e)
+    out = torch.empty(B, T, D * e, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
+    check(lib().mfvit_attention_drop_fwd(code, ptr(qkv), ptr(out), ptr(lse), B, T, heads, D // heads, float(p), int(seed), int(site), stream()),
+          "mfvit_attention_drop_fwd")
+    return out, lse
+
+
+def attention_drop_bwd(qkv, out, dout, lse, heads, p, seed, site, split=False):
+    require_cuda(qkv, out, dout, lse)
+    code = _code_of(qkv, split)
+    e = 2 if split else 1
+    B, T, D3 = qkv.shape
+    D = D3 // (3 * e)
+    dqkv = torch.empty_like(qkv)
+    check(lib().mfvit_attention_drop_bwd(code, ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, T, heads, D // heads, float(p), int(seed),
+                                         int(site), stream()), "mfvit_attention_drop_bwd")
+    return dqkv
+
+
+def dropout_mask(p, seed, site, n, device="cuda:0"):
+    """The keep mask (bool, n elements) the kernels regenerate for one dropout site."""
+    keep = torch.empty(n, device=device, dtype=torch.uint8)
+    check(lib().mfvit_dropout_mask(float(p), int(seed), int(site), n, ptr(keep), stream()), "mfvit_dropout_mask")
+    return keep.bool()
+
+
 def _code_of_dtype(dt, split=False):
     if dt == torch.bfloat16:
         return BF16X3 if split else BF16

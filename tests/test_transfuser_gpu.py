@@ -155,3 +155,52 @@ def test_transfuser_scope_is_stated_not_silent():
         fa.TransFuser(Stream(f, "bf16x3"), Stream(f, "bf16x3"), Config(), types.SimpleNamespace(arch="resnet50", pos_embed=True))
     with pytest.raises(NotImplementedError):
         fa.GPT(384, 4, 3, 8, 14, 14, 1, 0, 0, 0, args, Config(), precision="fp32")._eng()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["bf16x3", "fp16"])
+@pytest.mark.parametrize("B,T,H,hd,p", [(2, 394, 4, 96, 0.1), (3, 70, 2, 64, 0.25), (2, 197, 12, 32, 0.1)])
+def test_attention_dropout_matches_reference_with_the_same_masks(precision, B, T, H, hd, p):
+    """`att = self.attn_drop(att)` (fuseattention.py:52) inside the streaming attention kernels: torch's RNG stream cannot be reproduced, so
+    the kernels' counter-based keep mask is exported (mfvit_dropout_mask) and the reference arithmetic (float64: softmax -> mask / (1 - p)
+    -> @ v, autograd for the backward) runs with exactly that mask.  Also: the keep rate, p = 0 == plain attention, and determinism."""
+    import torch
+    from mfvit import ops
+    split = precision == "bf16x3"
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(1234 + T)
+    D = H * hd
+    qkv = torch.randn(B, T, 3 * D, generator=g) * 0.8
+    dout = torch.randn(B, T, D, generator=g)
+
+    def pack(x):
+        return ops.split_pack(x).to(dev) if split else x.to(torch.float16).to(dev)
+
+    def unpack(y):
+        return ops.split_unpack(y.cpu()).double() if split else y.double().cpu()
+
+    def seen(x):
+        return unpack(pack(x))
+    seed, site = 0x1234_5678_9ABC, 7
+    keep = ops.dropout_mask(p, seed, site, B * H * T * T).reshape(B, H, T, T).cpu()
+    rate = keep.double().mean().item()
+    assert abs(rate - (1 - p)) < 4 * (p * (1 - p) / keep.numel()) ** 0.5 + 1e-4, rate
+    qd = seen(qkv).requires_grad_(True)
+    q, k, v = qd.reshape(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    att = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    o_ref = ((att * keep.double() / (1 - p)) @ v).transpose(1, 2).reshape(B, T, D)
+    out, lse = ops.attention_drop_fwd(pack(qkv), H, p, seed, site, split=split)
+    e_o = ((unpack(out) - o_ref).abs().max() / o_ref.abs().max()).item()
+    o_ref.backward(seen(dout))
+    dqkv = ops.attention_drop_bwd(pack(qkv), out, pack(dout), lse, H, p, seed, site, split=split)
+    e_d = ((unpack(dqkv) - qd.grad).abs().max() / qd.grad.abs().max()).item()
+    tol_o, tol_d = (5e-5, 3e-4) if split else (2e-3, 6e-3)
+    assert e_o < tol_o and e_d < tol_d, (e_o, e_d)
+    out2, _ = ops.attention_drop_fwd(pack(qkv), H, p, seed, site, split=split)
+    assert torch.equal(out2, out)                                             # same (seed, site) -> same mask
+    out3, _ = ops.attention_drop_fwd(pack(qkv), H, p, seed + 1, site, split=split)
+    assert not torch.equal(out3, out)
+    out0, lse0 = ops.attention_drop_fwd(pack(qkv), H, 0.0, seed, site, split=split)
+    assert torch.equal(lse0, lse)                                             # the log-sum-exp is of the unmasked scores
+    o_plain = ((att.detach()) @ v.detach()).transpose(1, 2).reshape(B, T, D)
+    assert ((unpack(out0) - o_plain).abs().max() / o_plain.abs().max()).item() < tol_o
