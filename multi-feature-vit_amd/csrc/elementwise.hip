@@ -131,6 +131,96 @@ int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long
     return MFVIT_OK;
 }
 
+// ------------------------------------------------------------------------------------- dropout + residual + LayerNorm rows (TransFuser GPT)
+// One wave per row:  v = drop(t) with t = tin[row] (operand type, a GEMM output incl. bias)  or  a0[row] (+ a1[row % mod1]) (f32);
+// x = res[row] + v (res optional); writes x (f32), y = LN(x) (T or f32), mean, rstd.  The keep mask of element (row, n) is
+// drop_mul(drop, row * N + n).  This is `x = x + resid_drop(proj(y))` / `x + mlp(..)[Dropout]` / `drop(pos_emb + tokens)` of
+// fuseattention.py:57,71-72,187 with the LayerNorm that follows; used only while a dropout site is active.
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void drop_add_ln_rows_kernel(const T* __restrict__ tin, long ldt, const float* __restrict__ a0, long lda0,
+                                                               const float* __restrict__ a1, long lda1, int mod1, const float* __restrict__ res,
+                                                               long ldres, DropP drop, float* __restrict__ xout, long ldx, void* __restrict__ y,
+                                                               long ldy, int y_f32, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, int rows) {
+    constexpr int N = NPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= rows) return;
+    float v[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int n = lane + 64 * i;
+        float t = tin ? load_elem<T>(tin + (long)g * ldt, n) : a0[(long)g * lda0 + n];
+        if (!tin && a1) t += a1[(long)(mod1 ? g % mod1 : g) * lda1 + n];
+        t *= drop_mul(drop, (unsigned)g * (unsigned)N + (unsigned)n);
+        v[i] = res ? res[(long)g * ldres + n] + t : t;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) s += v[i];
+    const float mu = wave_sum(s) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { const float dd = v[i] - mu; q += dd * dd; }
+    const float rs = rsqrtf(wave_sum(q) * (1.0f / N) + eps);
+    if (lane == 0) {
+        if (mean) mean[g] = mu;
+        if (rstd) rstd[g] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int n = lane + 64 * i;
+        if (xout) xout[(long)g * ldx + n] = v[i];
+        const float o = (v[i] - mu) * rs * gamma[n] + beta[n];
+        if (y_f32) ((float*)y)[(long)g * ldy + n] = o;
+        else store_elem<T>((T*)y + (long)g * ldy, n, o);
+    }
+}
+int drop_add_ln_rows(int dtype, int N, const void* tin, long ldt, const float* a0, long lda0, const float* a1, long lda1, int mod1,
+                     const float* res, long ldres, DropP drop, float* xout, long ldx, void* y, long ldy, int y_f32, const float* gamma,
+                     const float* beta, float eps, float* mean, float* rstd, int rows, hipStream_t st) {
+    if (rows <= 0) return MFVIT_OK;
+    if (N != 384 || (!tin && !a0) || !y || (double)rows * N >= 4294967296.0) return MFVIT_EINVAL;
+    const dim3 grid((rows + 3) / 4), blk(256);
+#define MFVIT_DAL(TT)                                                                                                                      \
+    MFVIT_LAUNCH((drop_add_ln_rows_kernel<TT, 6>), grid, blk, 0, st, (const TT*)tin, ldt, a0, lda0, a1, lda1, mod1, res, ldres, drop, xout, ldx, y, \
+                 ldy, y_f32, gamma, beta, eps, mean, rstd, rows)
+    switch (dtype) {
+        case MFVIT_BF16: MFVIT_DAL(bf16); break;
+        case MFVIT_BF16X3: MFVIT_DAL(sbf16); break;
+        case MFVIT_F16: MFVIT_DAL(f16); break;
+        default: return MFVIT_EINVAL;
+    }
+#undef MFVIT_DAL
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+// dst[row][n] = src[row][n] * mask(row * N + n) / (1 - p): the gradient entering a dropped branch (operand type -> operand type), or
+// d tokens = d x_0 * mask (f32 -> f32; T ignored)
+template <typename T, bool F32>
+__global__ __launch_bounds__(256) void mask_scale_rows_kernel(const void* __restrict__ src, long lds_, void* __restrict__ dst, long ldd, DropP drop,
+                                                              int rows, int N) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)rows * N) return;
+    const int g = (int)(i / N), n = (int)(i % N);
+    const float mk = drop_mul(drop, (unsigned)i);
+    if constexpr (F32) ((float*)dst)[(long)g * ldd + n] = ((const float*)src)[(long)g * lds_ + n] * mk;
+    else store_elem<T>((T*)dst + (long)g * ldd, n, load_elem<T>((const T*)src + (long)g * lds_, n) * mk);
+}
+int mask_scale_rows(int dtype, bool f32, const void* src, long lds_, void* dst, long ldd, DropP drop, int rows, int N, hipStream_t st) {
+    if (rows <= 0) return MFVIT_OK;
+    if ((double)rows * N >= 4294967296.0) return MFVIT_EINVAL;
+    const dim3 grid((unsigned)(((long)rows * N + 255) / 256)), blk(256);
+    if (f32) MFVIT_LAUNCH((mask_scale_rows_kernel<float, true>), grid, blk, 0, st, src, lds_, dst, ldd, drop, rows, N);
+    else if (dtype == MFVIT_BF16) MFVIT_LAUNCH((mask_scale_rows_kernel<bf16, false>), grid, blk, 0, st, src, lds_, dst, ldd, drop, rows, N);
+    else if (dtype == MFVIT_BF16X3) MFVIT_LAUNCH((mask_scale_rows_kernel<sbf16, false>), grid, blk, 0, st, src, lds_, dst, ldd, drop, rows, N);
+    else if (dtype == MFVIT_F16) MFVIT_LAUNCH((mask_scale_rows_kernel<f16, false>), grid, blk, 0, st, src, lds_, dst, ldd, drop, rows, N);
+    else return MFVIT_EINVAL;
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
 // ------------------------------------------------------------------------------------- LayerNorm rows (bwd)
 // dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)) (+ dres);  column sums: dgamma, dbeta, sum(dx).
 // One wave per row, rows grid-strided; column partials are kept per lane and reduced over the block's 4 waves in LDS.

@@ -62,4 +62,9 @@ int attn_bwd_tiled_drop(int dtype, const void* qkv, const void* out, const void*
 bool attn_tiled_supported(int dtype, int Tn, int HDim);
 // elementwise.hip: the keep mask (1 / 0 bytes) of n elements of one dropout site - what the kernels regenerate from (seed, site, index)
 int dropout_mask(DropP drop, long n, unsigned char* out, hipStream_t st);
+// x = res + drop(t) -> LayerNorm (t: a GEMM output in the operand type, or a0 (+ a1[row % mod1]) in f32); see elementwise.hip
+int drop_add_ln_rows(int dtype, int N, const void* tin, long ldt, const float* a0, long lda0, const float* a1, long lda1, int mod1,
+                     const float* res, long ldres, DropP drop, float* xout, long ldx, void* y, long ldy, int y_f32, const float* gamma,
+                     const float* beta, float eps, float* mean, float* rstd, int rows, hipStream_t st);
+int mask_scale_rows(int dtype, bool f32, const void* src, long lds_, void* dst, long ldd, DropP drop, int rows, int N, hipStream_t st);
 }  // namespace mfvit

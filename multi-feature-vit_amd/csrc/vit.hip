@@ -18,6 +18,9 @@ struct Dims {
     int dtype, B, T, np, D, depth, H, HD, F, M, Mp, es, ep;   // es: bytes per LOGICAL element of a dtype tensor; ep: storage elements per logical one
     bool save, tok, use_pos;
     int act;
+    float p_embd, p_attn, p_resid;      // token-input mode: dropout sites (0 = off)
+    unsigned long long seed;
+    bool drop;                          // any site active
 };
 
 bool get_dims(const mfvit_vit_cfg* c, Dims& d) {
@@ -45,6 +48,14 @@ bool get_dims(const mfvit_vit_cfg* c, Dims& d) {
     d.es = (c->dtype == MFVIT_BF16 || c->dtype == MFVIT_F16) ? 2 : 4;   // split bf16: hi + lo = 4 bytes
     d.ep = c->dtype == MFVIT_BF16X3 ? 2 : 1;
     d.save = c->save_for_backward != 0;
+    d.p_embd = d.tok ? c->p_embd : 0.f;
+    d.p_attn = d.tok ? c->p_attn : 0.f;
+    d.p_resid = d.tok ? c->p_resid : 0.f;
+    for (float pp : {d.p_embd, d.p_attn, d.p_resid})
+        if (!(pp >= 0.f && pp < 1.f)) return false;
+    d.drop = d.p_embd > 0.f || d.p_attn > 0.f || d.p_resid > 0.f;
+    if (d.drop && c->dtype == MFVIT_F32) return false;               // the dropout stages exist for the 16-bit operand types
+    d.seed = ((unsigned long long)c->seed_hi << 32) | c->seed_lo;
     if (d.HD != 32 && d.HD != 64 && d.HD != 96) return false;
     if (d.HD == 96 && c->dtype == MFVIT_F32) return false;      // head_dim 96 runs on the streaming MFMA kernels (16-bit types, split bf16)
     if (c->dtype == MFVIT_BF16X3 && d.HD % 32) return false;    // a head's row piece is whole [hi x 32 | lo x 32] groups
@@ -125,6 +136,7 @@ struct WsLayout {
     size_t y1, qkv, attn, lse, xmid, st2, y2, hpre, hact;
     // backward scratch
     size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart, tnpart;
+    size_t dtmp;                // token-input mode with residual dropout: [M][D] of the operand type (branch output before the dropout; masked dY)
     size_t pp_stride;           // distance between the two ping-pong copies of gxT / gmidT / dhpre / dqkv (0 = none)
     size_t total;
 };
@@ -174,6 +186,7 @@ WsLayout ws_layout(const Dims& d) {
         W.gx = W.gmid = W.gxT = W.gmidT = W.dhpre = W.dattn = W.dqkv = W.colscratch = W.colpart = W.tnpart = o;
         W.pp_stride = 0;
     }
+    W.dtmp = o; o += (d.tok && d.p_resid > 0.f) ? align256(M * D * es) : 0;
     W.total = o;
     return W;
 }
@@ -230,7 +243,7 @@ SideStream& side_stream(hipStream_t caller) {
 
 extern "C" {
 
-int mfvit_abi_version(void) { return 2; }
+int mfvit_abi_version(void) { return 3; }
 int mfvit_set_wgrad_stream(int enabled) {
     g_wgrad_stream.store(enabled ? 1 : 0, std::memory_order_relaxed);
     return MFVIT_OK;
@@ -306,7 +319,14 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
     auto pblk = [&](int l) { return params + L.blk0 + (long)l * L.blk_stride; };
     auto sblk = [&](int l) { return sh + S.blk0 + (size_t)l * S.blk_stride; };
 
-    if (d.tok) {
+    // dropout sites of the token-input (GPT) mode, see mfvit_vit_cfg
+    auto site = [](int l, int which) { return 16u * (unsigned)l + (unsigned)which; };
+    if (d.tok && d.p_embd > 0.f) {
+        // x_0 = drop(tokens + pos_emb) (fuseattention.py:187 `self.drop(self.pos_emb + token_embeddings)`); LN1_0 -> y1_0
+        MFVIT_TRY(drop_add_ln_rows(d.dtype, d.D, nullptr, 0, img, D, d.use_pos ? params + L.pos : nullptr, D, d.T, nullptr, 0,
+                                   make_drop(d.p_embd, d.seed, 1), xbuf(0), D, blk(0) + W.y1, D * e, 0, pblk(0) + L.ln1_w, pblk(0) + L.ln1_b,
+                                   eps, stat(0), stat(0) + d.M, d.M, st));
+    } else if (d.tok) {
         // token input (fuseattention.py:186-189): x_0 = tokens (+ pos_emb, shared by the batch); LN1_0 -> y1_0.  One row kernel pass.
         MFVIT_TRY(ln_rows(d.dtype, d.D, img, D, d.use_pos ? params + L.pos : nullptr, D, d.T, xbuf(0), D, blk(0) + W.y1, D * e, 0,
                           pblk(0) + L.ln1_w, pblk(0) + L.ln1_b, eps, stat(0), stat(0) + d.M, d.M, 1, 0, 0, st));
@@ -342,7 +362,7 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
         // with the qkv store against 37.9 + 28.5 us separate; split bf16 142.4 / 176.8 us against 92.9 + 62.6 us.
         static const int fused_env = [] { const char* ev = getenv("MFVIT_MHSA_FUSED"); return ev ? atoi(ev) : -1; }();
         const int fused_mode = fused_env >= 0 ? fused_env : (d.dtype == MFVIT_BF16X3 ? 2 : 0);
-        if (hw && fused_mode && (fused_mode == 1 || !d.save) && mhsa_fused_supported(d.dtype, d.T, d.HD, d.D)) {
+        if (hw && fused_mode && (fused_mode == 1 || !d.save) && !(d.p_attn > 0.f) && mhsa_fused_supported(d.dtype, d.T, d.HD, d.D)) {
             MFVIT_TRY(mhsa_fused_fwd(d.dtype, b + W.y1, D * e, sb + S.qkv_w, D * e, pb + L.qkv_b, d.save ? b + W.qkv : nullptr, b + W.attn,
                                      (float*)(b + W.lse), d.B, d.T, d.H, d.D, st));
         } else {
@@ -355,7 +375,13 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
             p.out0 = b + W.qkv; p.ldo0 = 3 * D * e;
             MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS, p, st));
         }
-        MFVIT_TRY(attn_fwd(d.dtype, b + W.qkv, b + W.attn, (float*)(b + W.lse), d.B, d.T, d.H, d.HD, st));
+        if (d.p_attn > 0.f) {
+            if (!attn_tiled_supported(d.dtype, d.T, d.HD)) return MFVIT_ENOSYS;
+            MFVIT_TRY(attn_fwd_tiled_drop(d.dtype, b + W.qkv, b + W.attn, (float*)(b + W.lse), d.B, d.T, d.H, d.HD,
+                                          make_drop(d.p_attn, d.seed, site(l, 2)), st));
+        } else {
+            MFVIT_TRY(attn_fwd(d.dtype, b + W.qkv, b + W.attn, (float*)(b + W.lse), d.B, d.T, d.H, d.HD, st));
+        }
         }
         {   // xmid = x + attn Wproj^T + b ; y2 = LN2(xmid)
             GemmP p = zero_gemm();
@@ -368,7 +394,18 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
             p.out1 = b + W.y2; p.ldo1 = D * e;
             p.gamma = pb + L.ln2_w; p.beta = pb + L.ln2_b; p.eps = eps;
             p.mean = (float*)(b + W.st2); p.rstd = (float*)(b + W.st2) + d.M;
-            MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
+            if (d.p_resid > 0.f) {
+                // xmid = x + resid_drop(proj(attn)) (fuseattention.py:57): plain GEMM + bias, then dropout + residual + LN2 in one row pass
+                GemmP q = zero_gemm();
+                q.A = p.A; q.lda = p.lda; q.W = p.W; q.ldw = p.ldw; q.M = p.M; q.N = p.N; q.K = p.K; q.bias = p.bias;
+                q.out0 = ws + W.dtmp; q.ldo0 = D * e;
+                MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS, q, st));
+                MFVIT_TRY(drop_add_ln_rows(d.dtype, d.D, ws + W.dtmp, D * e, nullptr, 0, nullptr, 0, 0, xbuf(l), D,
+                                           make_drop(d.p_resid, d.seed, site(l, 3)), (float*)(b + W.xmid), D, b + W.y2, D * e, 0, p.gamma, p.beta,
+                                           eps, p.mean, p.rstd, d.M, st));
+            } else {
+                MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
+            }
         }
         {   // hpre = y2 W1^T + b1 ; hact = gelu(hpre)
             GemmP p = zero_gemm();
@@ -398,7 +435,18 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
             }
             p.eps = eps;
             p.mean = stat(l + 1); p.rstd = stat(l + 1) + d.M;
-            MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
+            if (d.p_resid > 0.f) {
+                // x_{l+1} = xmid + Dropout(fc2(relu(fc1(y2)))) (fuseattention.py:67-72,80)
+                GemmP q = zero_gemm();
+                q.A = p.A; q.lda = p.lda; q.W = p.W; q.ldw = p.ldw; q.M = p.M; q.N = p.N; q.K = p.K; q.bias = p.bias;
+                q.out0 = ws + W.dtmp; q.ldo0 = D * e;
+                MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS, q, st));
+                MFVIT_TRY(drop_add_ln_rows(d.dtype, d.D, ws + W.dtmp, D * e, nullptr, 0, nullptr, 0, 0, (const float*)(b + W.xmid), D,
+                                           make_drop(d.p_resid, d.seed, site(l, 4)), xbuf(l + 1), D, p.out1, p.ldo1, p.y_f32, p.gamma, p.beta, eps,
+                                           p.mean, p.rstd, d.M, st));
+            } else {
+                MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
+            }
         }
     }
     return MFVIT_OK;
@@ -437,7 +485,8 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     // dY buffers by layer parity (the embed stage counts as layer -1 -> parity 1)
     auto pp = [&](size_t off, int l) { return (void*)(ws + off + (size_t)(l & 1) * W.pp_stride); };
     SideStream& ss = side_stream(st);
-    const bool use_side = ss.ok && W.pp_stride != 0 && g_wgrad_stream.load(std::memory_order_relaxed) != 0;
+    // (residual dropout: the masked dY copies live in ONE scratch buffer - everything stays on the caller's stream)
+    const bool use_side = ss.ok && W.pp_stride != 0 && g_wgrad_stream.load(std::memory_order_relaxed) != 0 && !(d.p_resid > 0.f);
     hipStream_t wst = use_side ? ss.s : st;                       // stream of the weight-gradient GEMMs
     // the side stream may only start after everything already queued on the caller's stream (activations, zeroed gradients)
     auto fork = [&]() -> int {                                    // main -> side dependency at this point of the main stream
@@ -451,13 +500,15 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     };
 
     const bool lean_grad = d.dtype != MFVIT_F32;
+    auto site = [](int l, int which) { return 16u * (unsigned)l + (unsigned)which; };
+    const bool rdrop = d.p_resid > 0.f;             // the bias gradients of proj / fc2 then come from the MASKED dY (wgrad column sums)
     for (int s = stage_hi; s >= stage_lo; --s) {
         if (s == d.depth) {
             // final LayerNorm backward: dfeatures -> gx (grad of x_depth); dcol = d fc2_b of the last block
             if (!dfeatures) return MFVIT_EINVAL;
             MFVIT_TRY(ln_bwd_rows(d.dtype, d.D, dfeatures, D, xbuf(d.depth), D, stat(d.depth), stat(d.depth) + d.M, params + L.norm_w,
                                   nullptr, 0, gx, D, pp(W.gxT, d.depth - 1), D * e, dparams + L.norm_w, dparams + L.norm_b,
-                                  gblk(d.depth - 1) + L.fc2_b, colpart, d.M, 1, 0, st));
+                                  rdrop ? colscr + D : gblk(d.depth - 1) + L.fc2_b, colpart, d.M, 1, 0, st));
         } else if (s >= 0) {
             const int l = s;
             char* b = blk(l);
@@ -470,17 +521,23 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
             void* dqkv = pp(W.dqkv, l);
             MFVIT_TRY(wait_layer(l + 2));                         // layer l+2's wgrads read this parity's dhpre / gmidT / dqkv
             MFVIT_TRY(fork());                                    // gxT(l) is ready on the main stream
+            const void* gy2 = gxT;                                // dY of fc2: the residual gradient, masked where the branch was dropped
+            if (rdrop) {
+                MFVIT_TRY(mask_scale_rows(d.dtype, false, gxT, D * e, ws + W.dtmp, D * e, make_drop(d.p_resid, d.seed, site(l, 4)), d.M, d.D, st));
+                gy2 = ws + W.dtmp;
+            }
             {   // dW2 += gx^T hact
                 GemmP p = zero_gemm();
-                p.A = gxT; p.lda = D * e; p.W = b + W.hact; p.ldw = F * e;
+                p.A = gy2; p.lda = D * e; p.W = b + W.hact; p.ldw = F * e;
                 p.M = d.M; p.N = d.D; p.K = d.F;
+                if (rdrop) p.cs0 = gb + L.fc2_b;
                 p.out0 = gb + L.fc2_w; p.ldo0 = F;
                 p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
                 MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
             {   // dhpre = (gx W2) * gelu'(hpre)
                 GemmP p = zero_gemm();
-                p.A = gxT; p.lda = D * e; p.W = sb + S.fc2_t; p.ldw = D * e;
+                p.A = gy2; p.lda = D * e; p.W = sb + S.fc2_t; p.ldw = D * e;
                 p.M = d.M; p.N = d.F; p.K = d.D;
                 p.aux = b + W.hpre; p.ldaux = F;
                 p.out0 = dhpre; p.ldo0 = F * e;
@@ -508,25 +565,35 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 if (lean_grad) { p.res_t = gxT; p.ldres_t = D * e; p.out0 = nullptr; }
                 else { p.res = gx; p.ldres = D; p.out0 = gmid; }
                 p.ldo0 = D; p.out1 = gmidT; p.ldo1 = D * e;
-                p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = gb + L.proj_b; p.cpart = colpart;
+                p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = rdrop ? colscr + D : gb + L.proj_b; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
+            }
+            const void* gyp = gmidT;                              // dY of proj
+            if (rdrop) {
+                MFVIT_TRY(mask_scale_rows(d.dtype, false, gmidT, D * e, ws + W.dtmp, D * e, make_drop(d.p_resid, d.seed, site(l, 3)), d.M, d.D, st));
+                gyp = ws + W.dtmp;
             }
             MFVIT_TRY(fork());
             {   // dWproj += gmid^T attn
                 GemmP p = zero_gemm();
-                p.A = gmidT; p.lda = D * e; p.W = b + W.attn; p.ldw = D * e;
+                p.A = gyp; p.lda = D * e; p.W = b + W.attn; p.ldw = D * e;
                 p.M = d.M; p.N = d.D; p.K = d.D;
+                if (rdrop) p.cs0 = gb + L.proj_b;
                 p.out0 = gb + L.proj_w; p.ldo0 = D;
                 p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
                 MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
             {   // dattn = gmid Wproj
                 GemmP p = zero_gemm();
-                p.A = gmidT; p.lda = D * e; p.W = sb + S.proj_t; p.ldw = D * e;
+                p.A = gyp; p.lda = D * e; p.W = sb + S.proj_t; p.ldw = D * e;
                 p.M = d.M; p.N = d.D; p.K = d.D;
                 p.out0 = ws + W.dattn; p.ldo0 = D * e;
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, p, st));
             }
+            if (d.p_attn > 0.f)
+                MFVIT_TRY(attn_bwd_tiled_drop(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, d.B, d.T, d.H, d.HD,
+                                              make_drop(d.p_attn, d.seed, site(l, 2)), st));
+            else
             MFVIT_TRY(attn_bwd(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, nullptr,
                                d.B, d.T, d.H, d.HD, st));
             MFVIT_TRY(fork());
@@ -552,11 +619,13 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 if (lean_grad) { p.res_t = gmidT; p.ldres_t = D * e; p.out0 = l == 0 ? gx : nullptr; }     // (the embedding stage reads gx)
                 else { p.res = gmid; p.ldres = D; p.out0 = gx; }
                 p.ldo0 = D; p.out1 = pp(W.gxT, l - 1); p.ldo1 = D * e;
-                p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = l > 0 ? gblk(l - 1) + L.fc2_b : colscr; p.cpart = colpart;
+                p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = (l > 0 && !rdrop) ? gblk(l - 1) + L.fc2_b : colscr; p.cpart = colpart;
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
         } else if (d.tok) {
             // token-input embedding stage: gx = d x_0 = d tokens; d pos_emb = sum over the batch (fuseattention.py:187)
+            if (d.p_embd > 0.f)      // d (tokens + pos_emb) = d x_0 * mask / (1 - p)
+                MFVIT_TRY(mask_scale_rows(d.dtype, true, gx, D, gx, D, make_drop(d.p_embd, d.seed, 1), d.M, d.D, st));
             if (dinput && hipMemcpyAsync(dinput, gx, (size_t)d.M * D * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
                 return MFVIT_ELAUNCH;
             if (d.use_pos) MFVIT_TRY(batch_sum(gx, dparams + L.pos, d.B, (long)d.T * D, st));

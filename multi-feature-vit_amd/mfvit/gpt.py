@@ -15,8 +15,8 @@ from .arena import ParamArena
 
 class _GptFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, eng, tokens, need_grad, *params):
-        out, ws, cfg = eng.run_forward(tokens, need_grad)
+    def forward(ctx, eng, tokens, need_grad, drop, *params):
+        out, ws, cfg = eng.run_forward(tokens, need_grad, drop)
         ctx.eng, ctx.ws, ctx.cfg = eng, ws, cfg
         return out
 
@@ -28,7 +28,7 @@ class _GptFn(torch.autograd.Function):
         dtokens, grads = eng.run_backward(ctx.cfg, ctx.ws, dout)
         eng.release_ws(ctx.ws)
         ctx.ws = None
-        return (None, dtokens, None) + tuple(grads)
+        return (None, dtokens, None, None) + tuple(grads)
 
 
 class GptEngine:
@@ -47,7 +47,9 @@ class GptEngine:
         self._shadow_key = None
         self._pool = {}
 
-    def cfg(self, batch, save):
+    def cfg(self, batch, save, drop=None):
+        """drop: None, or (p_embd, p_attn, p_resid, seed) for a training-mode forward (the backward re-uses the SAME cfg: the masks are
+        functions of the seed in it)."""
         c = VitCfg()
         c.dtype = _lib.dtype_code(self.precision)
         c.batch, c.img_h, c.img_w = batch, 0, 0
@@ -56,6 +58,9 @@ class GptEngine:
         c.stop_grad_conv1 = 0
         c.ln_eps = self.ln_eps
         c.token_input, c.tokens, c.use_pos, c.act = 1, self.tokens, int(self.use_pos), 1
+        if drop is not None:
+            c.p_embd, c.p_attn, c.p_resid = float(drop[0]), float(drop[1]), float(drop[2])
+            c.seed_lo, c.seed_hi = int(drop[3]) & 0xFFFFFFFF, (int(drop[3]) >> 32) & 0xFFFFFFFF
         return c
 
     def _ensure(self, cfg):
@@ -76,13 +81,13 @@ class GptEngine:
         if len(pool) < 2:
             pool.append(ws)
 
-    def run_forward(self, tokens, save):
+    def run_forward(self, tokens, save, drop=None):
         _lib.require_cuda(tokens)
         tokens = tokens.contiguous().float()
         B, T, D = tokens.shape
         if T != self.tokens or D != self.dim:
             raise _lib.MfvitError(f"expected (B, {self.tokens}, {self.dim}) tokens, got {tuple(tokens.shape)} (pos_emb is length-bound)")
-        cfg = self.cfg(B, save)
+        cfg = self.cfg(B, save, drop)
         flat = self._ensure(cfg)
         nbytes = lib().mfvit_vit_workspace_bytes(cfg)
         if nbytes == 0:
@@ -105,6 +110,9 @@ class GptEngine:
               "mfvit_gpt_backward")
         return dtokens, self.arena.grad_views(gflat)
 
-    def __call__(self, tokens):
+    def __call__(self, tokens, drop=None):
+        """drop = (p_embd, p_attn, p_resid, seed): the training-mode dropout sites of the GPT (None / all zero: none)."""
         need = torch.is_grad_enabled() and (tokens.requires_grad or any(p.requires_grad for p in self.arena.params))
-        return _GptFn.apply(self, tokens, need, *self.arena.params)
+        if drop is not None and not any(float(p) > 0 for p in drop[:3]):
+            drop = None
+        return _GptFn.apply(self, tokens, need, drop, *self.arena.params)

@@ -14,8 +14,10 @@ streaming MFMA attention of csrc/attention_tiled.hip for head_dim 96).
 Scope notes (stated, not silent):
   * the ViT branch only (``args.arch`` starting with 'vit'); the ResNet branch (:105, :176-184, :198-203) is the CNN path (SURVEY §2
     out-of-scope rows) and raises NotImplementedError;
-  * dropout: the kernels have no dropout stage.  Eval mode and p = 0 are exact; TRAINING with a non-zero embd / attn / resid
-    dropout (config.py:40-42 sets 0.1) raises NotImplementedError instead of silently training without it;
+  * dropout (embd / attn / resid, config.py:40-42 sets 0.1 each) is built into the composite: counter-based masks drawn from a per-forward
+    seed (torch's generator supplies the seed, so `torch.manual_seed` makes runs reproducible) and regenerated in the backward.  The
+    mask STREAM is not torch's (a CUDA Philox stream cannot be reproduced from here): parity is proven with the kernels' own masks fed
+    to the reference arithmetic (tests/test_transfuser_gpu.py);
   * ``Block`` / ``SelfAttention`` are parameter holders here (the reference only ever runs them inside ``GPT``): their own
     ``forward`` raises.
 """
@@ -124,12 +126,16 @@ class GPT(nn.Module):
         return self._engine
 
     def forward(self, cxr_tensor, enh_tensor):
+        drop = None
         if self.training and any(p > 0 for p in self._pdrops):
-            raise NotImplementedError("training with dropout > 0 (embd / attn / resid pdrop) is not built on the HIP path: the kernels have no "
-                                      "dropout stage.  Use model.eval() or construct the GPT with all three pdrop = 0")
+            if self.precision == "fp32":
+                raise NotImplementedError("the dropout stages of the HIP GPT exist for the 16-bit operand types (bf16x3 / fp16 / bf16)")
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())                           # torch's CPU generator: manual_seed-able
+            drop = (*self._pdrops, seed)
+            self._last_drop = drop                                                                           # (tests: the masks of this forward)
         _, ftrs, _ = cxr_tensor.shape                                                                       # :183
         tokens = torch.cat([cxr_tensor, enh_tensor], dim=1)                                                  # :184
-        x = self._eng()(tokens)                                                                              # :186-192 (pos_emb, blocks, ln_f)
+        x = self._eng()(tokens, drop)                                                                        # :186-192 (pos_emb, blocks, ln_f)
         return x[:, :ftrs, :], x[:, ftrs:, :]                                                                # :207-208
 
 

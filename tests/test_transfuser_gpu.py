@@ -29,7 +29,7 @@ def scale_err(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
-class Config:      # config/config.py:6,21,31-42 of the reference; dropouts zero here (the HIP path has no dropout stage)
+class Config:      # config/config.py:6,21,31-42 of the reference; dropouts zero here (the dropout tests override them)
     seq_len, n_views, vert_anchors, horz_anchors = 1, 1, 14, 14
     n_embd, block_exp, n_layer, n_head = 384, 3, 8, 4
     embd_pdrop = resid_pdrop = attn_pdrop = 0.0
@@ -140,21 +140,102 @@ def test_transfuser_end_to_end_with_hip_backbones_vs_oracle():
 
 def test_transfuser_scope_is_stated_not_silent():
     from model import fuseattention as fa
-    f = torch.zeros(1, 197, 384, device=DEV)
+    f = rng_tensor(4, (1, 197, 384)).to(DEV)
 
     class Drop(Config):
         embd_pdrop = resid_pdrop = attn_pdrop = 0.1               # config.py:40-42
 
     args = types.SimpleNamespace(arch="vit_small", pos_embed=True)
     m = fa.TransFuser(Stream(f, "bf16x3"), Stream(f, "bf16x3"), Drop(), args).to(DEV)
-    with pytest.raises(NotImplementedError, match="dropout"):
-        m.train()(torch.zeros(1, 3, 224, 224, device=DEV), torch.zeros(1, 3, 224, 224, device=DEV))
-    out = m.eval()(torch.zeros(1, 3, 224, 224, device=DEV), torch.zeros(1, 3, 224, 224, device=DEV))   # eval mode: dropout is the identity
-    assert out.shape == (1, 3) and torch.isfinite(out).all()
+    img = torch.zeros(1, 3, 224, 224, device=DEV)
+    out_e = m.eval()(img, img)                                     # eval mode: dropout is the identity
+    assert out_e.shape == (1, 3) and torch.isfinite(out_e).all()
+    torch.manual_seed(5)
+    out_t = m.train()(img, img)                                    # training mode: the dropout sites are live ...
+    assert torch.isfinite(out_t).all() and not torch.equal(out_t, out_e)
+    torch.manual_seed(5)
+    assert torch.equal(m(img, img), out_t)                         # ... and reproducible through torch's generator
+    assert not torch.equal(m(img, img), out_t)                     # a fresh mask per forward
     with pytest.raises(NotImplementedError):
         fa.TransFuser(Stream(f, "bf16x3"), Stream(f, "bf16x3"), Config(), types.SimpleNamespace(arch="resnet50", pos_embed=True))
     with pytest.raises(NotImplementedError):
         fa.GPT(384, 4, 3, 8, 14, 14, 1, 0, 0, 0, args, Config(), precision="fp32")._eng()
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-3), ("fp16", 2e-2)])
+@pytest.mark.parametrize("pdrops", [(0.0, 0.0, 0.0), (0.1, 0.1, 0.1), (0.0, 0.2, 0.0), (0.15, 0.0, 0.3), (0.2, 0.0, 0.0), (0.0, 0.0, 0.2)])
+def test_gpt_training_mode_dropout_matches_reference_with_the_same_masks(precision, tol, pdrops):
+    """The reference config trains the GPT with embd / attn / resid dropout 0.1 (config.py:40-42).  torch's mask stream cannot be
+    reproduced, so the keep masks the kernels drew for THIS forward are exported (mfvit_dropout_mask: same (p, seed, site) -> same bits) and
+    handed to the float64 oracle, whose `_drop` is nn.Dropout with a given mask: outputs, d tokens and every parameter gradient must agree."""
+    from mfvit import ops
+    from model import fuseattention as fa
+    B, T, C, H, NL = 2, 394, 384, 4, 3
+
+    class Cfg(Config):
+        n_layer = NL
+        embd_pdrop, attn_pdrop, resid_pdrop = pdrops
+
+    args = types.SimpleNamespace(arch="vit_small", pos_embed=True)
+    gpt = fa.GPT(384, H, 3, NL, 14, 14, 1, *pdrops, args, Cfg(), precision=precision)
+    sd = ref_gpt.seeded_gpt_params(77, n_layer=NL)
+    gpt.load_state_dict(sd, strict=True)
+    gpt = gpt.to(DEV).train()
+    fc = rng_tensor(91, (B, 197, C)).to(DEV).requires_grad_(True)
+    fe = rng_tensor(92, (B, 197, C)).to(DEV).requires_grad_(True)
+    a, b = gpt(fc, fe)
+    seed = gpt._last_drop[3] if any(pdrops) else 0
+    r = rng_tensor(93, (B, T, C)).to(DEV)
+    (torch.cat([a, b], 1) * r).sum().backward()
+    # the masks of that forward
+    drop = {}
+    if pdrops[0]:
+        drop["embd"] = ops.dropout_mask(pdrops[0], seed, 1, B * T * C).reshape(B, T, C).cpu()
+    for l in range(NL):
+        if pdrops[1]:
+            drop[("attn", l)] = ops.dropout_mask(pdrops[1], seed, 16 * l + 2, B * H * T * T).reshape(B, H, T, T).cpu()
+        if pdrops[2]:
+            drop[("proj", l)] = ops.dropout_mask(pdrops[2], seed, 16 * l + 3, B * T * C).reshape(B, T, C).cpu()
+            drop[("mlp", l)] = ops.dropout_mask(pdrops[2], seed, 16 * l + 4, B * T * C).reshape(B, T, C).cpu()
+    pd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    fcd, fed = fc.detach().double().cpu().requires_grad_(True), fe.detach().double().cpu().requires_grad_(True)
+    ra, rb = ref_gpt.gpt_forward(pd, fcd, fed, n_head=H, pos_embed=True, drop=drop, pdrops=pdrops)
+    (torch.cat([ra, rb], 1) * r.double().cpu()).sum().backward()
+    # Gradients are compared in the L2 norm per tensor, plus a cap on the share of entries that miss the entry-wise tolerance: the MLP is a
+    # ReLU (fuseattention.py:69), and a unit whose pre-activation is within rounding of zero switches side between the f64 oracle and the
+    # kernels - its whole contribution to a few gradient entries appears / vanishes (measured WITHOUT dropout: a handful of entries per
+    # tensor at the 1e-2 level, L2 error 1e-4), so a max-norm bound would test the ReLU's discontinuity, not the dropout arithmetic.
+    def l2(got, ref):
+        got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+        return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+    def outliers(got, ref, scale):
+        got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+        return float(((got - ref).abs() > 2 * tol * scale).double().mean())
+    e_o = max(scale_err(a, ra), scale_err(b, rb))
+    e_t = max(l2(fc.grad, fcd.grad), l2(fe.grad, fed.grad))
+    o_t = max(outliers(fc.grad, fcd.grad, float(fcd.grad.abs().max())), outliers(fe.grad, fed.grad, float(fed.grad.abs().max())))
+    gmax = max(float(v.grad.abs().max()) for v in pd.values())
+    worst, worst_o = ("", 0.0), ("", 0.0)
+    for k, v in gpt.named_parameters():
+        ref = pd[k].grad
+        if float(ref.abs().max()) < 1e-3 * gmax:
+            continue                                      # mathematically zero gradients (attn.key.bias): rounding noise on both sides
+        e = l2(v.grad, ref)
+        o = outliers(v.grad, ref, float(ref.abs().max()))
+        if e > worst[1]:
+            worst = (k, e)
+        if o > worst_o[1]:
+            worst_o = (k, o)
+    log(f"GPT training-mode dropout [{precision}, p={pdrops}]: out {e_o:.2e}; L2: d tokens {e_t:.2e} worst parameter grad {worst[0]} {worst[1]:.2e}; "
+        f"entries past tolerance: d tokens {o_t:.1e} parameters {worst_o[0]} {worst_o[1]:.1e}")
+    # Thresholds.  The forward (no discontinuity on the way) pins the masks at the arithmetic's own accuracy (bf16x3: 5e-6 ... 8e-6).  For the
+    # gradients the yardstick is the ReLU itself: the float64 oracle against ITSELF with every weight perturbed by 1e-5 relative noise (the
+    # accuracy of bf16x3 products) differs by 2.9e-3 (d tokens) / 5.1e-3 (mlp.0.weight) in L2 and 2.2e-2 in the max norm; with 1e-7 noise by
+    # 1e-7.  The kernels measure 1.0e-3 ... 3.9e-3 (bf16x3) and 1.2e-2 ... 2.2e-2 (fp16) with AND without dropout, up to 2 % of the entries
+    # of a 384-entry tensor past the entry-wise tolerance.  A mask that differed between forward and backward, or between the kernels and
+    # the exported bits, on a p-sized share of the elements would be an error of order sqrt(p): 0.3 and more.
+    assert e_o < tol and e_t < 5 * tol and worst[1] < 5 * tol and o_t < 5e-2 and worst_o[1] < 5e-2, (e_o, e_t, worst, o_t, worst_o)
 
 
 @pytest.mark.gpu
