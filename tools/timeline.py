@@ -36,3 +36,22 @@ print("class: launches, avg us (while sharing the GPU), total ms")
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]): print(f"  {k:28s} {c:6d} {t/c/1e3:9.1f} {t/1e6:9.2f}")
 print(f"sum of kernel durations / window = {sum(t for c, t in agg.values())/tot:.2f}")
 qs = collections.Counter(q for *_, q in ev); print("queues:", dict(qs))
+# the idle gaps (no kernel in flight): which kernels sit on either side of the longest ones
+if len(sys.argv) > 4:
+    ev2 = sorted(ev)
+    gaps = []
+    cur_end = ev2[0][1]; last_name = ev2[0][2]
+    for s0, e0, n0, q0 in ev2[1:]:
+        if s0 > cur_end:
+            gaps.append((s0 - cur_end, last_name[:60], n0[:60]))
+        if e0 > cur_end:
+            cur_end = e0; last_name = n0
+    gaps.sort(reverse=True)
+    print(f"idle gaps: {len(gaps)} totalling {sum(g[0] for g in gaps)/1e6:.2f} ms; the longest:")
+    for g in gaps[:int(sys.argv[4])]:
+        print(f"  {g[0]/1e3:8.1f} us  after {g[1]}  before {g[2]}")
+    import collections as _c
+    agg2 = _c.Counter()
+    for g in gaps: agg2[(g[1][:40], g[2][:40])] += g[0]
+    print("by (previous kernel, next kernel), ms:")
+    for k, v in agg2.most_common(12): print(f"  {v/1e6:7.3f}  {k[0]}  ->  {k[1]}")
