@@ -1138,6 +1138,7 @@ template <int REPI> static int row_by_dtype(int dtype, const GemmP& p, hipStream
 static int tn_by_dtype(int dtype, const GemmP& p, hipStream_t st) { MFVIT_BY_DTYPE(dtype, (launch_tn<TT>(p, st))) }
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
+    if (gemm_nt_pp_supported(dtype, epi, p)) return gemm_nt_pp(epi, p, st);
     if (gemm_nt_ws_supported(dtype, epi, p)) return gemm_nt_ws(epi, p, st);
     if (gemm_nt_pers_supported(dtype, epi, p)) return gemm_nt_pers(dtype, epi, p, st);
     if (epi == EPI_GELU_BWD && p.cpart && p.cs0) {
@@ -1155,6 +1156,7 @@ int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
     return MFVIT_EINVAL;
 }
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
+    if (gemm_nt_rowp_supported(dtype, repi, p)) return gemm_nt_rowp(repi, p, st);
     if (repi == REPI_RES_LN) return row_by_dtype<REPI_RES_LN>(dtype, p, st);
     if (repi == REPI_LNBWD_RES) {
         const int rc = row_by_dtype<REPI_LNBWD_RES>(dtype, p, st);

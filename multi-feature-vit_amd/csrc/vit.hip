@@ -695,6 +695,14 @@ int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const 
     p.bias = bias; p.out0 = y; p.ldo0 = ldy; p.out1 = y2; p.ldo1 = ldy2;
     return gemm_nt_tile(dtype, epilogue, p, (hipStream_t)stream);
 }
+int mfvit_linear_dgrad_act(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const void* act_grad, int64_t ldg,
+                           void* dx, int64_t lddx, int M, int N, int K, mfvit_stream_t stream) {
+    if (!dy || !wt || !act_grad || !dx) return MFVIT_EINVAL;
+    GemmP p = zero_gemm();
+    p.A = dy; p.lda = lddy; p.W = wt; p.ldw = ldwt; p.M = M; p.N = N; p.K = K;
+    p.aux = act_grad; p.ldaux = ldg; p.out0 = dx; p.ldo0 = lddx;
+    return gemm_nt_tile(dtype, EPI_GELU_BWD, p, (hipStream_t)stream);
+}
 int mfvit_linear_fwd_persistent(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                                 int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream) {
     if (!x || !w || !y) return MFVIT_EINVAL;

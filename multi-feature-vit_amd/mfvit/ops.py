@@ -73,6 +73,20 @@ def linear_fwd(x, w, bias=None, gelu=False, persistent=False, split=False, want_
     return (y, y2) if gelu else y
 
 
+def linear_dgrad_act(dy, wt, act_grad, split=False):
+    """dx = (dy @ wt.T) * act_grad   (dy [M,K], wt [N,K]; act_grad [M,N] as linear_fwd(gelu=True) returns it: plain fp16 for split
+    tensors).  The fc2 data gradient fused with the GELU backward."""
+    require_cuda(dy, wt, act_grad)
+    code = _code_of(dy, split)
+    e = 2 if split else 1
+    M, K = dy.shape[0], dy.shape[1] // e
+    N = wt.shape[0]
+    dx = torch.empty(M, N * e, device=dy.device, dtype=dy.dtype)
+    check(lib().mfvit_linear_dgrad_act(code, ptr(dy), dy.stride(0), ptr(wt), wt.stride(0), ptr(act_grad), act_grad.stride(0), ptr(dx),
+                                       N * e, M, N, K, stream()), "mfvit_linear_dgrad_act")
+    return dx
+
+
 WGRAD_SCRATCH_FLOATS = 384 * 128 * 128   # include/mfvit.h: MFVIT_WGRAD_SCRATCH_FLOATS
 
 
