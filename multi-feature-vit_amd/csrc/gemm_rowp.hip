@@ -41,13 +41,21 @@ typedef bf16x4 __attribute__((may_alias)) stg_b4;
 constexpr int RP_N = 384;                       // output columns (embed dim): 8 waves x 48
 constexpr int RP_MF = 7;                        // row fragments of 16 per tile
 constexpr int RP_TH = 16 * RP_MF;               // 112 rows at most
-constexpr int RP_AROWS = 128;                   // A rows of a stage (the last 16 are never read: keeps 64 pieces = 8 per wave)
-constexpr int RP_ROWS = RP_AROWS + RP_N;        // 512
-constexpr int RP_STAGE = RP_ROWS * 128;         // 64 KB
-constexpr int RP_RING = 2 * RP_STAGE;           // 128 KB
-constexpr int RP_SCR = 32768;                   // reductions / statistics
+// LDS: W ring 2 x 48 KB | A ring 4 x 14 KB | 8 KB of reduction scratch.  The W rows come out of L2 (every CU streams the same 384 x K
+// matrix), the activation rows come from HBM once (inside a training step they are cold): their ring is four stages deep - a piece is
+// requested three stage times (~3.5 us) before its first use; with one 64 KB stage of both in flight the kernel stalled on every stage
+// inside the step (fc2 + LN 98 us isolated, where the 155 MB of activations sit in the Infinity Cache, but no faster than gemm_nt_row in it).
+constexpr int RP_WSTAGE = RP_N * 128;           // 48 KB
+constexpr int RP_WRING = 2 * RP_WSTAGE;         // 96 KB
+constexpr int RP_ASTAGE = RP_TH * 128;          // 14 KB
+constexpr int RP_ASLOTS = 4;
+constexpr int RP_RING = RP_WRING + RP_ASLOTS * RP_ASTAGE;   // 152 KB
+constexpr int RP_SCR = 8192;                    // reductions / statistics
 constexpr int RP_LDS = RP_RING + RP_SCR;        // 163,840 B
-constexpr int RP_L = 8;                         // LDS-DMA instructions per wave and stage
+constexpr int RP_TOUCH = 2;                     // L2 warm-up loads per thread in the prologue
+constexpr int RP_LW = 6, RP_LA = 2;             // LDS-DMA instructions per wave and stage: W pieces wave + 8 i; A pieces wave, wave + 7
+                                                // (14 pieces of 8 rows: wave 7 repeats wave 6's - identical bytes - so that every wave
+                                                // counts the same number of operations)
 constexpr int RP_YP = 1536 + 16;                // staging pitch of a split output row (768 storage elements + pad)
 
 __device__ __forceinline__ const char* rp_uniform_ptr(const void* q) {
@@ -74,36 +82,40 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
     const int nk = p.K / 32;
     const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
 
-    // ---- LDS-DMA: stage row R (A rows 0 .. 127, W rows 128 .. 511) = 8 chunks of 16 B, positions XOR (R >> 1) & 7; wave w copies the
-    // 8-row pieces w + 8 i (i = 0, 1: A rows, clamped to the tile's last valid row; i = 2 .. 7: W rows)
+    // ---- LDS-DMA: a row = 8 chunks of 16 B, positions XOR (R >> 1) & 7 (R = row inside its slot); a piece = 8 rows = one 1 KB instruction:
+    // position lane & 7 of row 8 pc + (lane >> 3) receives chunk (lane & 7) ^ ((4 (pc & 1) + (lane >> 4)) & 7)
     const int lrow = lane >> 3;
-    const unsigned coff = (unsigned)(((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 16);
-    unsigned voff[RP_L];
+    auto coff_of = [&](int pc) __attribute__((always_inline)) { return (unsigned)(((lane & 7) ^ ((4 * (pc & 1) + (lane >> 4)) & 7)) * 16); };
+    const int pa0 = wave < 7 ? wave : 6, pa1 = pa0 + 7;                // this wave's two A pieces
+    unsigned voffw[RP_LW], voffa[RP_LA];
 #pragma unroll
-    for (int i = 0; i < RP_L; ++i) {
-        const int pc = wave + 8 * i;
-        if (i < 2) {
-            int r = 8 * pc + lrow;
-            r = r < rows ? r : rows - 1;
-            voff[i] = (unsigned)(m0 + r) * (unsigned)(p.lda * 2) + coff;
-        } else {
-            voff[i] = (unsigned)(8 * (pc - 16) + lrow) * (unsigned)(p.ldw * 2) + coff;
-        }
+    for (int i = 0; i < RP_LW; ++i) voffw[i] = (unsigned)(8 * (wave + 8 * i) + lrow) * (unsigned)(p.ldw * 2) + coff_of(wave);
+#pragma unroll
+    for (int i = 0; i < RP_LA; ++i) {
+        const int pc = i ? pa1 : pa0;
+        int r = 8 * pc + lrow;
+        r = r < rows ? r : rows - 1;                                   // rows past the tile replicate its last valid row
+        voffa[i] = (unsigned)(m0 + r) * (unsigned)(p.lda * 2) + coff_of(pc);
     }
     const char* gA = rp_uniform_ptr(p.A);
     const char* gW = rp_uniform_ptr(p.W);
-    auto issue_piece2 = [&](int stage, int slot, int i) __attribute__((always_inline)) {     // k group `stage` -> ring slot `slot`
-        const char* base = rp_uniform_ptr((i < 2 ? gA : gW) + (long)stage * 128);
-        rp_dma16(voff[i], base, __builtin_amdgcn_readfirstlane(lbase + (unsigned)slot * RP_STAGE + (unsigned)(wave + 8 * i) * 1024u));
+    auto issue_w = [&](int stage, int slot, int i) __attribute__((always_inline)) {          // W k group `stage` -> W slot
+        rp_dma16(voffw[i], rp_uniform_ptr(gW + (long)stage * 128),
+                 __builtin_amdgcn_readfirstlane(lbase + (unsigned)slot * RP_WSTAGE + (unsigned)(wave + 8 * i) * 1024u));
     };
-    auto issue_piece = [&](int stage, int i) __attribute__((always_inline)) { issue_piece2(stage, stage & 1, i); };
+    auto issue_a = [&](int stage, int slot, int i) __attribute__((always_inline)) {          // A k group `stage` -> A slot
+        rp_dma16(voffa[i], rp_uniform_ptr(gA + (long)stage * 128),
+                 __builtin_amdgcn_readfirstlane(lbase + RP_WRING + (unsigned)slot * RP_ASTAGE + (unsigned)(i ? pa1 : pa0) * 1024u));
+    };
 
     // ---- fragments: lane (r = lane & 15, q = lane >> 4) holds k = 8 q .. 8 q + 7 of row base + r: chunk q (hi) / 4 + q (lo)
     const int fr = lane & 15, fq = lane >> 4, fsw = (fr >> 1) & 7;
     const int f_hi = fr * 128 + 16 * (fq ^ fsw), f_lo = fr * 128 + 16 * ((4 + fq) ^ fsw);
-    auto frag_a = [&](int slot, int i, int off) __attribute__((always_inline)) { return *(const bf16x8*)(lds + slot * RP_STAGE + (16 * i) * 128 + off); };
-    auto frag_w = [&](int slot, int j, int off) __attribute__((always_inline)) {
-        return *(const bf16x8*)(lds + slot * RP_STAGE + (RP_AROWS + 48 * wave + 16 * j) * 128 + off);
+    auto frag_a = [&](int stage, int i, int off) __attribute__((always_inline)) {
+        return *(const bf16x8*)(lds + RP_WRING + (stage & (RP_ASLOTS - 1)) * RP_ASTAGE + (16 * i) * 128 + off);
+    };
+    auto frag_w = [&](int stage, int j, int off) __attribute__((always_inline)) {
+        return *(const bf16x8*)(lds + (stage & 1) * RP_WSTAGE + (48 * wave + 16 * j) * 128 + off);
     };
 
     f32x4v acc[RP_MF][3];
@@ -114,16 +126,39 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
-    // prologue: stages 0 and 1 in flight, stage 0 landed, its W fragments and the first two row fragments in registers
+    // prologue.  Inside a training step W is cold, and every CU walks through it in lockstep: each stage would be a first touch served at HBM
+    // latency (measured inside the step: fc2 + LN 123 us against 98 us on a warm W).  So first the CUs of an XCD (blockIdx & 7: round-robin
+    // dispatch - an assumption for speed only) touch one dword of every 128-byte line of W once, two lines per thread: the stages behind the
+    // first ones find their lines in that XCD's L2 (123 -> 105 us).  The loaded values are never used, but their registers stay reserved
+    // until the wait that covers them (the compiler does not know an asm load is in flight).
+    auto kcl = [&](int st) __attribute__((always_inline)) { return st < nk ? st : nk - 1; };
+    unsigned sink[RP_TOUCH];
+    {
+        const unsigned lpr = (unsigned)(p.K / 32);                             // 128-byte lines per W row
+        const unsigned lines = (unsigned)RP_N * lpr;
+        const unsigned t0 = (unsigned)(blockIdx.x >> 3) * 512u + (unsigned)tid;
+        const unsigned nthr = ((gridDim.x + 7u) >> 3) * 512u;
 #pragma unroll
-    for (int i = 0; i < RP_L; ++i) issue_piece(0, i);
-    if (nk > 1) {
-#pragma unroll
-        for (int i = 0; i < RP_L; ++i) issue_piece(1, i);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP_L) : "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int k = 0; k < RP_TOUCH; ++k) {
+            unsigned ln = t0 + (unsigned)k * nthr;
+            ln = ln < lines ? ln : lines - 1;
+            asm volatile("global_load_dword %0, %1, %2" : "=&v"(sink[k]) : "v"((ln / lpr) * (unsigned)(p.ldw * 2) + (ln % lpr) * 128u), "s"(gW));
+        }
     }
+    // W stages 0, 1 and A stages 0 .. 3 in flight (clamped to the last stage for very short K), stage 0 landed
+#pragma unroll
+    for (int i = 0; i < RP_LW; ++i) issue_w(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < RP_LA; ++i) issue_a(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < RP_LW; ++i) issue_w(kcl(1), 1, i);
+#pragma unroll
+    for (int st = 1; st < RP_ASLOTS; ++st)
+#pragma unroll
+        for (int i = 0; i < RP_LA; ++i) issue_a(kcl(st), st, i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP_LW + (RP_ASLOTS - 1) * RP_LA) : "memory");     // the touches, W(0), A(0) have completed
+#pragma unroll
+    for (int k = 0; k < RP_TOUCH; ++k) asm volatile("" ::"v"(sink[k]));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 wh[2][3], wl[2][3], ah[RP_MF], al[RP_MF];
@@ -140,14 +175,15 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
 
     // one stage; `side(slot index 0 .. 62)` runs behind every MFMA
     auto stage_body = [&](int s, bf16x8 (&wH)[3], bf16x8 (&wL)[3], bf16x8 (&wHn)[3], bf16x8 (&wLn)[3]) __attribute__((always_inline)) {
-        const int slot = s & 1, nslot = slot ^ 1;
-        // (past the end of K the refills repeat the last stage and the reads take the other slot: harmless, and no branches in the MFMA stream)
-        const int s2 = s + 2 < nk ? s + 2 : nk - 1;
+        // (past the end of K the refills repeat the last stage and the reads take whatever slot comes next: harmless, and no branches in the
+        // MFMA stream)
+        const int sw2 = kcl(s + 2), sa4 = kcl(s + RP_ASLOTS);
 #pragma unroll
         for (int i = 0; i < RP_MF; ++i) {
             if (i == 4) {
-                // every fragment of stage s is in registers (requested during row fragments 0 - 3), stage s + 1 has landed
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // every fragment of stage s is in registers (requested during row fragments 0 - 3); W(s + 1) - and everything older - must
+                // have landed: the only younger operations of this wave are its two pieces of A(s + 3)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP_LA) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -161,23 +197,24 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
                     // row fragments 2 .. 6 of this stage: one read every third MFMA (10 reads in 30 slots)
                     if (idx % 3 == 0 && idx / 3 < 10) {
                         const int k = idx / 3, fi = 2 + k / 2;
-                        if (k % 2 == 0) ah[fi] = frag_a(slot, fi, f_hi);
-                        else al[fi] = frag_a(slot, fi, f_lo);
+                        if (k % 2 == 0) ah[fi] = frag_a(s, fi, f_hi);
+                        else al[fi] = frag_a(s, fi, f_lo);
                     }
                 } else {
-                    // behind the barrier: this wave's pieces of stage s + 2 into the slot just freed (8, every third slot), then the W
-                    // fragments and row fragments 0, 1 of stage s + 1 (10 reads)
+                    // behind the barrier: this wave's pieces of W(s + 2) and then of A(s + 4) into the slots just freed (8, every third slot),
+                    // the W fragments and row fragments 0, 1 of stage s + 1 (10 reads)
                     const int u = idx - 36;                                  // 0 .. 26
-                    if (u % 3 == 0 && u / 3 < RP_L) {
-                        issue_piece2(s2, slot, u / 3);
+                    if (u % 3 == 0 && u / 3 < RP_LW + RP_LA) {
+                        if (u / 3 < RP_LW) issue_w(sw2, s & 1, u / 3);
+                        else issue_a(sa4, s & (RP_ASLOTS - 1), u / 3 - RP_LW);
                     } else if (u % 3 == 1 && u / 3 < 6) {
                         const int k = u / 3;
-                        if (k < 3) wHn[k] = frag_w(nslot, k, f_hi);
-                        else wLn[k - 3] = frag_w(nslot, k - 3, f_lo);
+                        if (k < 3) wHn[k] = frag_w(s + 1, k, f_hi);
+                        else wLn[k - 3] = frag_w(s + 1, k - 3, f_lo);
                     } else if (u % 3 == 2 && u / 3 < 4) {
                         const int k = u / 3;
-                        if (k < 2) ah[k] = frag_a(nslot, k, f_hi);
-                        else al[k - 2] = frag_a(nslot, k - 2, f_lo);
+                        if (k < 2) ah[k] = frag_a(s + 1, k, f_hi);
+                        else al[k - 2] = frag_a(s + 1, k - 2, f_lo);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -196,10 +233,20 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
     // A rows, clamped residual rows): they are stored to that row's address again - identical duplicates, no branches
     float* red = (float*)(lds + RP_RING);                              // [8 waves][RP_TH]
     float* red2 = red + 8 * RP_TH;
-    const int ncol0 = 48 * wave + 4 * fq;                              // + 16 j + r
-    auto row_of = [&](int i) __attribute__((always_inline)) {
-        const int r = 16 * i + fr;
-        return m0 + (r < rows ? r : rows - 1);
+    // (the epilogue's lane-derived values are re-derived from a laundered lane id at the start of every phase: otherwise the compiler
+    // computes the addresses of ALL phases up front and carries them - in scratch - across the reductions)
+    int lanee = lane;
+    int fre = fr, fqe = fq, ncol0 = 48 * wave + 4 * fq;                // ncol0 + 16 j + r = this lane's column
+    auto fresh_lane = [&]() __attribute__((always_inline)) {
+        asm volatile("" : "+v"(lanee));
+        fre = lanee & 15;
+        fqe = lanee >> 4;
+        ncol0 = 48 * wave + 4 * fqe;
+    };
+    int m0e = m0;                                                      // laundered before every epilogue phase: fresh row arithmetic instead of
+    auto row_of = [&](int i) __attribute__((always_inline)) {          // dozens of 64-bit row addresses carried (in scratch) across the reductions
+        const int r = 16 * i + fre;
+        return m0e + (r < rows ? r : rows - 1);
     };
     // per-row totals over the 384 columns of `part[i]` (this lane's partial over its 12 values): all 512 threads call it
     auto row_total = [&](float (&part)[RP_MF], float* buf) __attribute__((always_inline)) {
@@ -208,20 +255,48 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
             float v = part[i];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (fq == 0) buf[wave * RP_TH + 16 * i + fr] = v;
+            if (fqe == 0) buf[wave * RP_TH + 16 * i + fre] = v;
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < RP_MF; ++i) {
             float t = 0.f;
 #pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) t += buf[w8 * RP_TH + 16 * i + fr];
+            for (int w8 = 0; w8 < 8; ++w8) t += buf[w8 * RP_TH + 16 * i + fre];
             part[i] = t;
+        }
+    };
+    // the same for two partials at once (one barrier)
+    auto row_total2 = [&](float (&pa)[RP_MF], float (&pb)[RP_MF]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < RP_MF; ++i) {
+            float a = pa[i], b = pb[i];
+            a += __shfl_xor(a, 16, 64);
+            b += __shfl_xor(b, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 32, 64);
+            if (fqe == 0) {
+                red[wave * RP_TH + 16 * i + fre] = a;
+                red2[wave * RP_TH + 16 * i + fre] = b;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RP_MF; ++i) {
+            float ta = 0.f, tb = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) {
+                ta += red[w8 * RP_TH + 16 * i + fre];
+                tb += red2[w8 * RP_TH + 16 * i + fre];
+            }
+            pa[i] = ta;
+            pb[i] = tb;
         }
     };
     // split output tile rows [16 i0, 16 i1) of this workgroup -> out (storage ld `ldo`), through LDS (ring region) as whole lines
     auto store_split = [&](void* out, long ldo, int i0, int i1) __attribute__((always_inline)) {
         char* ybuf = lds;
+        fresh_lane();
 #pragma unroll
         for (int i = 0; i < RP_MF; ++i) {
             if (i < i0 || i >= i1) continue;
@@ -234,7 +309,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
                 bf16x4 hv, lv;
                 hv[0] = h0; hv[1] = h1; hv[2] = h2; hv[3] = h3;
                 lv[0] = l0; lv[1] = l1; lv[2] = l2; lv[3] = l3;
-                char* rowp = ybuf + (16 * (i - i0) + fr) * RP_YP + 128 * (n >> 5) + 2 * (n & 31);
+                char* rowp = ybuf + (16 * (i - i0) + fre) * RP_YP + 128 * (n >> 5) + 2 * (n & 31);
                 *(stg_b4*)rowp = hv;
                 *(stg_b4*)(rowp + 64) = lv;
             }
@@ -254,17 +329,18 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
     if constexpr (REPI == REPI_RES_LN) {
         const float invN = 1.0f / (float)RP_N;
         float part[RP_MF];
+        fresh_lane();
         // v = acc + bias + residual
 #pragma unroll
         for (int i = 0; i < RP_MF; ++i) {
-            const long m = row_of(i);
+            const unsigned m = (unsigned)row_of(i);
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int n = ncol0 + 16 * j;
                 f32x4v b = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias) b = *(const f32x4v*)(p.bias + n);
-                if (p.res) rv = *(const f32x4v*)(p.res + m * p.ldres + n);
+                if (p.res) rv = *(const f32x4v*)(p.res + m * (unsigned)p.ldres + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc[i][j][r] += b[r] + rv[r];
@@ -289,27 +365,146 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
             part[i] = s;
         }
         row_total(part, red2);
+        asm volatile("" : "+s"(m0e));
+        fresh_lane();
         float* xo = (float*)p.out0;
 #pragma unroll
         for (int i = 0; i < RP_MF; ++i) {
-            const long m = row_of(i);
+            const unsigned m = (unsigned)row_of(i);
             const float rs = rsqrtf(part[i] * invN + p.eps);
-            if (wave == 0 && fq == 0 && p.mean) {
+            if (wave == 0 && fqe == 0 && p.mean) {
                 p.mean[m] = mu[i];
                 p.rstd[m] = rs;
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int n = ncol0 + 16 * j;
-                if (xo) *(f32x4v*)(xo + m * p.ldo0 + n) = acc[i][j];
+                if (xo) *(f32x4v*)(xo + m * (unsigned)p.ldo0 + n) = acc[i][j];
                 const f32x4v g = *(const f32x4v*)(p.gamma + n), be = *(const f32x4v*)(p.beta + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] - mu[i]) * rs * g[r] + be[r];
-                if (p.y_f32) *(f32x4v*)((float*)p.out1 + m * p.ldo1 + n) = acc[i][j];
+                if (p.y_f32) *(f32x4v*)((float*)p.out1 + m * (unsigned)p.ldo1 + n) = acc[i][j];
             }
         }
         if (!p.y_f32) {
             __syncthreads();                                           // (red / red2 live outside the ring; the ring itself is free)
+            store_split(p.out1, p.ldo1, 0, 4);
+            store_split(p.out1, p.ldo1, 4, RP_MF);
+        }
+    }
+
+    if constexpr (REPI == REPI_LNBWD_RES) {
+        // acc = dL/dy (y = LayerNorm output); aux = the saved LayerNorm input x (f32), mean / rstd its row statistics:
+        //   h = (x - mu) rs,  g = dy gamma,  dx = rs (g - mean_n(g) - h mean_n(g h)) + residual gradient
+        //   column sums over the VALID rows: dgamma += dy h, dbeta += dy, dcol += dx
+        // Register plan (256): acc 84 + the column sums; h is recomputed in the second phase from a second read of x (this CU fetched those
+        // 152 KB a moment ago: L2 / Infinity Cache) - kept in 84 registers beside the accumulators it spilled 70 - 150 of them; the dgamma /
+        // dbeta sums leave before the second phase starts, gamma and rstd are read again where they are used.
+        const float invN = 1.0f / (float)RP_N;
+        const float* __restrict__ xin = (const float*)p.aux;
+        const float* __restrict__ gamp = p.gamma;
+        float s1[RP_MF], s2[RP_MF];
+        // one column quantity: sum over the 16 row lanes, then out (a column belongs to exactly one wave)
+        auto col_out = [&](float (&cv)[3][4], int q, float* dst) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) cv[j][r] += __shfl_xor(cv[j][r], o, 64);
+                }
+            if (fre != 0) return;
+            if (p.cpart) {
+                float* cp = p.cpart + ((long)blockIdx.x * 3 + q) * RP_N + ncol0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    f32x4v v4 = {cv[j][0], cv[j][1], cv[j][2], cv[j][3]};
+                    *(f32x4v*)(cp + 16 * j) = v4;
+                }
+            } else if (dst) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(dst + ncol0 + 16 * j + r, cv[j][r]);
+            }
+        };
+        fresh_lane();
+        {
+            float cg[3][4], cb[3][4];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cg[j][r] = cb[j][r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < RP_MF; ++i) {
+                const unsigned m = (unsigned)row_of(i);
+                const bool ok = 16 * i + fre < rows;
+                const float mu = p.mean[m], rs = p.rstd[m];
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const f32x4v xv = *(const f32x4v*)(xin + m * (unsigned)p.ldaux + ncol0 + 16 * j);
+                    const f32x4v gm = *(const f32x4v*)(gamp + ncol0 + 16 * j);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float h = (xv[r] - mu) * rs, dy = acc[i][j][r], g = dy * gm[r];
+                        a1 += g;
+                        a2 += g * h;
+                        cg[j][r] += ok ? dy * h : 0.f;
+                        cb[j][r] += ok ? dy : 0.f;
+                    }
+                }
+                s1[i] = a1;
+                s2[i] = a2;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            col_out(cg, 0, p.cs0);
+            col_out(cb, 1, p.cs1);
+        }
+        row_total2(s1, s2);
+        float* dxo = (float*)p.out0;
+        const bf16* __restrict__ rest = (const bf16*)p.res_t;
+        float cx[3][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cx[j][r] = 0.f;
+        const float* gam2 = gamp;
+        const float* xin2 = xin;
+        asm volatile("" : "+s"(gam2), "+s"(xin2), "+s"(m0e));
+        fresh_lane();                     // (fresh reads of gamma and x: nothing carried across the reduction)
+#pragma unroll
+        for (int i = 0; i < RP_MF; ++i) {
+            const unsigned m = (unsigned)row_of(i);
+            const bool ok = 16 * i + fre < rows;
+            const float c1 = s1[i] * invN, c2 = s2[i] * invN, rs = p.rstd[m], mu = p.mean[m];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int n = ncol0 + 16 * j;
+                const f32x4v gm = *(const f32x4v*)(gam2 + n);
+                f32x4v rv = {0.f, 0.f, 0.f, 0.f};
+                if (p.res) {
+                    rv = *(const f32x4v*)(p.res + m * (unsigned)p.ldres + n);
+                } else if (rest) {                                      // residual gradient in the operand type: hi + lo
+                    const bf16* rp2 = rest + m * (unsigned)p.ldres_t + 64 * (n >> 5) + (n & 31);
+                    const bf16x4 hv = *(const bf16x4*)rp2, lv = *(const bf16x4*)(rp2 + 32);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rv[r] = (float)hv[r] + (float)lv[r];
+                }
+                const f32x4v xv = *(const f32x4v*)(xin2 + m * (unsigned)p.ldaux + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dx = rs * (acc[i][j][r] * gm[r] - c1 - (xv[r] - mu) * rs * c2) + rv[r];
+                    acc[i][j][r] = dx;
+                    cx[j][r] += ok ? dx : 0.f;
+                }
+                if (dxo) *(f32x4v*)(dxo + m * (unsigned)p.ldo0 + n) = acc[i][j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        col_out(cx, 2, p.cs2);
+        if (p.out1) {
+            __syncthreads();
             store_split(p.out1, p.ldo1, 0, 4);
             store_split(p.out1, p.ldo1, 4, RP_MF);
         }
@@ -356,9 +551,17 @@ int rowp_mode() {   // MFVIT_ROWP: 0 off, 1 (default) on.  Read at every launch 
 
 bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
     if (dtype != MFVIT_BF16X3 || rowp_mode() == 0) return false;
-    if (repi != REPI_RES_LN) return false;
+    if (repi != REPI_RES_LN && repi != REPI_LNBWD_RES) return false;
     if (p.N != RP_N || p.K % 32 || p.K < 64 || p.M < 4096 || p.nb > 1) return false;
     if (p.orow_in || p.res_mod || p.rows_per_wg) return false;                  // patch-embedding row remap stays with gemm_nt_row
+    if (repi == REPI_LNBWD_RES) {
+        if (!p.aux || !p.mean || !p.rstd || !p.gamma || p.ldaux % 4 || (size_t)p.aux % 16 || (size_t)p.gamma % 16) return false;
+        if ((p.out0 && (p.ldo0 % 4 || (size_t)p.out0 % 16)) || (p.out1 && (p.ldo1 % 8 || (size_t)p.out1 % 16))) return false;
+        if ((p.res && (p.ldres % 4 || (size_t)p.res % 16)) || (p.res_t && (p.ldres_t % 8 || (size_t)p.res_t % 16))) return false;
+        if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 32) || (unsigned long long)p.N * p.ldw * 2 >= (1ull << 32)) return false;
+        if (p.lda % 8 || p.ldw % 8 || (size_t)p.A % 16 || (size_t)p.W % 16) return false;
+        return true;
+    }
     if (!p.out1 || !p.gamma || !p.beta) return false;
     if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 32) || (unsigned long long)p.N * p.ldw * 2 >= (1ull << 32)) return false;
     if (p.lda % 8 || p.ldw % 8 || (p.out0 && p.ldo0 % 4) || p.ldo1 % (p.y_f32 ? 4 : 8) || (p.res && p.ldres % 4)) return false;
@@ -370,6 +573,12 @@ bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
 
 int gemm_nt_rowp(int repi, const GemmP& p, hipStream_t st) {
     if (repi == REPI_RES_LN) return launch_rowp<REPI_RES_LN>(p, st);
+    if (repi == REPI_LNBWD_RES) {
+        const int rc = launch_rowp<REPI_LNBWD_RES>(p, st);
+        if (rc != MFVIT_OK || !p.cpart) return rc;
+        const int rpt = rp_rows_per_tile(p.M);
+        return colpart_reduce(p.cpart, (p.M + rpt - 1) / rpt, RP_N, 3, p.cs0, p.cs1, p.cs2, st);   // [tile][3][384] partials -> dgamma, dbeta, dcol
+    }
     return MFVIT_EINVAL;
 }
 

@@ -61,5 +61,33 @@ for M, tag in [(128 * 197, "full"), (128 * 197 - 57, "ragged"), (4096 + 40, "sma
             if tag == "full":
                 line += f" | row {timeit(0, fn):7.1f} us  rowp {timeit(1, fn):7.1f} us"
             print(line, flush=True)
+# ---- LayerNorm-backward row kernel: dx = LNbwd(dy @ wt.T; x) + dres, dgamma, dbeta, dcol
+for M, tag in [(128 * 197, "full"), (128 * 197 - 57, "ragged"), (4096 + 40, "small")][: 1 if quick else 3]:
+    for K, name in ((3 * D, "qkvd+LNb"), (4 * D, "fc1d+LNb")):
+        dy32, wt32 = torch.randn(M, K, device=dev) * .1, torch.randn(D, K, device=dev) * .05
+        dy, wt = sp(dy32), sp(wt32)
+        x = torch.randn(M, D, device=dev) * 1.5 + .3
+        mean = x.mean(1)
+        rstd = 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-6)
+        g = torch.rand(D, device=dev) + .5
+        dres = torch.randn(M, D, device=dev) * .1
+        d64 = ops.split_unpack(dy).double() @ ops.split_unpack(wt).double().T
+        h = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
+        gg = d64 * g.double()
+        dx64 = rstd.double()[:, None] * (gg - gg.mean(1, keepdim=True) - h * (gg * h).mean(1, keepdim=True)) + dres.double()
+        dg64, db64, dc64 = (d64 * h).sum(0), d64.sum(0), dx64.sum(0)
+        fn = lambda: ops.linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, g, dres, split=True)
+        line = f"M={M:6d} {tag:6s} {name:8s}"
+        for mode in (0, 1):
+            os.environ["MFVIT_ROWP"] = str(mode)
+            dx, dxt, dgm, dbt, dcl = fn()
+            torch.cuda.synchronize()
+            e = [rel(dx, dx64), rel(ops.split_unpack(dxt), dx64), rel(dgm, dg64), rel(dbt, db64), rel(dcl, dc64)]
+            good = max(e[:2]) < 3e-5 and max(e[2:]) < 2e-4
+            ok &= good
+            line += f" | {'rowp' if mode else 'row '}: dx {e[0]:.1e} dxT {e[1]:.1e} dgamma {e[2]:.1e} dbeta {e[3]:.1e} dcol {e[4]:.1e}{'' if good else ' BAD'}"
+        if tag == "full":
+            line += f" | row {timeit(0, fn):7.1f} us  rowp {timeit(1, fn):7.1f} us"
+        print(line, flush=True)
 print("ALL OK" if ok else "MISMATCH", flush=True)
 sys.exit(0 if ok else 1)
