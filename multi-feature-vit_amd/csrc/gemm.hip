@@ -1138,6 +1138,7 @@ template <int REPI> static int row_by_dtype(int dtype, const GemmP& p, hipStream
 static int tn_by_dtype(int dtype, const GemmP& p, hipStream_t st) { MFVIT_BY_DTYPE(dtype, (launch_tn<TT>(p, st))) }
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
+    if (gemm_nt_rowt_supported(dtype, epi, p)) return gemm_nt_rowt(epi, p, st);
     if (gemm_nt_pp_supported(dtype, epi, p)) return gemm_nt_pp(epi, p, st);
     if (gemm_nt_ws_supported(dtype, epi, p)) return gemm_nt_ws(epi, p, st);
     if (gemm_nt_pers_supported(dtype, epi, p)) return gemm_nt_pers(dtype, epi, p, st);

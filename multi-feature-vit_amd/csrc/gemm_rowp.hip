@@ -71,8 +71,14 @@ __device__ __forceinline__ void rp_dma16(unsigned voff, const char* sbase, unsig
                  : "memory");
 }
 
-template <int REPI>
-__global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
+// MODE: the two row-complete epilogues (REPI_RES_LN = 0, REPI_LNBWD_RES = 1; N = 384, one pass) or RP_TILE + EPI_* : the plain linears
+// (qkv, fc1 + GELU, fc2-dgrad * gelu', proj-dgrad) as `npass` passes of 384 columns over the same tile rows - the stage stream runs
+// on across the passes (no fill bubble), the outputs of pass p leave while the MFMAs of pass p + 1 run
+constexpr int RP_TILE = 10;
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int npass) {
+    constexpr int REPI = MODE < RP_TILE ? MODE : -1;
+    constexpr int EPI = MODE >= RP_TILE ? MODE - RP_TILE : -1;
     typedef sbf16 T;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -99,8 +105,9 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
     }
     const char* gA = rp_uniform_ptr(p.A);
     const char* gW = rp_uniform_ptr(p.W);
-    auto issue_w = [&](int stage, int slot, int i) __attribute__((always_inline)) {          // W k group `stage` -> W slot
-        rp_dma16(voffw[i], rp_uniform_ptr(gW + (long)stage * 128),
+    const long wpass = (long)RP_N * p.ldw * 2;                         // bytes between the W rows of two passes
+    auto issue_w = [&](int pass, int stage, int slot, int i) __attribute__((always_inline)) {   // W rows of `pass`, k group `stage` -> W slot
+        rp_dma16(voffw[i], rp_uniform_ptr(gW + pass * wpass + (long)stage * 128),
                  __builtin_amdgcn_readfirstlane(lbase + (unsigned)slot * RP_WSTAGE + (unsigned)(wave + 8 * i) * 1024u));
     };
     auto issue_a = [&](int stage, int slot, int i) __attribute__((always_inline)) {          // A k group `stage` -> A slot
@@ -131,11 +138,17 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
     // dispatch - an assumption for speed only) touch one dword of every 128-byte line of W once, two lines per thread: the stages behind the
     // first ones find their lines in that XCD's L2 (123 -> 105 us).  The loaded values are never used, but their registers stay reserved
     // until the wait that covers them (the compiler does not know an asm load is in flight).
-    auto kcl = [&](int st) __attribute__((always_inline)) { return st < nk ? st : nk - 1; };
+    const int G = npass * nk;                                          // stages of the whole tile
+    float* sbias = (float*)(lds + RP_RING);                            // tile modes: the bias vector (N <= 2048 floats)
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
+        // before any LDS-DMA is in flight (the compiler's own wait for these loads would otherwise drain the ring)
+        for (int n = tid; n < p.N; n += 512) sbias[n] = p.bias ? p.bias[n] : 0.f;
+        __syncthreads();
+    }
     unsigned sink[RP_TOUCH];
     {
         const unsigned lpr = (unsigned)(p.K / 32);                             // 128-byte lines per W row
-        const unsigned lines = (unsigned)RP_N * lpr;
+        const unsigned lines = (unsigned)p.N * lpr;                            // all passes
         const unsigned t0 = (unsigned)(blockIdx.x >> 3) * 512u + (unsigned)tid;
         const unsigned nthr = ((gridDim.x + 7u) >> 3) * 512u;
 #pragma unroll
@@ -146,16 +159,17 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
         }
     }
     // W stages 0, 1 and A stages 0 .. 3 in flight (clamped to the last stage for very short K), stage 0 landed
+    // (requires nk >= 4: checked by the launcher)
 #pragma unroll
-    for (int i = 0; i < RP_LW; ++i) issue_w(0, 0, i);
+    for (int i = 0; i < RP_LW; ++i) issue_w(0, 0, 0, i);
 #pragma unroll
     for (int i = 0; i < RP_LA; ++i) issue_a(0, 0, i);
 #pragma unroll
-    for (int i = 0; i < RP_LW; ++i) issue_w(kcl(1), 1, i);
+    for (int i = 0; i < RP_LW; ++i) issue_w(0, 1, 1, i);
 #pragma unroll
     for (int st = 1; st < RP_ASLOTS; ++st)
 #pragma unroll
-        for (int i = 0; i < RP_LA; ++i) issue_a(kcl(st), st, i);
+        for (int i = 0; i < RP_LA; ++i) issue_a(st, st, i);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP_LW + (RP_ASLOTS - 1) * RP_LA) : "memory");     // the touches, W(0), A(0) have completed
 #pragma unroll
     for (int k = 0; k < RP_TOUCH; ++k) asm volatile("" ::"v"(sink[k]));
@@ -174,10 +188,16 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
     }
 
     // one stage; `side(slot index 0 .. 62)` runs behind every MFMA
+    // lookahead of the two streams: W is at stage s + 2 = (wp, wk), A at stage s + 4 = k group ak (the same rows in every pass); past the end
+    // of the tile both repeat its last stage (harmless refills of free slots: no branches in the MFMA stream)
+    int wp = nk > 2 ? 0 : 1, wk = nk > 2 ? 2 : 2 - nk, ak = RP_ASLOTS % nk;
+    if (wp >= npass) { wp = npass - 1; wk = nk - 1; }
+    auto advance_streams = [&]() __attribute__((always_inline)) {
+        if (++wk == nk) { wk = 0; ++wp; }
+        if (wp >= npass) { wp = npass - 1; wk = nk - 1; }
+        if (++ak == nk) ak = 0;
+    };
     auto stage_body = [&](int s, bf16x8 (&wH)[3], bf16x8 (&wL)[3], bf16x8 (&wHn)[3], bf16x8 (&wLn)[3]) __attribute__((always_inline)) {
-        // (past the end of K the refills repeat the last stage and the reads take whatever slot comes next: harmless, and no branches in the
-        // MFMA stream)
-        const int sw2 = kcl(s + 2), sa4 = kcl(s + RP_ASLOTS);
 #pragma unroll
         for (int i = 0; i < RP_MF; ++i) {
             if (i == 4) {
@@ -205,8 +225,8 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
                     // the W fragments and row fragments 0, 1 of stage s + 1 (10 reads)
                     const int u = idx - 36;                                  // 0 .. 26
                     if (u % 3 == 0 && u / 3 < RP_LW + RP_LA) {
-                        if (u / 3 < RP_LW) issue_w(sw2, s & 1, u / 3);
-                        else issue_a(sa4, s & (RP_ASLOTS - 1), u / 3 - RP_LW);
+                        if (u / 3 < RP_LW) issue_w(wp, wk, s & 1, u / 3);
+                        else issue_a(ak, s & (RP_ASLOTS - 1), u / 3 - RP_LW);
                     } else if (u % 3 == 1 && u / 3 < 6) {
                         const int k = u / 3;
                         if (k < 3) wHn[k] = frag_w(s + 1, k, f_hi);
@@ -221,18 +241,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
             }
         }
     };
-    for (int s = 0; s < nk; s += 2) {
-        stage_body(s, wh[0], wl[0], wh[1], wl[1]);
-        if (s + 1 < nk) stage_body(s + 1, wh[1], wl[1], wh[0], wl[0]);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                                   // the ring is free: epilogue scratch
-
-    // ------------------------------------------------------------------------------------------------ epilogues
-    // acc[i][j][r] = out[m0 + 16 i + fr][48 wave + 16 j + 4 fq + r]; rows past `rows` replicate the tile's last valid row exactly (clamped
-    // A rows, clamped residual rows): they are stored to that row's address again - identical duplicates, no branches
-    float* red = (float*)(lds + RP_RING);                              // [8 waves][RP_TH]
-    float* red2 = red + 8 * RP_TH;
     // (the epilogue's lane-derived values are re-derived from a laundered lane id at the start of every phase: otherwise the compiler
     // computes the addresses of ALL phases up front and carries them - in scratch - across the reductions)
     int lanee = lane;
@@ -248,6 +256,93 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt) {
         const int r = 16 * i + fre;
         return m0e + (r < rows ? r : rows - 1);
     };
+
+    // ---- tile modes: the outputs of one pass (columns 384 pass .. + 383), straight from the accumulators: a lane owns 4 consecutive columns
+    // of a row, i.e. 8 bytes of the hi part and 8 of the lo part of one line (written whole by 4 lanes x 2 tiles x 2 parts; no LDS staging:
+    // the ring is busy with the next pass).  Then the accumulators start again from zero.
+    auto tile_epilogue = [&](int pass) __attribute__((always_inline)) {
+        if constexpr (EPI >= 0) {
+            typedef typename act_grad_type<T>::type AX;
+            asm volatile("" : "+s"(m0e));
+            fresh_lane();
+            const bool want_grad = EPI == EPI_BIAS_GELU && p.out0 != nullptr;
+#pragma unroll
+            for (int i = 0; i < RP_MF; ++i) {
+                const unsigned m = (unsigned)row_of(i);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int n = pass * RP_N + ncol0 + 16 * j;        // logical column of acc[i][j][0]; n .. n + 3 inside one 32-group
+                    float v[4], d[4];
+                    f32x4v b4 = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) b4 = *(const f32x4v*)(sbias + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + b4[r];
+                    if constexpr (EPI == EPI_GELU_BWD) {
+                        const f16x4 a4 = *(const f16x4*)((const f16*)p.aux + m * (unsigned)p.ldaux + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] *= (float)a4[r];
+                    }
+                    if constexpr (EPI == EPI_BIAS_GELU) {
+                        if (want_grad) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) gelu_both_t<T>(v[r], v[r], d[r]);
+                            f16 a0, a1, a2, a3, u0, u1;
+                            cvt_pair<f16, false>(d[0], d[1], a0, a1, u0, u1);
+                            cvt_pair<f16, false>(d[2], d[3], a2, a3, u0, u1);
+                            f16x4 dv;
+                            dv[0] = a0; dv[1] = a1; dv[2] = a2; dv[3] = a3;
+                            *(f16x4*)((AX*)p.out0 + m * (unsigned)p.ldo0 + n) = dv;
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_t<T>(v[r]);
+                        }
+                    }
+                    bf16 h0, h1, h2, h3, l0, l1, l2, l3;
+                    cvt_pair<bf16, true>(v[0], v[1], h0, h1, l0, l1);
+                    cvt_pair<bf16, true>(v[2], v[3], h2, h3, l2, l3);
+                    bf16x4 hv, lv;
+                    hv[0] = h0; hv[1] = h1; hv[2] = h2; hv[3] = h3;
+                    lv[0] = l0; lv[1] = l1; lv[2] = l2; lv[3] = l3;
+                    void* outp = EPI == EPI_BIAS_GELU ? p.out1 : p.out0;
+                    const unsigned ldo = (unsigned)(EPI == EPI_BIAS_GELU ? p.ldo1 : p.ldo0);
+                    bf16* op = (bf16*)outp + m * ldo + 64 * (n >> 5) + (n & 31);
+                    if (p.rows_per_wg == 77) {                         // (timing experiment MFVIT_ROWT_NOSTORE=1: results invalid)
+                        asm volatile("" ::"v"(hv), "v"(lv));
+                    } else {
+                        *(bf16x4*)op = hv;
+                        *(bf16x4*)(op + 32) = lv;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    {
+        int kt = 0, pass = 0;
+        for (int g = 0; g < G; g += 2) {
+            stage_body(g, wh[0], wl[0], wh[1], wl[1]);
+            advance_streams();
+            stage_body(g + 1, wh[1], wl[1], wh[0], wl[0]);             // (nk is even: checked by the launcher)
+            advance_streams();
+            kt += 2;
+            if (kt == nk) {
+                kt = 0;
+                if constexpr (EPI >= 0) tile_epilogue(pass);
+                ++pass;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                                   // the ring is free: epilogue scratch
+
+    // ------------------------------------------------------------------------------------------------ epilogues
+    // acc[i][j][r] = out[m0 + 16 i + fr][48 wave + 16 j + 4 fq + r]; rows past `rows` replicate the tile's last valid row exactly (clamped
+    // A rows, clamped residual rows): they are stored to that row's address again - identical duplicates, no branches
+    float* red = (float*)(lds + RP_RING);                              // [8 waves][RP_TH]
+    float* red2 = red + 8 * RP_TH;
     // per-row totals over the 384 columns of `part[i]` (this lane's partial over its 12 values): all 512 threads call it
     auto row_total = [&](float (&part)[RP_MF], float* buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -528,21 +623,27 @@ int rp_rows_per_tile(int M) {
     return (M + cus * rounds - 1) / (cus * rounds);
 }
 
-template <int REPI> int launch_rowp(const GemmP& p, hipStream_t st) {
+template <int MODE> int launch_rowp(const GemmP& p, hipStream_t st) {
     const int rpt = rp_rows_per_tile(p.M);
     const int grid = (p.M + rpt - 1) / rpt;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_rowp_kernel<REPI>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_rowp_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
         attr = true;
     }
-    ProfScope ps(REPI == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
-    MFVIT_LAUNCH((gemm_rowp_kernel<REPI>), dim3(grid), dim3(512), RP_LDS, st, p, rpt);
+    ProfScope ps(MODE >= RP_TILE ? PROF_GEMM_TILE : (MODE == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD), 2.0 * p.M * p.N * p.K, 0, st);
+    GemmP q = p;
+    if (MODE >= RP_TILE) { const char* e = getenv("MFVIT_ROWT_NOSTORE"); q.rows_per_wg = (e && atoi(e)) ? 77 : 0; }
+    MFVIT_LAUNCH((gemm_rowp_kernel<MODE>), dim3(grid), dim3(512), RP_LDS, st, q, rpt, p.N / RP_N);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
 
-int rowp_mode() {   // MFVIT_ROWP: 0 off, 1 (default) on.  Read at every launch (A/B runs in one process)
+// MFVIT_ROWP: 0 off, 1 (default) the forward epilogue (+ bias + residual -> LayerNorm), 2 the LayerNorm-backward epilogue as well.  Read at
+// every launch (A/B runs in one process).  Measured inside the training step (serialized pass, rocprofv3 kernel durations, M = 25,216):
+// forward proj + LN 56 -> 54 us, fc2 + LN 140 -> 105 us; backward fc1-dgrad 139 -> 137 us, qkv-dgrad 112 -> 119 us (its epilogue reads x twice
+// and spills ~40 registers beside 84 accumulators): the backward stays with gemm_nt_row until that is fixed.
+int rowp_mode() {
     const char* e = getenv("MFVIT_ROWP");
     return e ? atoi(e) : 1;
 }
@@ -552,7 +653,8 @@ int rowp_mode() {   // MFVIT_ROWP: 0 off, 1 (default) on.  Read at every launch 
 bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
     if (dtype != MFVIT_BF16X3 || rowp_mode() == 0) return false;
     if (repi != REPI_RES_LN && repi != REPI_LNBWD_RES) return false;
-    if (p.N != RP_N || p.K % 32 || p.K < 64 || p.M < 4096 || p.nb > 1) return false;
+    if (repi == REPI_LNBWD_RES && rowp_mode() < 2) return false;
+    if (p.N != RP_N || p.K % 64 || p.K < 128 || p.M < 4096 || p.nb > 1) return false;   // (an even number of stages, at least 4)
     if (p.orow_in || p.res_mod || p.rows_per_wg) return false;                  // patch-embedding row remap stays with gemm_nt_row
     if (repi == REPI_LNBWD_RES) {
         if (!p.aux || !p.mean || !p.rstd || !p.gamma || p.ldaux % 4 || (size_t)p.aux % 16 || (size_t)p.gamma % 16) return false;
@@ -569,6 +671,34 @@ bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
         (p.bias && (size_t)p.bias % 16) || (size_t)p.gamma % 16 || (size_t)p.beta % 16)
         return false;
     return true;
+}
+
+// The plain linears on the same kernel.  OPT-IN (MFVIT_ROWT=1; read at every launch): measured (tools/rowt_check.py, M = 25,216) qkv 107 - 119 us
+// against 79 - 85 us of the 128x128 kernel, fc1 + GELU 144 - 152 vs 135 - 142, fc2-dgrad 143 - 146 vs 122, proj-dgrad 32.8 vs 34.7.  With the output
+// stores switched off (MFVIT_ROWT_NOSTORE=1) the same launches take 82 / 123 / 99 / 23 us: the 8-byte-per-lane partial-line stores of this
+// accumulator layout cost 20 - 45 us per launch (the LDS is full: no staging into whole lines), and even without them the three-pass qkv only
+// ties the tile kernel - outputs of 116 - 232 MB per launch keep these linears on the HBM side of the ridge.
+bool gemm_nt_rowt_supported(int dtype, int epi, const GemmP& p) {
+    const char* e = getenv("MFVIT_ROWT");
+    if (dtype != MFVIT_BF16X3 || !(e && atoi(e) != 0)) return false;
+    if (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_GELU_BWD && epi != EPI_NONE) return false;
+    if (p.N % RP_N || p.N > 2048 || p.K % 64 || p.K < 128 || p.M < 4096 || p.nb > 1) return false;
+    if (epi == EPI_GELU_BWD && (p.cs0 || !p.aux || p.ldaux % 4 || (size_t)p.aux % 8)) return false;   // column sums stay with the 128x128 kernel
+    if (epi == EPI_BIAS_GELU && (!p.out1 || p.ldo1 % 8 || (size_t)p.out1 % 16 || (p.out0 && (p.ldo0 % 4 || (size_t)p.out0 % 8)))) return false;
+    if (epi != EPI_BIAS_GELU && (!p.out0 || p.ldo0 % 8 || (size_t)p.out0 % 16)) return false;
+    if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 32) || (unsigned long long)p.N * p.ldw * 2 >= (1ull << 32)) return false;
+    if ((unsigned long long)p.M * (p.ldo0 > p.ldo1 ? p.ldo0 : p.ldo1) * 2 >= (1ull << 32)) return false;      // 32-bit element offsets
+    if (p.lda % 8 || p.ldw % 8 || (size_t)p.A % 16 || (size_t)p.W % 16) return false;
+    return true;
+}
+int gemm_nt_rowt(int epi, const GemmP& p, hipStream_t st) {
+    switch (epi) {
+        case EPI_BIAS: return launch_rowp<RP_TILE + EPI_BIAS>(p, st);
+        case EPI_BIAS_GELU: return launch_rowp<RP_TILE + EPI_BIAS_GELU>(p, st);
+        case EPI_GELU_BWD: return launch_rowp<RP_TILE + EPI_GELU_BWD>(p, st);
+        case EPI_NONE: return launch_rowp<RP_TILE + EPI_NONE>(p, st);
+    }
+    return MFVIT_EINVAL;
 }
 
 int gemm_nt_rowp(int repi, const GemmP& p, hipStream_t st) {
