@@ -287,14 +287,22 @@ class CaRun:
         self.x = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
         self.xe = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
         self.target = torch.randint(0, 3, (B,), generator=g).to(dev)
-        params = list(self.model.parameters())
+        # one param group per gradient exchange: the fusion arena + classifier heads (flat synchronous exchange after backward), then
+        # each encoder arena (asynchronous per-bucket exchange from its backward hooks) - the optimizer joins an encoder's buckets just
+        # before that group's kernel is queued, so the update of what has arrived overlaps what is still on the links
+        self.small = list(self.model.parameters()) + [p for m in self.backs for p in m.head.parameters()]
+        heads = {id(p) for m in self.backs for p in m.head.parameters()}
+        groups, owners = [{"params": self.small}], [None]
         for m in self.backs:
-            params += [p for p in m.parameters() if p.requires_grad]
-        self.opt = Adam(params, lr=1e-4, betas=(0.9, 0.999))                             # MAIN_CA:455-459 (multi-tensor HIP kernel)
+            ps = [p for p in m.parameters() if p.requires_grad and id(p) not in heads]
+            if ps:                                                                       # mode F: frozen backbones have no group
+                groups.append({"params": ps})
+                owners.append(m)
+        self.opt = Adam(groups, lr=1e-4, betas=(0.9, 0.999))                             # MAIN_CA:455-459 (multi-tensor HIP kernel)
         self.sync = GradSync()
         for m in self.backs:
             self.sync.attach(m)
-        self.small = list(self.model.parameters()) + [p for m in self.backs for p in m.head.parameters()]
+        self.opt.before_group = lambda gi: self.sync.finish(owners[gi]) if owners[gi] is not None else None
         self._ce = cross_entropy
 
     def step(self):
@@ -304,14 +312,22 @@ class CaRun:
         loss, preds = self._ce(output, self.target)                                      # MAIN_CA:870-873
         loss.backward()                                                                  # MAIN_CA:880
         self.sync.reduce_grads(self.small)
-        self.sync.finish()
-        self.opt.step()                                                                  # MAIN_CA:882
-        return loss, output
+        self.opt.step()                                                                  # MAIN_CA:882 (joins each encoder's exchange per group)
+        assert not self.sync.pending()
+        # detached: a loss that outlives the step keeps the autograd graph - and the parameters' AccumulateGrad nodes, with the stream
+        # they were created under - alive into the next forward (torch then warns when a later pass runs an encoder on another stream)
+        return loss.detach(), output.detach()
 
-    def logits(self, n):
-        with torch.no_grad():
+    def logits(self, n, train_path=True):
+        """Logits of the first n pairs on the current weights.  train_path (default): the NEED-GRAD forward, i.e. the very kernels the timed
+        step runs (qkv tile GEMM + attention core, activations saved) - a no-grad forward takes the fused MHSA kernel in split bf16 and
+        would validate something that was not timed."""
+        if train_path:
             f_, xc_, xe_ = self.model(self.backs[0], self.backs[1], self.x, self.xe)
-        return (f_ + xc_ + xe_)[:n].float().cpu()
+        else:
+            with torch.no_grad():
+                f_, xc_, xe_ = self.model(self.backs[0], self.backs[1], self.x, self.xe)
+        return (f_ + xc_ + xe_).detach()[:n].float().cpu()
 
 
 def timed_region(run, steps, warmup, world, dev):
@@ -336,8 +352,11 @@ def timed_region(run, steps, warmup, world, dev):
 
 def parity_vs_oracle(run, ref_out):
     got = run.logits(ref_out.shape[0])
+    nog = run.logits(ref_out.shape[0], train_path=False)
     return dict(logits_max_rel_err=float((got - ref_out).abs().max() / ref_out.abs().max()),
-                argmax_equal=bool((got.argmax(1) == ref_out.argmax(1)).all()))
+                argmax_equal=bool((got.argmax(1) == ref_out.argmax(1)).all()),
+                path="need-grad forward: the kernels of the timed step",
+                no_grad_forward_max_rel_err=float((nog - ref_out).abs().max() / ref_out.abs().max()))
 
 
 def main():

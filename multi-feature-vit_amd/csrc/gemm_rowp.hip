@@ -75,6 +75,15 @@ __device__ __forceinline__ void rp_dma16(unsigned voff, const char* sbase, unsig
 // (qkv, fc1 + GELU, fc2-dgrad * gelu', proj-dgrad) as `npass` passes of 384 columns over the same tile rows - the stage stream runs
 // on across the passes (no fill bubble), the outputs of pass p leave while the MFMAs of pass p + 1 run
 constexpr int RP_TILE = 10;
+// the same with 4 bytes per lane (used as a register-free "touch": the data lands in a dummy LDS line nobody reads)
+__device__ __forceinline__ void rp_dma4(unsigned voff, const char* sbase, unsigned m0v) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(m0v)
+                 : "memory");
+}
+
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int npass) {
     constexpr int REPI = MODE < RP_TILE ? MODE : -1;
@@ -136,8 +145,9 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     // prologue.  Inside a training step W is cold, and every CU walks through it in lockstep: each stage would be a first touch served at HBM
     // latency (measured inside the step: fc2 + LN 123 us against 98 us on a warm W).  So first the CUs of an XCD (blockIdx & 7: round-robin
     // dispatch - an assumption for speed only) touch one dword of every 128-byte line of W once, two lines per thread: the stages behind the
-    // first ones find their lines in that XCD's L2 (123 -> 105 us).  The loaded values are never used, but their registers stay reserved
-    // until the wait that covers them (the compiler does not know an asm load is in flight).
+    // first ones find their lines in that XCD's L2 (123 -> 105 us).  The touches are LDS-DMA loads into a dummy 256-byte line of the scratch
+    // area: no destination register (a register destination was copied away and reused by the compiler while the load was still in
+    // flight - caught by tools/check_vmem_hazards.py - the compiler does not know an asm load is outstanding).
     const int G = npass * nk;                                          // stages of the whole tile
     float* sbias = (float*)(lds + RP_RING);                            // tile modes: the bias vector (N <= 2048 floats)
     if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
@@ -145,7 +155,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         for (int n = tid; n < p.N; n += 512) sbias[n] = p.bias ? p.bias[n] : 0.f;
         __syncthreads();
     }
-    unsigned sink[RP_TOUCH];
     {
         const unsigned lpr = (unsigned)(p.K / 32);                             // 128-byte lines per W row
         const unsigned lines = (unsigned)p.N * lpr;                            // all passes
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         for (int k = 0; k < RP_TOUCH; ++k) {
             unsigned ln = t0 + (unsigned)k * nthr;
             ln = ln < lines ? ln : lines - 1;
-            asm volatile("global_load_dword %0, %1, %2" : "=&v"(sink[k]) : "v"((ln / lpr) * (unsigned)(p.ldw * 2) + (ln % lpr) * 128u), "s"(gW));
+            rp_dma4((ln / lpr) * (unsigned)(p.ldw * 2) + (ln % lpr) * 128u, gW, __builtin_amdgcn_readfirstlane(lbase + RP_RING + RP_SCR - 256));
         }
     }
     // W stages 0, 1 and A stages 0 .. 3 in flight (clamped to the last stage for very short K), stage 0 landed
@@ -171,8 +180,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
 #pragma unroll
         for (int i = 0; i < RP_LA; ++i) issue_a(st, st, i);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP_LW + (RP_ASLOTS - 1) * RP_LA) : "memory");     // the touches, W(0), A(0) have completed
-#pragma unroll
-    for (int k = 0; k < RP_TOUCH; ++k) asm volatile("" ::"v"(sink[k]));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     bf16x8 wh[2][3], wl[2][3], ah[RP_MF], al[RP_MF];

@@ -499,7 +499,9 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
         return hipStreamWaitEvent(st, ss.done[l & 63], 0) == hipSuccess ? MFVIT_OK : MFVIT_ELAUNCH;
     };
 
-    const bool lean_grad = d.dtype != MFVIT_F32;
+    // only split bf16 (hi + lo = the f32 value to 2^-17) drops the f32 residual-gradient copies; plain bf16 / fp16 keep them: re-rounding the residual
+    // gradient to 8 / 11 mantissa bits at each of the 2 x depth LayerNorm-backward stages departs from the reference's autocast (fp32 residual grads)
+    const bool lean_grad = d.dtype == MFVIT_BF16X3;
     auto site = [](int l, int which) { return 16u * (unsigned)l + (unsigned)which; };
     const bool rdrop = d.p_resid > 0.f;             // the bias gradients of proj / fc2 then come from the MASKED dY (wgrad column sums)
     for (int s = stage_hi; s >= stage_lo; --s) {

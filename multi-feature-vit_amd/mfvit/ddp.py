@@ -5,15 +5,25 @@ blocks per group: 4 x 1.77 M floats = 28 MB f32, contiguous in the flat gradient
 all-reduced asynchronously, so the exchange of a group overlaps the backward of the groups below it.  xGMI is
 point-to-point (7 links x ~153 GB/s per GPU): per-block buckets keep every message large enough for the ring/direct
 algorithms while leaving 11 blocks of compute to hide each one behind.
+
+``bucket_dtype=torch.bfloat16`` halves the bytes on the links: every group is cast into a persistent bf16 bucket (same offsets as
+the gradient arena), the bucket is all-reduced, and the result is written back over the f32 slice when the group is joined.
+Joins are per owner: ``finish(vit)`` waits for one encoder's groups only, so the optimizer can start on the arenas whose exchange
+is complete (``optimizer.before_group``) while the rest is still on the links.
 """
 import torch
 import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, group=None):
+    def __init__(self, group=None, bucket_dtype=None):
+        import os
         self.group = group
-        self.handles = []
+        self.handles = []                  # (owner key, work handle, write-back or None)
+        if bucket_dtype is None and os.environ.get("MFVIT_GRAD_BUCKET_DTYPE", "f32") in ("bf16", "bfloat16"):
+            bucket_dtype = torch.bfloat16
+        self.bucket_dtype = bucket_dtype if bucket_dtype not in (None, torch.float32) else None
+        self._buckets = {}                 # id(vit) -> persistent low-precision copy of the gradient arena
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         self.world = dist.get_world_size(group) if self.enabled else 1
         # RCCL reduces with AVG in one pass; gloo (CPU tests) has no AVG: SUM then scale
@@ -48,12 +58,30 @@ class GradSync:
         if b_hi >= b_lo:
             a, _ = vit.block_slice(b_lo)
             e, n = vit.block_slice(b_hi)
-            self._push(self._all_reduce(gflat[a:e + n], True))
+            self._exchange(vit, gflat, a, e + n)
         if lo <= -1:
             a0, _ = vit.block_slice(0)
-            self._push(self._all_reduce(gflat[:a0], True))
+            self._exchange(vit, gflat, 0, a0)
             e, n = vit.block_slice(vit.depth - 1)
-            self._push(self._all_reduce(gflat[e + n:], True))
+            self._exchange(vit, gflat, e + n, gflat.numel())
+
+    def _exchange(self, vit, gflat, a, b):
+        """Asynchronous mean over ranks of gflat[a:b]; joined by finish(vit) / finish()."""
+        if b <= a:
+            return
+        if self.bucket_dtype is None:
+            self._push(self._all_reduce(gflat[a:b], True), id(vit))
+            return
+        buf = self._buckets.get(id(vit))
+        if buf is None or buf.numel() != gflat.numel() or buf.device != gflat.device:
+            buf = self._buckets[id(vit)] = torch.empty(gflat.numel(), dtype=self.bucket_dtype, device=gflat.device)
+        src, dst = gflat[a:b], buf[a:b]
+        if self.avg:
+            dst.copy_(src)
+        else:
+            dst.copy_(src / self.world)                                  # scale in f32, round once
+        h = dist.all_reduce(dst, op=dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._push(h, id(vit), lambda: src.copy_(dst))
 
     # ---- everything else (fusion arena, heads): one flat exchange after backward
     def reduce_grads(self, params):
@@ -69,11 +97,23 @@ class GradSync:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
 
-    def _push(self, h):
+    def _push(self, h, owner=None, write_back=None):
         if h is not None and hasattr(h, "wait"):
-            self.handles.append(h)
+            self.handles.append((owner, h, write_back))
 
-    def finish(self):
-        for h in self.handles:
+    def pending(self, owner=None):
+        key = id(owner) if owner is not None else None
+        return sum(1 for k, _, _ in self.handles if key is None or k == key)
+
+    def finish(self, owner=None):
+        """Join the exchanges issued for `owner` (an attached encoder); without an argument, all of them."""
+        key = id(owner) if owner is not None else None
+        rest = []
+        for k, h, write_back in self.handles:
+            if key is not None and k != key:
+                rest.append((k, h, write_back))
+                continue
             h.wait()
-        self.handles = []
+            if write_back is not None:
+                write_back()
+        self.handles = rest

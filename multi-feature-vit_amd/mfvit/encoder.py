@@ -97,6 +97,9 @@ class _EncoderFn(torch.autograd.Function):
         grads = model._run_backward(ctx.cfg, ctx.ws, dfeats)
         model._release_ws(ctx.ws)
         ctx.ws = None
+        # the single-use feature cache holds the forward's output, i.e. this graph and the parameters' AccumulateGrad nodes (which carry
+        # the stream they were created under): once the backward has run it must not keep them alive into the next iteration
+        model._feat_cache = None
         return (None, None, None) + tuple(grads)
 
 
@@ -382,6 +385,7 @@ class VisionTransformerMoCo(nn.Module):
             # all dropouts are 0, so the second result is head(first[:, 0]): computed once.  Single use: a repeated call of
             # the SAME method always recomputes.
             return c[3]
+        c = None
         self._grad_arena_lent = False
         feats = _EncoderFn.apply(self, x, need, *self._arena_params)
         self._feat_cache = (x, key, caller, feats)

@@ -93,11 +93,22 @@ class _TableOptimizer(torch.optim.Optimizer):
     def _flag(self, p, group):
         return 0
 
+    # ``optimizer.before_group = fn(group_index)`` runs before the kernels of each param group are queued: the data-parallel driver
+    # joins only that group's gradient exchange there (GradSync.finish(owner)), so the update of the arenas whose all-reduce is
+    # complete overlaps the exchanges still on the links.
+    before_group = None
+
+    def _pre(self, gi):
+        cb = self.__dict__.get("before_group")
+        if cb is not None:
+            cb(gi)
+
     @torch.no_grad()
     def unscale_(self, inv_scale, found_inf):
         """GradScaler.unscale_: g *= inv_scale for every gradient of this optimizer; found_inf (device f32[1]) is set to 1 when a
         gradient held an inf / nan (mfvit_amp_unscale)."""
         for gi, g in enumerate(self.param_groups):
+            self._pre(gi)
             table, nt, _ = self._table(gi, g)
             if table is None:
                 continue
@@ -118,6 +129,7 @@ class LARS(_TableOptimizer):
     @torch.no_grad()
     def step(self):
         for gi, g in enumerate(self.param_groups):
+            self._pre(gi)
             table, nt, live = self._table(gi, g)
             if table is None:
                 continue
@@ -141,11 +153,14 @@ class Adam(_TableOptimizer):
     @torch.no_grad()
     def step(self):
         for gi, g in enumerate(self.param_groups):
+            self._pre(gi)
             table, nt, live = self._table(gi, g)
             if table is None:
                 continue
-            # per-parameter 'step' like torch.optim (f32 scalar tensors on the host); one kernel launch serves one step number, so the
-            # parameters of a group must agree on it (they do unless a caller hand-edits the state)
+            # per-parameter 'step' like torch.optim (f32 scalar tensors on the host).  One kernel launch serves one step number (bias
+            # correction): normally every parameter of the group agrees and the whole table goes out in one launch; otherwise (a parameter
+            # whose first gradient arrived later, an unfrozen layer, a loaded torch state dict with mixed steps) the table rows - laid out
+            # parameter by parameter - are launched in runs of equal step.
             steps = []
             for p in live:
                 st = self.state[p]
@@ -155,12 +170,21 @@ class Adam(_TableOptimizer):
                 elif t.device.type != "cpu":
                     t = st["step"] = t.detach().float().cpu()
                 steps.append(t)
-            step = int(steps[0]) + 1
-            if any(int(t) + 1 != step for t in (steps[len(steps) // 2], steps[-1])):
-                raise _lib.MfvitError("Adam: the parameters of one group disagree on their step count")
+            vals = [int(t) for t in steps]
             torch._foreach_add_(steps, 1.0)
-            check(lib().mfvit_adam_step(ptr(table), table.shape[0], float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                                        float(g["eps"]), float(g["weight_decay"]), step, stream()), "mfvit_adam_step")
+            runs = []                                      # (first table row, rows, step after the increment)
+            row = 0
+            for p, v in zip(live, vals):
+                nrows = (p.numel() + CHUNK - 1) // CHUNK
+                if runs and runs[-1][2] == v + 1:
+                    runs[-1][1] += nrows
+                else:
+                    runs.append([row, nrows, v + 1])
+                row += nrows
+            assert row == table.shape[0]
+            for first, nrows, step in runs:
+                check(lib().mfvit_adam_step(ptr(table) + first * table.shape[1] * 8, nrows, float(g["lr"]), float(g["betas"][0]),
+                                            float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), step, stream()), "mfvit_adam_step")
             _bump_versions(live)
 
 
@@ -186,6 +210,7 @@ class SGD(_TableOptimizer):
     @torch.no_grad()
     def step(self):
         for gi, g in enumerate(self.param_groups):
+            self._pre(gi)
             table, nt, live = self._table(gi, g)
             if table is None:
                 continue

@@ -90,14 +90,16 @@ def test_backward_all_parameters(precision, tol, stop_grad_conv1):
     log(f"backward[{precision},stop_grad_conv1={stop_grad_conv1}] worst {worst[0]} err={worst[1]:.3e}")
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp16", "fp32"])
 def test_full_size_batch_is_sample_independent(precision):
     """BASELINE configs[2] size (B = 128 at 224^2, M = 25,216 token rows - too big for the CPU oracle): a ViT has no cross-sample
     op, so every sample of the full batch must come out exactly as it does in the small batches the oracle tests cover (the GEMM
     tiles, attention workgroups and row kernels may not leak between rows, pad rows or tile tails).  Forward: bit-exact in fp32; in the
-    16-bit modes the row-complete GEMMs switch to their two-workgroups-per-CU variant above 16,384 token rows (same sums, but a
-    separately compiled epilogue: an f32 last-bit difference can flip a bf16 rounding), so there the rows must agree to a few bf16
-    ulps - a leak between rows or tiles would be an O(1) error.  Backward:
+    16-bit modes the row-complete GEMMs switch kernels with the row count (two workgroups per CU above 16,384 token rows; in the default
+    split-bf16 precision the tall-tile kernel of gemm_rowp.hip above 4,096: other MFMA shape, other summation order), so an f32 last-bit
+    difference can flip a rounding of the operand type: the rows must agree to a few ulps of THAT type - 1e-4 for split bf16 (16
+    mantissa bits: a flipped hi rounding is absorbed by the lo part), 1e-2 for bf16, 2e-3 for fp16; a leak between rows, pad rows or tile
+    tails would be an O(1) error.  Backward:
     the input-independent reduction order of the split-M weight gradients changes with M, so the full-batch gradient is compared
     with the SUM of the sub-batch gradients at rounding level."""
     m, _ = build(precision, 601, depth=2 if precision == "fp32" else 12)
@@ -111,7 +113,7 @@ def test_full_size_batch_is_sample_independent(precision):
                 assert torch.equal(full[lo:lo + n], part), (precision, lo)
             else:
                 e = ((full[lo:lo + n] - part).abs().max() / part.abs().max()).item()
-                assert e < 1e-2, (precision, lo, e)
+                assert e < {"bf16x3": 1e-4, "bf16": 1e-2, "fp16": 2e-3}[precision], (precision, lo, e)
     assert torch.isfinite(full).all()
     # gradient linearity over the batch: grad(sum over 128) == grad(first 64) + grad(last 64)
     w = rng_tensor(603, (B, 197, 384)).to("cuda:0")
@@ -123,13 +125,15 @@ def test_full_size_batch_is_sample_independent(precision):
         return {k: p_.grad.detach().clone() for k, p_ in m.named_parameters() if p_.grad is not None}
 
     g_all, g_a, g_b = grads(0, B), grads(0, 64), grads(64, B)
-    tol = 2e-2 if precision == "bf16" else 1e-4                      # bf16: dY is rounded to bf16 per call; sums differ by rounding
+    # 16-bit modes: dY is rounded to the operand type per call, so the sums differ by its rounding (split bf16: 2^-17, but gelu' rides in
+    # plain fp16 - see DESIGN.md 2)
+    tol = {"bf16": 2e-2, "fp16": 5e-3, "bf16x3": 1e-3, "fp32": 1e-4}[precision]
     worst = 0.0
     for k in g_all:
         e = scale_err(g_all[k], g_a[k] + g_b[k])
         worst = max(worst, e)
         assert e < tol, (k, e)
-    log(f"full-size batch independence [{precision}]: forward bit-exact, gradient additivity worst {worst:.2e}")
+    log(f"full-size batch independence [{precision}]: forward {'bit-exact' if precision == 'fp32' else 'to a few ulps'}, gradient additivity worst {worst:.2e}")
 
 
 @pytest.mark.parametrize("bucket", [1, 4, 5])

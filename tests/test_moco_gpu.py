@@ -109,11 +109,52 @@ def test_ema_and_enqueue_against_reference_golden():
     assert abs(float(loss) - float(g["nce_loss"])) < 1e-4 * abs(float(g["nce_loss"]))
 
 
-@pytest.mark.parametrize("predict_keys", [True, False])
-def test_moco_forward_backward_vs_oracle(predict_keys):
+def _oracle_step(m, im_q, im_k, mval, T, predict_keys=True):
+    """The f64 oracle (oracle/ref_moco.py: BLD:154-199 restated) on the CURRENT weights / queue of the HIP builder `m`: returns the oracle's
+    result dict (after .backward() of its loss) and a lookup parameter name -> oracle gradient (None where the reference has none)."""
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    split = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    base_vit = {k: v for k, v in split("base_encoder.").items() if not k.startswith("head.")}
+    mom_vit = {k: v for k, v in split("momentum_encoder.").items() if not k.startswith("head.")}
+    base_proj = {k: v for k, v in split("base_encoder.").items() if k.startswith("head.") and "running" not in k and "num_b" not in k}
+    mom_proj = {k: v for k, v in split("momentum_encoder.").items() if k.startswith("head.") and "running" not in k and "num_b" not in k}
+    pred = {k: v for k, v in sd.items() if k.startswith("predictor.") and "running" not in k and "num_b" not in k}
+    for d_ in (base_vit, base_proj, pred):
+        for k, v in d_.items():
+            v.requires_grad_(k != "pos_embed" and not k.startswith("patch_embed"))
+    ref = ref_moco.moco_forward(base_vit, base_proj, mom_vit, mom_proj, pred, sd["queue"], int(sd["queue_ptr"]), im_q.double().cpu(),
+                                im_k.double().cpu(), mval, T, use_predictor_on_k=predict_keys)
+    ref["loss"].backward()
+
+    def ref_grad(name):
+        if name.startswith("base_encoder.head."):
+            return base_proj[name[len("base_encoder."):]].grad
+        if name.startswith("base_encoder."):
+            return base_vit[name[len("base_encoder."):]].grad
+        if name.startswith("predictor."):
+            return pred[name].grad
+        return None                                       # momentum encoder: no gradient (BLD:52-54)
+    gmax = max(float(v.grad.abs().max()) for d_ in (base_vit, base_proj, pred) for v in d_.values() if v.grad is not None)
+    return ref, ref_grad, gmax
+
+
+# per precision: (logits, loss, worst parameter gradient [max error / max value], worst per-tensor L2 error) against the f64 oracle.
+# fp16: this step is badly conditioned at random initialisation - d loss / d q passes through the L2 normalisation, (k - (q.k) q) / |q|,
+# a difference of nearly parallel unit vectors, and three batch-of-8 BatchNorms - so the 6e-3 forward error of fp16 operands comes back
+# as a UNIFORM ~10 % L2 error on every gradient tensor (tools/moco_fp16_diag.py: fp16 9-12 %, plain bf16 20-24 %, while the same kernels
+# in exact-f32 mode give 2e-5 and bf16x3 9e-4).  The fp16 gradient bound therefore only catches a wrong scale or a missing term; the
+# forward bound and the gradient-norm comparison of test_fp16_moco_step_with_grad_scaler are the tight ones.
+_MOCO_TOL = {"fp32": (1e-3, 1e-3, 2e-3, 2e-3), "bf16x3": (1e-3, 1e-3, 2e-3, 2e-3), "fp16": (1e-2, 3e-3, 0.6, 0.15)}
+
+
+@pytest.mark.parametrize("precision,predict_keys", [("fp32", True), ("fp32", False), ("bf16x3", True), ("fp16", True)])
+def test_moco_forward_backward_vs_oracle(precision, predict_keys):
+    """MoCo.forward + backward of the HIP builder in EVERY precision the bench MoCo lines run in, against the f64 oracle on the same
+    weights (not against another HIP mode)."""
     from mfvit.moco_ops import cross_entropy_rows
     depth, mlp_dim, dim, T, n, mval = 2, 512, 256, 0.2, 8, 0.99
-    m = make_moco(depth=depth, mlp_dim=mlp_dim, dim=dim, T=T, predict_keys=predict_keys)
+    tol_logits, tol_loss, tol_grad, tol_l2 = _MOCO_TOL[precision]
+    m = make_moco(depth=depth, mlp_dim=mlp_dim, dim=dim, T=T, predict_keys=predict_keys, precision=precision)
     with torch.no_grad():                                   # make everything non-trivial
         sd = ref_vit.seeded_params(701, num_classes=0, depth=depth)
         m.base_encoder.load_state_dict(sd, strict=False)
@@ -125,54 +166,50 @@ def test_moco_forward_backward_vs_oracle(predict_keys):
             else:
                 p.copy_(rng_tensor(710 + i, p.shape) / p.shape[1] ** 0.5)
     m = m.to(DEV).train()
-    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
-    split = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
-    base_vit = {k: v for k, v in split("base_encoder.").items() if not k.startswith("head.")}
-    mom_vit = {k: v for k, v in split("momentum_encoder.").items() if not k.startswith("head.")}
-    base_proj = {k: v for k, v in split("base_encoder.").items() if k.startswith("head.") and "running" not in k and "num_b" not in k}
-    mom_proj = {k: v for k, v in split("momentum_encoder.").items() if k.startswith("head.") and "running" not in k and "num_b" not in k}
-    pred = {k: v for k, v in sd.items() if k.startswith("predictor.") and "running" not in k and "num_b" not in k}
-    for d_ in (base_vit, base_proj, pred):
-        for k, v in d_.items():
-            v.requires_grad_(k != "pos_embed" and not k.startswith("patch_embed"))
     im_q, im_k = rng_tensor(720, (n, 3, 224, 224)), rng_tensor(721, (n, 3, 224, 224))
-    ref = ref_moco.moco_forward(base_vit, base_proj, mom_vit, mom_proj, pred, sd["queue"], int(sd["queue_ptr"]), im_q.double(),
-                                im_k.double(), mval, T, use_predictor_on_k=predict_keys)
-    ref["loss"].backward()
+    ref, ref_grad, gmax = _oracle_step(m, im_q, im_k, mval, T, predict_keys)
     logits, labels = m(im_q.to(DEV), im_k.to(DEV), mval)
     assert tuple(logits.shape) == (n, 1 + m.K) and labels.dtype == torch.long and int(labels.abs().sum()) == 0
     loss = cross_entropy_rows(logits, labels)
-    loss.backward()
-    errs = dict(logits=scale_err(logits, ref["logits"]), loss=abs(float(loss) - float(ref["loss"])) / abs(float(ref["loss"])))
+    # fp16: d loss / d logits ~ 1 / (8 x 65,537) is far below fp16's normal range - the reference never runs this backward without its
+    # GradScaler (MAIN_MOCO:349,540), so the test scales the loss the same way (2^12, a power of two: exact) and unscales the gradients
+    gscale = 4096.0 if precision == "fp16" else 1.0
+    (loss * gscale).backward()
+    errs = dict(logits=scale_err(logits, ref["logits"]), loss=abs(float(loss.detach()) - float(ref["loss"])) / abs(float(ref["loss"])))
     worst = ("", 0.0)
+    all_errs = []
     # gradients that are mathematically zero (a batch-constant shift in front of a BatchNorm, e.g. norm.bias) are pure
     # rounding noise in both implementations: compare against a floor tied to the largest gradient
-    gfloor = 1e-4 * max(float(v.grad.abs().max()) for d_ in (base_vit, base_proj, pred) for v in d_.values() if v.grad is not None)
+    gfloor = (1e-4 if precision != "fp16" else 1e-2) * gmax
     for name, p in m.named_parameters():
-        if name.startswith("base_encoder.head."):
-            rg = base_proj[name[len("base_encoder."):]].grad
-        elif name.startswith("base_encoder."):
-            rg = base_vit[name[len("base_encoder."):]].grad
-        elif name.startswith("predictor."):
-            rg = pred[name].grad
-        else:
-            assert p.grad is None, name                   # momentum encoder: no gradient (BLD:52-54)
-            continue
+        rg = ref_grad(name)
         if rg is None:
             assert p.grad is None, name
             continue
-        e = scale_err(p.grad, rg, gfloor)
+        if float(rg.abs().max()) < 1e-9 * gmax:
+            # mathematically zero (a bias in front of a BatchNorm): the HIP value is the rounding residue of a column sum of
+            # gradients that cancel - bound it against the largest gradient instead of against the oracle's own ~1e-17
+            assert float(p.grad.abs().max()) / gscale < (1e-4 if precision != "fp16" else 2e-2) * gmax, name
+            continue
+        e = scale_err(p.grad / gscale, rg, gfloor)
+        all_errs.append((e, name))
+        if float(rg.abs().max()) > gfloor:
+            l2 = float((p.grad.double().cpu() / gscale - rg.double()).norm() / rg.double().norm())
+            assert l2 < tol_l2, (name, l2)
         worst = max(worst, (name, e), key=lambda t: t[1])
-        assert e < 2e-3, (name, e)
+    log(f"moco vs oracle [{precision}] worst gradients: {sorted(all_errs, reverse=True)[:4]}")
+    assert worst[1] < tol_grad, worst
     # momentum encoder after the EMA, queue after the enqueue
+    tol_state = 1e-5 if precision == "fp32" else 1e-3
     for k, v in ref["mom_vit"].items():
         assert scale_err(m.momentum_encoder.state_dict()[k], v) < 1e-5, k
     for k, v in ref["mom_proj"].items():
         assert scale_err(m.momentum_encoder.state_dict()[k], v) < 1e-5, k
     assert int(m.queue_ptr) == ref["ptr"] == n
     errs["queue"] = scale_err(m.queue[:, :n], ref["queue"][:, :n])
-    log(f"moco fwd/bwd vs oracle [predict_keys={predict_keys}]: {errs} worst grad {worst}")
-    assert errs["logits"] < 1e-3 and errs["loss"] < 1e-3 and errs["queue"] < 1e-3
+    log(f"moco fwd/bwd vs oracle [{precision}, predict_keys={predict_keys}]: {errs} worst grad {worst}")
+    assert errs["logits"] < tol_logits and errs["loss"] < tol_loss and errs["queue"] < max(1e-3, tol_logits), errs
+    del tol_state
 
 
 def test_moco_v3_symmetric_loss_vs_oracle_and_golden():
@@ -281,6 +318,42 @@ def test_lars_against_reference_golden_and_adam_sgd_vs_torch():
             oa.step(); ob.step()
         for pa, pb in zip(a, b):
             torch.testing.assert_close(pa.detach(), pb.detach(), rtol=2e-5, atol=2e-6)
+
+
+def test_adam_parameters_with_different_step_counts_match_torch():
+    """torch.optim keeps 'step' per parameter: a parameter whose first gradient arrives later (an unfrozen layer, a loaded state dict
+    with mixed steps) gets the bias correction of ITS step.  The HIP Adam / AdamW launch one kernel per run of equal step over the rows
+    of their chunk table (a single step number per group silently mis-corrected such parameters)."""
+    from mfvit.optim import Adam, AdamW
+    for mine, theirs in ((Adam, torch.optim.Adam), (AdamW, torch.optim.AdamW)):
+        shapes = [(70000,), (33, 7), (5,), (129, 3)]                # the first one spans two table rows
+        a = [torch.nn.Parameter(rng_tensor(540 + i, s).to(DEV)) for i, s in enumerate(shapes)]
+        b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+        oa, ob = mine(a, lr=1e-2, weight_decay=0.1), theirs(b, lr=1e-2, weight_decay=0.1)
+        for step in range(5):
+            for i, (pa, pb) in enumerate(zip(a, b)):
+                late = (i == 1 and step < 2) or (i == 3 and step < 3)   # parameters 1 and 3 get their first gradients at steps 2 and 3
+                if late:
+                    pa.grad = pb.grad = None
+                    continue
+                gr = rng_tensor(560 + 10 * step + i, pa.shape).to(DEV)
+                pa.grad, pb.grad = gr.clone(), gr.clone()
+            oa.step()
+            ob.step()
+            for pa, pb in zip(a, b):
+                torch.testing.assert_close(pa.detach(), pb.detach(), rtol=2e-6, atol=2e-7)
+        assert [int(oa.state[p]["step"]) for p in a] == [5, 3, 5, 2] == [int(ob.state[p]["step"]) for p in b]
+        # a torch state dict with mixed steps loads and continues identically
+        oa2 = mine(a, lr=1e-2, weight_decay=0.1)
+        oa2.load_state_dict(copy.deepcopy(ob.state_dict()))     # a copy, as torch.load gives: state_dict() hands out the live tensors
+        for pa, pb in zip(a, b):
+            gr = rng_tensor(700 + pa.numel() % 97, pa.shape).to(DEV)
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        oa2.step()
+        ob.step()
+        for pa, pb in zip(a, b):
+            torch.testing.assert_close(pa.detach(), pb.detach(), rtol=2e-6, atol=2e-7)
+    log("Adam / AdamW with per-parameter step counts (late first gradients, mixed-step state dict): equal to torch.optim")
 
 
 def test_raw_pointer_updates_refresh_weight_shadows():
@@ -476,7 +549,6 @@ def test_moco_forward_against_the_references_own_forward():
     e_q = scale_err(m.queue[:, K - n:], torch.from_numpy(g["queue_tail"]))
     for name, p in m.momentum_encoder.named_parameters():
         check_sampled(g, "mom." + name, p, rtol=1e-5, atol=1e-6)
-    worst = 0.0
     named = list(m.base_encoder.named_parameters()) + [("predictor." + k_, v) for k_, v in m.predictor.named_parameters()]
     # gradients that are mathematically zero (a bias in front of a BatchNorm: body.bias) are rounding noise on both sides: the
     # absolute tolerance is tied to the largest mean |gradient| of the model
@@ -488,13 +560,14 @@ def test_moco_forward_against_the_references_own_forward():
     e_rv = scale_err(m.predictor[1].running_var, torch.from_numpy(g["pred_bn_running_var"]))
     assert float(m.predictor[1].running_mean.abs().max()) < 1e-5 and float(np.abs(g["pred_bn_running_mean"]).max()) < 1e-12
     log(f"MoCo.forward vs reference forward golden: logits[:, :16] {e_head:.2e} queue tail {e_q:.2e} predictor BN running_var {e_rv:.2e}")
-    assert e_head < 1e-3 and e_q < 1e-4 and e_rv < 1e-4 and worst == 0.0
+    assert e_head < 1e-3 and e_q < 1e-4 and e_rv < 1e-4
 
 
 def test_fp16_moco_step_with_grad_scaler():
-    """configs[3]/[4] arithmetic (MAIN_MOCO:349,533,546-548): MoCo step with fp16 MFMA operands and loss scaling.  Against the f64
-    oracle on the same weights: logits at fp16 accuracy; after scaler.step the parameters moved exactly as an unscaled-gradient AdamW
-    step would move them (gradients are unscaled in place by mfvit_amp_unscale before the optimizer kernel reads them)."""
+    """configs[3]/[4] arithmetic (MAIN_MOCO:349,533,546-548): MoCo step with fp16 MFMA operands and loss scaling.  Logits and loss against
+    the f64 ORACLE on the same weights (fp16 accuracy) and against the HIP fp32 model; the gradients the optimizer sees are the UNSCALED
+    ones (a missed / doubled unscale would be off by 2^14) and track both the oracle's and the fp32 model's; after scaler.step every
+    parameter has moved."""
     from mfvit.amp import GradScaler
     from mfvit.moco_ops import cross_entropy_rows
     from mfvit.optim import AdamW
@@ -511,6 +584,7 @@ def test_fp16_moco_step_with_grad_scaler():
     scaler = GradScaler(init_scale=2.0 ** 14)
     opt = AdamW([p for p in m16.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.1)
     before = {k: v.detach().clone() for k, v in m16.named_parameters() if v.requires_grad}
+    ref, ref_grad, _ = _oracle_step(m16, im_q, im_k, mval, T)            # the oracle on the weights / queue BEFORE the step
     logits, labels = m16(im_q, im_k, mval)
     loss = cross_entropy_rows(logits, labels)
     scaler.scale(loss).backward()
@@ -520,7 +594,9 @@ def test_fp16_moco_step_with_grad_scaler():
     loss32 = cross_entropy_rows(l32, lab32)
     loss32.backward()
     e_l = scale_err(logits, l32)
+    e_lo = scale_err(logits, ref["logits"])
     assert e_l < 1e-2 and abs(float(loss) - float(loss32)) < 2e-3 * abs(float(loss32))
+    assert e_lo < 1e-2 and abs(float(loss) - float(ref["loss"])) < 3e-3 * abs(float(ref["loss"])), (e_lo, float(loss), float(ref["loss"]))
     # gradients after the unscale == the f32 model's gradients at fp16 accuracy.  Per tensor, relative L2 error; tensors whose
     # gradient is tiny beside the largest one (mathematically-zero gradients in front of a BatchNorm, fp16 underflow territory) are
     # compared against that largest norm instead.
@@ -540,5 +616,7 @@ def test_fp16_moco_step_with_grad_scaler():
     # pins is that the gradients are the UNSCALED ones (a missed / doubled unscale would be off by 2^14) and track the f32 model
     n16 = sum(float(p.grad.double().pow(2).sum()) for p in m16.parameters() if p.grad is not None) ** 0.5
     n32 = sum(float(p.grad.double().pow(2).sum()) for p in m32.parameters() if p.grad is not None) ** 0.5
-    assert abs(n16 / n32 - 1.0) < 2e-2, (n16, n32)
+    nor = sum(float(ref_grad(k).pow(2).sum()) for k, p in m16.named_parameters() if p.grad is not None and ref_grad(k) is not None) ** 0.5
+    log(f"fp16 MoCo step: logits vs f64 oracle {e_lo:.2e}; gradient norm fp16 {n16:.4e} / fp32 HIP {n32:.4e} / oracle {nor:.4e}")
+    assert abs(n16 / n32 - 1.0) < 2e-2 and abs(n16 / nor - 1.0) < 2e-2, (n16, n32, nor)
     assert worst < 0.2 and moved == len(before) and scaler.get_scale() == 2.0 ** 14

@@ -7,7 +7,9 @@ both ranks share cuda:0 and talk over gloo (RCCL needs one GPU per rank; the dri
   (b) MoCo_ViT(shuffle_bn=True).forward (BLD:107-152: image all_gather, broadcast permutation, unshuffle) gives the logits and
       queue of shuffle_bn=False - the claim DESIGN.md makes for skipping the shuffle by default.
   (c) GradSync: the asynchronous per-bucket all-reduce issued from the encoder's backward hooks (the handles the RCCL path uses)
-      == the mean over ranks of the unsynchronised gradients.
+      == the mean over ranks of the unsynchronised gradients; joins per owner; the bf16 bucket option.
+  (d) The reference's wrapper sequence with stock torch objects (convert_sync_batchnorm -> DistributedDataParallel -> torch.optim.AdamW
+      -> torch.cuda.amp.GradScaler -> autocast) on the drop-in MoCo_ViT, two steps == GradSync + mfvit.optim.AdamW + mfvit.amp.GradScaler.
 """
 import os
 import types
@@ -105,14 +107,105 @@ def _grad_sync(rank, world):
     sync.attach(m, bucket_layers=2)                                  # 3 block groups + embedding / norm pieces: 5 asynchronous handles
     seen = []
     orig = sync._push
-    sync._push = lambda h: (seen.append(h), orig(h))[1]
+    sync._push = lambda h, *a: (seen.append(h), orig(h, *a))[1]
     for p in m.parameters():
         p.grad = None
     (m.features3D(x) * w).sum().backward()
     assert len(seen) >= 5 and all(hasattr(h, "wait") for h in seen)  # handles of async_op=True collectives, issued by the hooks
-    sync.finish()
+    other = torch.nn.Linear(2, 2)                                    # joins are per owner: nothing was issued for this one
+    assert sync.pending() == len(seen) and sync.pending(m) == len(seen) and sync.pending(other) == 0
+    sync.finish(other)
+    assert sync.pending() == len(seen)
+    sync.finish(m)
+    assert sync.pending() == 0
     got = m._last_grad_arena
-    return dict(sync=_err(got, want), differs_from_local=float((want - local).abs().max()) > 0)
+    res = dict(sync=_err(got, want), differs_from_local=float((want - local).abs().max()) > 0)
+    # bf16 buckets: half the bytes on the links; the mean is rounded to bf16 once on the way out and once on the way back
+    sync16 = GradSync(bucket_dtype=torch.bfloat16)
+    sync16.attach(m, bucket_layers=2)
+    for p in m.parameters():
+        p.grad = None
+    (m.features3D(x) * w).sum().backward()
+    assert sync16.pending(m) >= 5 and sync16._buckets[id(m)].dtype == torch.bfloat16
+    sync16.finish()
+    got16 = m._last_grad_arena
+    assert got16.dtype == torch.float32
+    res.update(sync_bf16=_err(got16, want), bf16_rounds=bool((got16 != want).any()))
+    m._grad_stage_hook = None
+    return res
+
+
+def _stock_wrappers(rank, world):
+    """The reference's wrapper sequence with STOCK torch objects on the drop-in modules (MAIN_MOCO:297 convert_sync_batchnorm,
+    :312 DistributedDataParallel, :338-340 torch.optim.AdamW, :349 torch.cuda.amp.GradScaler, :533-548 autocast / scale / step /
+    update), two steps, against the package's own GradSync + mfvit.optim.AdamW + mfvit.amp.GradScaler on identically seeded models."""
+    import vits
+    import moco.builder_vit_mocov3structure_mocov2loss as bld
+    from mfvit.amp import GradScaler as HipGradScaler
+    from mfvit.ddp import GradSync
+    from mfvit.moco_ops import cross_entropy_rows
+    from mfvit.optim import AdamW as HipAdamW
+
+    def make():
+        torch.manual_seed(91)
+        return bld.MoCo_ViT(partial(vits.vit_small, stop_grad_conv1=True, depth=2, precision="fp16"), types.SimpleNamespace(arch="vit_small"),
+                            256, 256, 0.2).to("cuda:0")
+
+    n = 4
+    x1 = rng_tensor(951 + rank, (n, 3, 224, 224)).to("cuda:0")
+    x2 = rng_tensor(961 + rank, (n, 3, 224, 224)).to("cuda:0")
+    # --- A: stock torch wrappers
+    ma = torch.nn.SyncBatchNorm.convert_sync_batchnorm(make())
+    dda = torch.nn.parallel.DistributedDataParallel(ma)
+    opt_a = torch.optim.AdamW([p for p in dda.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.1)
+    sc_a = torch.cuda.amp.GradScaler(init_scale=2.0 ** 12)
+    crit = torch.nn.CrossEntropyLoss().cuda(0)
+    # --- B: the package's own objects
+    mb = make()
+    sync = GradSync()
+    sync.attach(mb.base_encoder, bucket_layers=1)
+    train_b = [p for p in mb.parameters() if p.requires_grad]
+    small_b = [p for k, p in mb.named_parameters() if p.requires_grad and (".head." in k or k.startswith("predictor"))]
+    opt_b = HipAdamW(train_b, lr=1e-3, weight_decay=0.1)
+    sc_b = HipGradScaler(init_scale=2.0 ** 12)
+    names = [k for k, p in mb.named_parameters() if p.requires_grad]
+    assert names == [k for k, p in ma.named_parameters() if p.requires_grad]
+    init = {k: p.detach().clone() for k, p in mb.named_parameters()}
+    res = {}
+    for step in range(2):
+        with torch.cuda.amp.autocast(True):
+            la, lab_a = dda(x1, x2, 0.99)
+            loss_a = crit(la, lab_a)
+        opt_a.zero_grad()
+        sc_a.scale(loss_a).backward()
+        lb, lab_b = mb(x1, x2, 0.99)
+        loss_b = cross_entropy_rows(lb, lab_b)
+        opt_b.zero_grad(set_to_none=True)
+        sc_b.scale(loss_b).backward()
+        sync.reduce_grads(small_b)
+        sync.finish()
+        pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+        if step == 0:                                                # averaged, still scaled gradients: DDP's buckets vs GradSync's
+            res["grad"] = max(_err(pa[k].grad, pb[k].grad) for k in names)
+            res["grad_is_mean"] = float(pa["predictor.0.weight"].grad.abs().max()) > 0
+        sc_a.step(opt_a)
+        sc_a.update()
+        sc_b.step(opt_b)
+        sc_b.update()
+        res[f"logits{step}"] = _err(la, lb)
+        res[f"loss{step}"] = abs(float(loss_a.detach()) - float(loss_b.detach())) / abs(float(loss_b.detach()))
+    moved = max(float((pb[k].detach() - init[k]).abs().max()) for k in names)
+    # Adam normalises every element's update to ~lr: where a gradient element is rounding noise its sign may differ between the two
+    # reduction orders, so compare the bulk (fraction of elements further apart than 5% of one update) and the worst element (<= 2 lr x 2 steps)
+    far, tot, worst = 0, 0, 0.0
+    for k in names:
+        d = (pa[k].detach() - pb[k].detach()).abs()
+        far += int((d > 5e-5).sum())
+        tot += d.numel()
+        worst = max(worst, float(d.max()))
+    res.update(param_far_fraction=far / tot, param_worst=worst, moved=moved, scale_a=float(sc_a.get_scale()), scale_b=float(sc_b.get_scale()),
+               queue=_err(ma.queue, mb.queue), queue_ptr=(int(ma.queue_ptr), int(mb.queue_ptr)))
+    return res
 
 
 def _worker(rank, world, port, q):
@@ -122,7 +215,7 @@ def _worker(rank, world, port, q):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = dict(bn=_sync_bn(rank, world), moco=_moco_pair(rank, world), sync=_grad_sync(rank, world))
+        res = dict(bn=_sync_bn(rank, world), moco=_moco_pair(rank, world), sync=_grad_sync(rank, world), stock=_stock_wrappers(rank, world))
         q.put((rank, res, None))
     except Exception as e:   # noqa: BLE001 - reported to the parent, which fails the test
         import traceback
@@ -152,3 +245,13 @@ def test_two_ranks_syncbn_shufflebn_gradsync():
         assert r["moco"]["logits"] < 1e-4 and r["moco"]["queue"] < 1e-4 and r["moco"]["rest_untouched"] == 0.0, (rank, r["moco"])
         assert r["moco"]["pred_grad"] < 1e-3, (rank, r["moco"])
         assert r["sync"]["sync"] < 1e-6 and r["sync"]["differs_from_local"], (rank, r["sync"])
+        # bf16 buckets: each rank's term and the mean are rounded to bf16 (2^-9 of their size); error relative to the largest gradient
+        assert r["sync"]["sync_bf16"] < 4e-3 and r["sync"]["bf16_rounds"], (rank, r["sync"])
+        st = r["stock"]
+        assert st["grad"] < 2e-3 and st["grad_is_mean"], (rank, st)
+        # step 0 runs on identical weights: same logits bit for bit, gradients equal to reduction-order rounding.  Step 1 runs on
+        # weights that differ where Adam normalised rounding-noise gradients (measured: 0.3 % of the elements further apart than 5 % of
+        # one update, logits 2.4e-3, the fp16 keys written to the queue 1e-2)
+        assert st["logits0"] < 1e-6 and st["loss0"] < 1e-6 and st["logits1"] < 1e-2 and st["loss1"] < 1e-4, (rank, st)
+        assert st["moved"] > 5e-4 and st["param_far_fraction"] < 1e-2 and st["param_worst"] <= 4.2e-3, (rank, st)
+        assert st["scale_a"] == st["scale_b"] and st["queue"] < 3e-2 and st["queue_ptr"][0] == st["queue_ptr"][1], (rank, st)

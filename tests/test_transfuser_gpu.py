@@ -47,6 +47,12 @@ class Stream(torch.nn.Module):
         return self.feats
 
 
+# fp16 tolerance 1.5e-2 (x2 for the gradients): the forward tensors (GPT token rows, logits) sit well inside it; the entries that need it are
+# PARAMETER GRADIENTS BEHIND THE ReLU MLP - first seen on d.encoder.transformer4.blocks.7.mlp.0.weight, where 1 of 256 sampled entries was
+# off by its whole value (1.4e-2 against 8.2e-3 allowed at tol 1e-2; gpurun_out/t10.log of round 2): a ReLU unit whose pre-activation lies
+# within fp16 rounding of zero switches side, so its whole contribution to that weight row appears / vanishes.  The wider tolerance plus the
+# "at most 1 % of the sampled entries" allowance in chk() below cover exactly that discontinuity; split bf16 (1e-3, zero misses allowed)
+# shows that nothing else is hiding behind it.
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("fp16", 1.5e-2)])
 def test_transfuser_against_reference_golden(precision, tol):
     from model import fuseattention as fa

@@ -3,6 +3,9 @@ compiler does not know those registers are in flight, so a register copy, spill 
 covers it reads or clobbers garbage.  This scans the device assembly (hipcc -S) of every matching kernel linearly from its entry to its
 last MFMA, keeps the in-order queue of outstanding vector-memory operations (gfx9: loads and stores share vmcnt), retires entries at
 each `s_waitcnt vmcnt(N)`, and fails if any other instruction names a VGPR that is still the destination of an outstanding load.
+Only loads issued from INLINE ASM (between the `;;#ASMSTART` / `;;#ASMEND` markers of hipcc -S) are tracked as hazards: the compiler
+counts its own loads itself, and a linear scan of a loop it generated would report them falsely; they still occupy their slot in the
+vmcnt queue, as stores do.
 
 usage: python3 tools/check_vmem_hazards.py <file.s> <kernel-name-regex>      (exit status 1 on a violation)"""
 import re
@@ -29,7 +32,14 @@ def regs(text):
 def check_kernel(name, lines):
     last = max((i for i, l in enumerate(lines) if l.startswith("v_mfma")), default=-1)
     queue, bad = [], []
+    in_asm = False
     for i, l in enumerate(lines[:last + 1]):
+        if l == "#ASMSTART":
+            in_asm = True
+            continue
+        if l == "#ASMEND":
+            in_asm = False
+            continue
         m = WAIT.match(l)
         if m:
             c = re.search(r"vmcnt\((\d+)\)", m.group(1))
@@ -48,7 +58,10 @@ def check_kernel(name, lines):
             if (dst | addr) & inflight:
                 bad.append((i, l))
             assert kind in WIDTH or kind.startswith("lds"), (name, l)
-            queue.append(dst)
+            queue.append(dst if in_asm else set())
+            continue
+        if m:                                   # LDS-DMA: no register destination, one slot in the queue
+            queue.append(set())
             continue
         if STORE.match(l):
             inflight = set().union(*[q for q in queue if q]) if queue else set()
@@ -70,6 +83,9 @@ def main(path, pattern):
         if raw.startswith("_Z") and l.endswith(":") or (raw.startswith("_Z") and ":" in l and "; @" in l):
             cur = l.split(":")[0]
             body = kernels.setdefault(cur, [])
+            continue
+        if cur is not None and l in (";;#ASMSTART", ";;#ASMEND"):
+            body.append(l[2:])
             continue
         if cur is None or not l or l.startswith(";") or l.startswith(".") and not l.startswith(".LBB"):
             if l.startswith(".Lfunc_end"):
