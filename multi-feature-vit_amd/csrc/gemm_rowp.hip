@@ -56,6 +56,8 @@ constexpr int RP_TOUCH = 2;                     // L2 warm-up loads per thread i
 constexpr int RP_LW = 6, RP_LA = 2;             // LDS-DMA instructions per wave and stage: W pieces wave + 8 i; A pieces wave, wave + 7
                                                 // (14 pieces of 8 rows: wave 7 repeats wave 6's - identical bytes - so that every wave
                                                 // counts the same number of operations)
+constexpr int RP_XROWS = 100;                   // LayerNorm-backward mode: tile rows whose x (1536 B each) fit the ring
+constexpr int RP_XDMA = (RP_XROWS * 96 + 511) / 512;   // 16-byte LDS-DMA instructions per thread for them (19: exactly the 152 KB ring)
 constexpr int RP_YP = 1536 + 16;                // staging pitch of a split output row (768 storage elements + pad)
 
 __device__ __forceinline__ const char* rp_uniform_ptr(const void* q) {
@@ -344,6 +346,8 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                   // the ring is free: epilogue scratch
+    if constexpr (EPI < 0)
+        if (p.rows_per_wg == 78) return;                               // (timing experiment MFVIT_ROWP_NOEPI=1: main loop only, nothing stored)
 
     // ------------------------------------------------------------------------------------------------ epilogues
     // acc[i][j][r] = out[m0 + 16 i + fr][48 wave + 16 j + 4 fq + r]; rows past `rows` replicate the tile's last valid row exactly (clamped
@@ -499,13 +503,49 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         // acc = dL/dy (y = LayerNorm output); aux = the saved LayerNorm input x (f32), mean / rstd its row statistics:
         //   h = (x - mu) rs,  g = dy gamma,  dx = rs (g - mean_n(g) - h mean_n(g h)) + residual gradient
         //   column sums over the VALID rows: dgamma += dy h, dbeta += dy, dcol += dx
-        // Register plan (256): acc 84 + the column sums; h is recomputed in the second phase from a second read of x (this CU fetched those
-        // 152 KB a moment ago: L2 / Infinity Cache) - kept in 84 registers beside the accumulators it spilled 70 - 150 of them; the dgamma /
-        // dbeta sums leave before the second phase starts, gamma and rstd are read again where they are used.
+        // x is needed on both sides of the row reduction.  Read twice from global memory by 84-accumulator lanes it cost 60 - 90 us per launch
+        // (tools/rowp_epi_cost.py: one row fragment of loads in flight at a time, ~40 registers in scratch), three times the forward epilogue.
+        // Now the tile's x rows (<= 100 x 1536 B: the launcher caps the tile height of this mode) are fetched ONCE, by LDS-DMA into the free ring:
+        // 19 instructions per thread, all in flight at once, no registers; both phases read them from LDS (16-byte chunk c of row r sits at
+        // position c ^ (r & 15): the 16 rows of a fragment read hit 16 different bank groups).  The residual gradient is folded in BEFORE the
+        // reduction (u = rs g + res, prefetched two row fragments ahead), so the second phase touches no global memory but its output:
+        //   dx = u - rs (c1 + h c2)
         const float invN = 1.0f / (float)RP_N;
-        const float* __restrict__ xin = (const float*)p.aux;
+        const char* gX = rp_uniform_ptr(p.aux);
+        {
+            const unsigned nchunk = (unsigned)rows * 96u;
+#pragma unroll 1
+            for (int n = 0; n < RP_XDMA; ++n) {
+                unsigned q = (unsigned)n * 512u + (unsigned)tid;
+                q = q < nchunk ? q : nchunk - 1;
+                const unsigned r = q / 96u, c = (q % 96u) ^ (r & 15u);
+                rp_dma16((unsigned)(m0 + (int)r) * (unsigned)(p.ldaux * 4) + 16u * c, gX,
+                         __builtin_amdgcn_readfirstlane(lbase + ((unsigned)n * 512u + (unsigned)wave * 64u) * 16u));
+            }
+        }
+        asm volatile("" : "+s"(m0e));
+        fresh_lane();
         const float* __restrict__ gamp = p.gamma;
-        float s1[RP_MF], s2[RP_MF];
+        const bf16* __restrict__ rest = (const bf16*)p.res_t;
+        f32x4v gm[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gm[j] = *(const f32x4v*)(gamp + ncol0 + 16 * j);
+        float mu[RP_MF], rsd[RP_MF];
+#pragma unroll
+        for (int i = 0; i < RP_MF; ++i) {
+            const unsigned m = (unsigned)row_of(i);
+            mu[i] = p.mean[m];
+            rsd[i] = p.rstd[m];
+        }
+        // residual gradient of row fragment i -> rq[i % 3] (f32 rows, or the operand-type copy: hi + lo)
+        int xlaunder = 0;                                              // (opaque zero, refreshed before the second phase: its reads of x must not
+                                                                       // be merged with the first phase's - that kept 84 values of h alive, in scratch)
+        auto x_lds = [&](int i, int j) __attribute__((always_inline)) {
+            int r = 16 * i + fre;
+            r = r < rows ? r : rows - 1;
+            const int c = (12 * wave + 4 * j + fqe) ^ (r & 15);
+            return *(const f32x4v*)(lds + xlaunder + r * 1536 + 16 * c);
+        };
         // one column quantity: sum over the 16 row lanes, then out (a column belongs to exactly one wave)
         auto col_out = [&](float (&cv)[3][4], int q, float* dst) __attribute__((always_inline)) {
 #pragma unroll
@@ -530,8 +570,42 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
                     for (int r = 0; r < 4; ++r) atomicAdd(dst + ncol0 + 16 * j + r, cv[j][r]);
             }
         };
-        fresh_lane();
-        {
+        float s1[RP_MF], s2[RP_MF];
+        // phase 1, instantiated per residual-gradient kind (0 none, 1 f32 rows, 2 the operand-type copy hi + lo): a run-time test per
+        // element turned the phase into 400 branches and 100 spilled registers
+        auto phase1 = [&](auto kind) __attribute__((always_inline)) {
+            constexpr int KIND = decltype(kind)::value;
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            u32x4 rq[3][3];                                            // 16 bytes either way: 4 floats, or 4 hi + 4 lo bf16
+            auto res_load = [&](int i) __attribute__((always_inline)) {
+                if constexpr (KIND != 0) {
+                    const unsigned m = (unsigned)row_of(i);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int n = ncol0 + 16 * j;
+                        if constexpr (KIND == 1) {
+                            rq[i % 3][j] = *(const u32x4 __attribute__((may_alias))*)(p.res + m * (unsigned)p.ldres + n);
+                        } else {
+                            const bf16* rp2 = rest + m * (unsigned)p.ldres_t + 64 * (n >> 5) + (n & 31);
+                            const u32x2 hv = *(const u32x2 __attribute__((may_alias))*)rp2, lv = *(const u32x2 __attribute__((may_alias))*)(rp2 + 32);
+                            rq[i % 3][j][0] = hv[0];
+                            rq[i % 3][j][1] = hv[1];
+                            rq[i % 3][j][2] = lv[0];
+                            rq[i % 3][j][3] = lv[1];
+                        }
+                    }
+                }
+            };
+            auto res_val = [&](const u32x4& q, int r) __attribute__((always_inline)) {
+                if constexpr (KIND == 0) return 0.f;
+                if constexpr (KIND == 1) return __uint_as_float(q[r]);
+                const unsigned h = q[r >> 1], l = q[2 + (r >> 1)];
+                return __uint_as_float((r & 1) ? (h & 0xffff0000u) : (h << 16)) + __uint_as_float((r & 1) ? (l & 0xffff0000u) : (l << 16));
+            };
+            res_load(0);
+            res_load(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                           // every wave's x pieces have landed
             float cg[3][4], cb[3][4];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -539,22 +613,25 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
                 for (int r = 0; r < 4; ++r) cg[j][r] = cb[j][r] = 0.f;
 #pragma unroll
             for (int i = 0; i < RP_MF; ++i) {
-                const unsigned m = (unsigned)row_of(i);
+                if (i + 2 < RP_MF) res_load(i + 2);
                 const bool ok = 16 * i + fre < rows;
-                const float mu = p.mean[m], rs = p.rstd[m];
                 float a1 = 0.f, a2 = 0.f;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const f32x4v xv = *(const f32x4v*)(xin + m * (unsigned)p.ldaux + ncol0 + 16 * j);
-                    const f32x4v gm = *(const f32x4v*)(gamp + ncol0 + 16 * j);
+                    const f32x4v xv = x_lds(i, j);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float h = (xv[r] - mu) * rs, dy = acc[i][j][r], g = dy * gm[r];
+                        const float h = (xv[r] - mu[i]) * rsd[i], dy = acc[i][j][r], g = dy * gm[j][r];
                         a1 += g;
                         a2 += g * h;
                         cg[j][r] += ok ? dy * h : 0.f;
                         cb[j][r] += ok ? dy : 0.f;
+                        acc[i][j][r] = rsd[i] * g + res_val(rq[i % 3][j], r);
                     }
+                    // pinned here: left alone, the compiler sinks these updates behind the reduction (next to their uses) and carries h of
+                    // every element there - through scratch
+                    asm volatile("" : "+v"(a1), "+v"(a2), "+v"(acc[i][j]));
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 s1[i] = a1;
                 s2[i] = a2;
@@ -562,51 +639,38 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
             }
             col_out(cg, 0, p.cs0);
             col_out(cb, 1, p.cs1);
-        }
+        };
+        if (p.res) phase1(std::integral_constant<int, 1>{});
+        else if (rest) phase1(std::integral_constant<int, 2>{});
+        else phase1(std::integral_constant<int, 0>{});
         row_total2(s1, s2);
+        asm volatile("" : "+v"(xlaunder));
+        fresh_lane();
         float* dxo = (float*)p.out0;
-        const bf16* __restrict__ rest = (const bf16*)p.res_t;
         float cx[3][4];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) cx[j][r] = 0.f;
-        const float* gam2 = gamp;
-        const float* xin2 = xin;
-        asm volatile("" : "+s"(gam2), "+s"(xin2), "+s"(m0e));
-        fresh_lane();                     // (fresh reads of gamma and x: nothing carried across the reduction)
 #pragma unroll
         for (int i = 0; i < RP_MF; ++i) {
-            const unsigned m = (unsigned)row_of(i);
             const bool ok = 16 * i + fre < rows;
-            const float c1 = s1[i] * invN, c2 = s2[i] * invN, rs = p.rstd[m], mu = p.mean[m];
+            const float k1 = rsd[i] * s1[i] * invN, k2 = rsd[i] * s2[i] * invN;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int n = ncol0 + 16 * j;
-                const f32x4v gm = *(const f32x4v*)(gam2 + n);
-                f32x4v rv = {0.f, 0.f, 0.f, 0.f};
-                if (p.res) {
-                    rv = *(const f32x4v*)(p.res + m * (unsigned)p.ldres + n);
-                } else if (rest) {                                      // residual gradient in the operand type: hi + lo
-                    const bf16* rp2 = rest + m * (unsigned)p.ldres_t + 64 * (n >> 5) + (n & 31);
-                    const bf16x4 hv = *(const bf16x4*)rp2, lv = *(const bf16x4*)(rp2 + 32);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) rv[r] = (float)hv[r] + (float)lv[r];
-                }
-                const f32x4v xv = *(const f32x4v*)(xin2 + m * (unsigned)p.ldaux + n);
+                const f32x4v xv = x_lds(i, j);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float dx = rs * (acc[i][j][r] * gm[r] - c1 - (xv[r] - mu) * rs * c2) + rv[r];
+                    const float dx = acc[i][j][r] - (k1 + (xv[r] - mu[i]) * rsd[i] * k2);
                     acc[i][j][r] = dx;
                     cx[j][r] += ok ? dx : 0.f;
                 }
-                if (dxo) *(f32x4v*)(dxo + m * (unsigned)p.ldo0 + n) = acc[i][j];
+                if (dxo) *(f32x4v*)(dxo + (unsigned)row_of(i) * (unsigned)p.ldo0 + ncol0 + 16 * j) = acc[i][j];
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         col_out(cx, 2, p.cs2);
         if (p.out1) {
-            __syncthreads();
+            __syncthreads();                                           // x is dead: the ring turns into the staging buffer of the split rows
             store_split(p.out1, p.ldo1, 0, 4);
             store_split(p.out1, p.ldo1, 4, RP_MF);
         }
@@ -624,14 +688,15 @@ int rp_cus() {
 }
 
 // rows per tile: the smallest whole number of rounds of one tile per CU that covers M with tiles of at most 112 rows, rows spread evenly
-int rp_rows_per_tile(int M) {
+int rp_rows_per_tile(int M, int cap = RP_TH) {
     const int cus = rp_cus();
-    const int rounds = (M + cus * RP_TH - 1) / (cus * RP_TH);
+    const int rounds = (M + cus * cap - 1) / (cus * cap);
     return (M + cus * rounds - 1) / (cus * rounds);
 }
+template <int MODE> constexpr int rp_cap() { return MODE == REPI_LNBWD_RES ? RP_XROWS : RP_TH; }
 
 template <int MODE> int launch_rowp(const GemmP& p, hipStream_t st) {
-    const int rpt = rp_rows_per_tile(p.M);
+    const int rpt = rp_rows_per_tile(p.M, rp_cap<MODE>());
     const int grid = (p.M + rpt - 1) / rpt;
     static bool attr = false;
     if (!attr) {
@@ -641,18 +706,19 @@ template <int MODE> int launch_rowp(const GemmP& p, hipStream_t st) {
     ProfScope ps(MODE >= RP_TILE ? PROF_GEMM_TILE : (MODE == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD), 2.0 * p.M * p.N * p.K, 0, st);
     GemmP q = p;
     if (MODE >= RP_TILE) { const char* e = getenv("MFVIT_ROWT_NOSTORE"); q.rows_per_wg = (e && atoi(e)) ? 77 : 0; }
+    else { const char* e = getenv("MFVIT_ROWP_NOEPI"); q.rows_per_wg = (e && atoi(e)) ? 78 : 0; }
     MFVIT_LAUNCH((gemm_rowp_kernel<MODE>), dim3(grid), dim3(512), RP_LDS, st, q, rpt, p.N / RP_N);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
 
-// MFVIT_ROWP: 0 off, 1 (default) the forward epilogue (+ bias + residual -> LayerNorm), 2 the LayerNorm-backward epilogue as well.  Read at
-// every launch (A/B runs in one process).  Measured inside the training step (serialized pass, rocprofv3 kernel durations, M = 25,216):
-// forward proj + LN 56 -> 54 us, fc2 + LN 140 -> 105 us; backward fc1-dgrad 139 -> 137 us, qkv-dgrad 112 -> 119 us (its epilogue reads x twice
-// and spills ~40 registers beside 84 accumulators): the backward stays with gemm_nt_row until that is fixed.
+// MFVIT_ROWP: 0 off, 1 the forward epilogue only (+ bias + residual -> LayerNorm), 2 (default) the LayerNorm-backward epilogue as well.  Read at
+// every launch (A/B runs in one process).  Measured inside the training step (serialized pass, M = 25,216): forward proj + LN 56 -> 54 us,
+// fc2 + LN 140 -> 105 us; backward class average (fc1-dgrad + qkv-dgrad) 125 -> 95 us once the epilogue fetched x by LDS-DMA (before that
+// 137 / 119 us against 139 / 112 us of gemm_nt_row); whole step 33.85 -> 32.21 ms (profiles/r03_rowp_ab.txt).
 int rowp_mode() {
     const char* e = getenv("MFVIT_ROWP");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 2;
 }
 
 }  // namespace
@@ -665,6 +731,7 @@ bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
     if (p.orow_in || p.res_mod || p.rows_per_wg) return false;                  // patch-embedding row remap stays with gemm_nt_row
     if (repi == REPI_LNBWD_RES) {
         if (!p.aux || !p.mean || !p.rstd || !p.gamma || p.ldaux % 4 || (size_t)p.aux % 16 || (size_t)p.gamma % 16) return false;
+        if ((unsigned long long)p.M * p.ldaux * 4 >= (1ull << 32)) return false;                                      // 32-bit LDS-DMA offsets into x
         if ((p.out0 && (p.ldo0 % 4 || (size_t)p.out0 % 16)) || (p.out1 && (p.ldo1 % 8 || (size_t)p.out1 % 16))) return false;
         if ((p.res && (p.ldres % 4 || (size_t)p.res % 16)) || (p.res_t && (p.ldres_t % 8 || (size_t)p.res_t % 16))) return false;
         if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 32) || (unsigned long long)p.N * p.ldw * 2 >= (1ull << 32)) return false;
@@ -713,7 +780,7 @@ int gemm_nt_rowp(int repi, const GemmP& p, hipStream_t st) {
     if (repi == REPI_LNBWD_RES) {
         const int rc = launch_rowp<REPI_LNBWD_RES>(p, st);
         if (rc != MFVIT_OK || !p.cpart) return rc;
-        const int rpt = rp_rows_per_tile(p.M);
+        const int rpt = rp_rows_per_tile(p.M, RP_XROWS);
         return colpart_reduce(p.cpart, (p.M + rpt - 1) / rpt, RP_N, 3, p.cs0, p.cs1, p.cs2, st);   // [tile][3][384] partials -> dgamma, dbeta, dcol
     }
     return MFVIT_EINVAL;

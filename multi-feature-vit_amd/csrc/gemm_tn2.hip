@@ -10,8 +10,14 @@
 //     per 16 lanes) stay conflict-free because the 16-B chunks of row m are XOR-swizzled by 4 * (m & 3) - applied on the SOURCE
 //     address of the DMA and on the read address (same involution on both sides).
 //   * one workgroup per CU and launch wave (96 KB of LDS): tiles x splits <= 256.
+//   * W8 (round 3, default): EIGHT waves per workgroup.  Waves 4 - 7 own the same four 64 x 64 quadrants as waves 0 - 3 and take the second
+//     half of every stage's reduction rows; the two halves are added through LDS (the ring is free by then) before the float atomics.  The
+//     tile, the LDS traffic and the L2 traffic are unchanged - what changes is that every SIMD holds two MFMA-issuing waves instead of one, so
+//     one wave's transposing fragment reads hide behind the other's MFMAs (MFVIT_TN2_W8=0 restores four waves).
 //   * a split's last stage may be partial: its rows past the end are fetched clamped (finite data) and the A-operand rows are
 //     zeroed in LDS before use, so they add nothing.
+#include <stdlib.h>
+
 #include <type_traits>
 #include "gemm.cuh"
 #include "kernels.h"
@@ -22,9 +28,9 @@ namespace mfvit {
 namespace {
 
 constexpr int T2_NS = 3;
+constexpr int T2_NSP = 4;                       // ring slots of the pipelined form (split bf16, eight waves): three stages in flight
 constexpr int T2_TILE = 16 * 1024;              // bytes per operand and stage (KR rows x TW columns x 2 B)
 constexpr int T2_STAGE = 2 * T2_TILE;           // 32 KB
-constexpr int T2_LPS = 8;                       // LDS-DMA instructions per wave and stage (4 per operand)
 
 // Tile geometry by element type.  Plain 16-bit types: 128 x 128 output tile, 64 reduction rows per stage.  Split bf16 (sbf16): the
 // operand tiles are 256 STORAGE columns wide = 128 logical columns as [hi x 32 | lo x 32] groups, 32 reduction rows per stage (the
@@ -70,9 +76,12 @@ template <typename T> __device__ __forceinline__ typename Vec8<T>::type t2_frag(
 }
 
 // T = bf16 | f16 | sbf16 (split bf16, see T2Geo)
-template <typename T, bool CS>
-__global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
+template <typename T, bool CS, bool W8, bool IL>
+__global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
     typedef T2Geo<T> G;
+    constexpr int NWV = W8 ? 8 : 4;                          // waves
+    constexpr int NI = 16 / NWV;                             // LDS-DMA instructions per wave, operand and stage
+    constexpr int T2_LPS = 2 * NI;
     constexpr bool SPLIT = G::SPLIT;
     constexpr int EP = elems_per<T>::value, TW = G::TW, KR = G::KR, ROWB = G::ROWB, CPR = G::CPR, RPI = G::RPI, NF = G::NF;
     constexpr int NL = 2;                                    // 32 x 32 LOGICAL output tiles per wave and dimension
@@ -80,7 +89,8 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
     typedef typename Vec4<T>::elem E16;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wq = wave & 3, kh = wave >> 2;                 // output quadrant; half of the stage's reduction rows (W8)
+    const int wm = wq >> 1, wn = wq & 1;
     const int ntk = p.K * EP / TW;
     const int tiles = ntk * (p.N * EP / TW);
     const int lin = xcd_remap(blockIdx.x, gridDim.x);        // each XCD gets a contiguous run of the split-major block order
@@ -95,26 +105,40 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
     const E16* A = (const E16*)p.A;
     const E16* X = (const E16*)p.W;
 
-    // LDS-DMA g = wave + 4 i (i = 0..3) of an operand fills rows RPI g .. RPI g + RPI - 1: lane -> row RPI g + lane / CPR, chunk
-    // position lane % CPR, which receives source chunk (lane % CPR) ^ (4 * (row & 3))   (4 RPI i is a multiple of 4)
-    const int lrow = RPI * wave + lane / CPR;                // + 4 RPI i
+    // LDS-DMA g = wave + NWV i (i = 0 .. NI-1) of an operand fills rows RPI g .. RPI g + RPI - 1: lane -> row RPI g + lane / CPR, chunk
+    // position lane % CPR, which receives source chunk (lane % CPR) ^ (4 * (row & 3))   (NWV RPI i is a multiple of 4)
+    const int lrow = RPI * wave + lane / CPR;                // + NWV RPI i
     const int lch = (lane % CPR) ^ (4 * (lrow & 3));
     const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (unsigned)wave * 1024u);
     auto issue = [&](int st, int slot) {
         const unsigned sa = lbase + (unsigned)slot * T2_STAGE, sb = sa + T2_TILE;
         const int mrow = mbeg + st * KR + lrow;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int m = mrow + 4 * RPI * i;
+        for (int i = 0; i < NI; ++i) {
+            int m = mrow + NWV * RPI * i;
             m = m < p.M ? m : p.M - 1;                        // never read past the tensor (clamped rows are zeroed below)
-            t2_glds16(A + (long)m * p.lda + n0 + lch * 8, sa + i * 4096);
+            t2_glds16(A + (long)m * p.lda + n0 + lch * 8, sa + i * NWV * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int m = mrow + 4 * RPI * i;
+        for (int i = 0; i < NI; ++i) {
+            int m = mrow + NWV * RPI * i;
             m = m < p.M ? m : p.M - 1;
-            t2_glds16(X + (long)m * p.ldw + k0 + lch * 8, sb + i * 4096);
+            t2_glds16(X + (long)m * p.ldw + k0 + lch * 8, sb + i * NWV * 1024);
         }
+    };
+
+    // IL: the same instructions ONE at a time, spread between the MFMAs of the stage (d = 0 .. 2 NI - 1: A pieces, then X pieces).  Issued
+    // in one burst behind the barrier they hold the wave's instruction stream for the ~500 cycles the CU's vector-memory path needs to take
+    // 32 KB - with the matrix pipe idle: DMA phase + MFMA phase = the measured 2.1 x of the MFMA time per stage.  Stages past the end of
+    // the split re-fetch its last stage into the free slot (harmless; no branch in the MFMA stream).
+    auto dma_one = [&](int st, int slot, int d) __attribute__((always_inline)) {
+        const int stc = st < nst ? st : nst - 1;
+        const int i = d % NI;
+        int m = mbeg + stc * KR + lrow + NWV * RPI * i;
+        m = m < p.M ? m : p.M - 1;
+        const unsigned dst = lbase + (unsigned)slot * T2_STAGE + (d >= NI ? T2_TILE : 0) + i * NWV * 1024;
+        if (d < NI) t2_glds16(A + (long)m * p.lda + n0 + lch * 8, dst);
+        else t2_glds16(X + (long)m * p.ldw + k0 + lch * 8, dst);
     };
 
     f32x16 acc[NL][NL], bacc[NL];
@@ -130,91 +154,207 @@ __global__ __launch_bounds__(256) void gemm_tn_glds_kernel(GemmP p) {
     frag_t ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (E16)1.0f;
-    const bool do_cs = CS && k0 == 0 && wn == 0;             // column sums of A (= bias gradient): k-tile 0, wn 0 waves
+    const bool do_cs = CS && k0 == 0 && wn == 0;             // column sums of A (= bias gradient): k-tile 0, wn 0 waves (each k half its own rows)
 
     // the bias-column-sum MFMAs are selected ONCE per wave (template flag), not per k-step: a branch inside the hot loop splits it
     // into basic blocks and serialises the ds_read -> MFMA pipeline (measured: 72 vs 52 us on the kernels that carry a bias sum)
+    // Split bf16, eight waves, interleaved issue ("pipelined" form): the stage barrier sits in the MIDDLE of the stage.  A wave enters stage st
+    // with its 8 fragments already in registers and starts on the MFMAs at once; behind MFMA 6 it waits for stage st + 1 (requested a stage
+    // earlier), meets the other waves, and then reads the fragments of stage st + 1 into the second register set BETWEEN MFMAs 7 - 12.  The
+    // barrier -> 16 transposing reads -> first MFMA chain of the plain form (every wave of the CU in that phase at the same time, the matrix
+    // pipe idle) is gone; the LDS-DMA pieces of stage st + 2 go out one per three MFMAs as before.
+    auto main_loop_pipe = [&](auto cs_tag) {
+        constexpr bool WITH_CS = decltype(cs_tag)::value;
+        static_assert(!(SPLIT && W8 && IL) || (KR == 32 && NF == 4 && NI == 2), "pipelined wgrad loop: geometry");
+        frag_t fa[2][NF], fb[2][NF];
+        auto zero_partial = [&](int st_, int slot_) __attribute__((always_inline)) {
+            const int valid = mend - mbeg - st_ * KR;            // rows of the stage inside the split
+            if (valid < KR) {                                    // partial last stage: zero the A rows past the end (block-uniform branch)
+                char* ta = lds + slot_ * T2_STAGE;
+                for (int q = tid; q < (KR - valid) * CPR; q += NWV * 64)
+                    *(uint4*)(ta + (valid + q / CPR) * ROWB + (q % CPR) * 16) = make_uint4(0, 0, 0, 0);
+                __syncthreads();
+            }
+        };
+        auto load_one = [&](auto set_tag, int slot_, int q) __attribute__((always_inline)) {
+            constexpr int SET = decltype(set_tag)::value;
+            const char* ta = lds + slot_ * T2_STAGE;
+            if (q < NF) fa[SET][q] = t2_frag<T>(ta, (wm * NF + q) * 32, kh, lane);
+            else fb[SET][q - NF] = t2_frag<T>(ta + T2_TILE, (wn * NF + q - NF) * 32, kh, lane);
+        };
+        auto mfma_t = [&](auto set_tag, int t) __attribute__((always_inline)) {
+            constexpr int SET = decltype(set_tag)::value;
+            const int term = t / (NL * NL), i = (t % (NL * NL)) / NL, j = t % NL;
+            acc[i][j] = MmaTraits<T>::mma(fa[SET][2 * i + (term == 0 ? 1 : 0)], fb[SET][2 * j + (term == 1 ? 1 : 0)], acc[i][j]);
+        };
+        auto stage = [&](int st, auto set_tag, auto nset_tag, int slot) __attribute__((always_inline)) {
+            const int nslot = slot == 0 ? T2_NSP - 1 : slot - 1; // slot of stage st + 3 = that of st - 1: its last readers passed the previous mid-stage barrier
+            const int rslot = slot == T2_NSP - 1 ? 0 : slot + 1; // slot of stage st + 1
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                mfma_t(set_tag, t);
+                if (t == 2) dma_one(st + T2_NSP - 1, nslot, 0);
+                if (t == 5) dma_one(st + T2_NSP - 1, nslot, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            t2_wait_vm<2 + (T2_NSP - 3) * T2_LPS>();             // all but the two pieces just issued and stage st + 2's: stage st + 1 has landed
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 < nst) zero_partial(st + 1, rslot);
+#pragma unroll
+            for (int t = 6; t < 12; ++t) {
+                mfma_t(set_tag, t);
+                // 8 fragment reads of stage st + 1 (past the end: a stale slot, never used) and the other two LDS-DMA pieces
+                if (t == 6) { load_one(nset_tag, rslot, 0); load_one(nset_tag, rslot, 1); }
+                if (t == 7) { load_one(nset_tag, rslot, 2); dma_one(st + T2_NSP - 1, nslot, 2); }
+                if (t == 8) { load_one(nset_tag, rslot, 3); load_one(nset_tag, rslot, 4); }
+                if (t == 9) { load_one(nset_tag, rslot, 5); dma_one(st + T2_NSP - 1, nslot, 3); }
+                if (t == 10) load_one(nset_tag, rslot, 6);
+                if (t == 11) load_one(nset_tag, rslot, 7);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (WITH_CS) {
+                constexpr int SET = decltype(set_tag)::value;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    bacc[i] = MmaTraits<T>::mma(fa[SET][2 * i], ones, bacc[i]);
+                    bacc[i] = MmaTraits<T>::mma(fa[SET][2 * i + 1], ones, bacc[i]);
+                }
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < T2_NSP - 1; ++q) issue(q < nst ? q : nst - 1, q);
+        t2_wait_vm<(T2_NSP - 2) * T2_LPS>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        zero_partial(0, 0);
+#pragma unroll
+        for (int q = 0; q < 2 * NF; ++q) load_one(std::integral_constant<int, 0>{}, 0, q);
+        int slot = 0;
+        for (int st = 0; st < nst; st += 2) {
+            stage(st, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, slot);
+            slot = slot == T2_NSP - 1 ? 0 : slot + 1;
+            if (st + 1 < nst) {
+                stage(st + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, slot);
+                slot = slot == T2_NSP - 1 ? 0 : slot + 1;
+            }
+        }
+        t2_wait_vm<0>();                                         // the refills behind the end have landed too (the ring is reused below)
+    };
     auto main_loop = [&](auto cs_tag) {
         constexpr bool WITH_CS = decltype(cs_tag)::value;
         issue(0, 0);
-        if (nst > 1) issue(1, 1);
+        if (IL || nst > 1) issue(nst > 1 ? 1 : 0, 1);
         int slot = 0;
         for (int st = 0; st < nst; ++st) {
-            if (st + 1 < nst) t2_wait_vm<T2_LPS>();              // stage st landed; stage st+1 may stay in flight
+            if (IL || st + 1 < nst) t2_wait_vm<T2_LPS>();        // stage st landed; stage st+1 (IL: or the refill behind the end) may stay in flight
             else t2_wait_vm<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (st + 2 < nst) issue(st + 2, slot == 0 ? 2 : slot - 1);      // (st + 2) % 3: read last in step st-1, free since the barrier
+            const int nslot = slot == 0 ? 2 : slot - 1;          // (st + 2) % 3: read last in step st-1, free since the barrier
+            if constexpr (!IL)
+                if (st + 2 < nst) issue(st + 2, nslot);
             char* ta = lds + slot * T2_STAGE;
             const char* tb = ta + T2_TILE;
             const int valid = mend - mbeg - st * KR;             // rows of this stage inside the split
             if (valid < KR) {                                    // partial last stage: zero the A rows past the end (block-uniform branch)
-                for (int q = tid; q < (KR - valid) * CPR; q += 256)
+                for (int q = tid; q < (KR - valid) * CPR; q += NWV * 64)
                     *(uint4*)(ta + (valid + q / CPR) * ROWB + (q % CPR) * 16) = make_uint4(0, 0, 0, 0);
                 __syncthreads();
             }
+            constexpr int KS = KR / 16 / (W8 ? 2 : 1);          // k steps of 16 rows per wave and stage
+            const int sb0 = W8 ? kh * KS : 0;                    // first k step of this wave
             frag_t a[2][NF], b[2][NF];
 #pragma unroll
-            for (int i = 0; i < NF; ++i) a[0][i] = t2_frag<T>(ta, (wm * NF + i) * 32, 0, lane);
+            for (int i = 0; i < NF; ++i) a[0][i] = t2_frag<T>(ta, (wm * NF + i) * 32, sb0, lane);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) b[0][j] = t2_frag<T>(tb, (wn * NF + j) * 32, 0, lane);
+            for (int j = 0; j < NF; ++j) b[0][j] = t2_frag<T>(tb, (wn * NF + j) * 32, sb0, lane);
 #pragma unroll
-            for (int s = 0; s < KR / 16; ++s) {
-                if (s + 1 < KR / 16) {
+            for (int s = 0; s < KS; ++s) {
+                if (s + 1 < KS) {
 #pragma unroll
-                    for (int i = 0; i < NF; ++i) a[(s + 1) & 1][i] = t2_frag<T>(ta, (wm * NF + i) * 32, s + 1, lane);
+                    for (int i = 0; i < NF; ++i) a[(s + 1) & 1][i] = t2_frag<T>(ta, (wm * NF + i) * 32, sb0 + s + 1, lane);
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) b[(s + 1) & 1][j] = t2_frag<T>(tb, (wn * NF + j) * 32, s + 1, lane);
+                    for (int j = 0; j < NF; ++j) b[(s + 1) & 1][j] = t2_frag<T>(tb, (wn * NF + j) * 32, sb0 + s + 1, lane);
                 }
-                if constexpr (SPLIT) {   // fragments 2 l / 2 l + 1 = hi / lo part of logical group l
+                // product MFMAs of this k step, one at a time (t): split bf16 - fragments 2 l / 2 l + 1 = hi / lo part of logical group l,
+                // terms a_lo b_hi, a_hi b_lo, a_hi b_hi over the 2 x 2 tiles; plain types - the 2 x 2 tiles
+                constexpr int MPK = SPLIT ? 3 * NL * NL : NL * NL;
+                constexpr int NM = KS * MPK, ND = 2 * NI;
 #pragma unroll
-                    for (int i = 0; i < NL; ++i)
+                for (int t = 0; t < MPK; ++t) {
+                    const int term = t / (NL * NL), i = (t % (NL * NL)) / NL, j = t % NL;
+                    if constexpr (SPLIT)
+                        acc[i][j] = MmaTraits<T>::mma(a[s & 1][2 * i + (term == 0 ? 1 : 0)], b[s & 1][2 * j + (term == 1 ? 1 : 0)], acc[i][j]);
+                    else
+                        acc[i][j] = MmaTraits<T>::mma(a[s & 1][i], b[s & 1][j], acc[i][j]);
+                    if constexpr (IL) {
+                        const int m = s * MPK + t;
+                        if ((m + 1) * ND / NM != m * ND / NM) dma_one(st + 2, nslot, m * ND / NM);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if constexpr (WITH_CS) {
 #pragma unroll
-                        for (int j = 0; j < NL; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][2 * i + 1], b[s & 1][2 * j], acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < NL; ++i)
-#pragma unroll
-                        for (int j = 0; j < NL; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][2 * i], b[s & 1][2 * j + 1], acc[i][j]);
-#pragma unroll
-                    for (int i = 0; i < NL; ++i)
-#pragma unroll
-                        for (int j = 0; j < NL; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][2 * i], b[s & 1][2 * j], acc[i][j]);
-                    if constexpr (WITH_CS) {
-#pragma unroll
-                        for (int i = 0; i < NL; ++i) {
+                    for (int i = 0; i < NL; ++i) {
+                        if constexpr (SPLIT) {
                             bacc[i] = MmaTraits<T>::mma(a[s & 1][2 * i], ones, bacc[i]);
                             bacc[i] = MmaTraits<T>::mma(a[s & 1][2 * i + 1], ones, bacc[i]);
+                        } else {
+                            bacc[i] = MmaTraits<T>::mma(a[s & 1][i], ones, bacc[i]);
                         }
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NL; ++i)
-#pragma unroll
-                        for (int j = 0; j < NL; ++j) acc[i][j] = MmaTraits<T>::mma(a[s & 1][i], b[s & 1][j], acc[i][j]);
-                    if constexpr (WITH_CS) {
-#pragma unroll
-                        for (int i = 0; i < NL; ++i) bacc[i] = MmaTraits<T>::mma(a[s & 1][i], ones, bacc[i]);
                     }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the slot are done before it reaches the next barrier
             slot = slot == T2_NS - 1 ? 0 : slot + 1;
         }
+        if constexpr (IL) t2_wait_vm<0>();                       // the refills behind the end have landed too (the ring is reused below)
     };
-    if (do_cs) main_loop(std::true_type{});
-    else main_loop(std::false_type{});
+    if constexpr (SPLIT && W8 && IL) {
+        if (do_cs) main_loop_pipe(std::true_type{});
+        else main_loop_pipe(std::false_type{});
+    } else {
+        if (do_cs) main_loop(std::true_type{});
+        else main_loop(std::false_type{});
+    }
     const int nw = n0 / EP + wm * 64, kw = k0 / EP + wn * 64;   // LOGICAL origin of this wave's 64 x 64 tile
     float* out = (float*)p.out0;
+    if constexpr (W8) {
+        // the second k half hands its 64 x 64 quadrant to the first through LDS (4 quadrants x 4 tiles x 16 registers x 64 lanes x 4 B = 64 KB
+        // of the ring: every wave is past its last fragment read and every LDS-DMA has landed)
+        __syncthreads();
+        float* xch = (float*)lds + (size_t)wq * (NL * NL * 16 * 64) + lane;
+        if (kh == 1) {
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
+            for (int i = 0; i < NL; ++i)
 #pragma unroll
-        for (int j = 0; j < NL; ++j)
+                for (int j = 0; j < NL; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = nw + i * 32 + acc_row(r, lane);
-                const int k = kw + j * 32 + (lane & 31);
-                atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
-            }
+                    for (int r = 0; r < 16; ++r) xch[((i * NL + j) * 16 + r) * 64] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+#pragma unroll
+                for (int j = 0; j < NL; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * NL + j) * 16 + r) * 64];
+        }
+    }
+    if (!W8 || kh == 0) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+#pragma unroll
+            for (int j = 0; j < NL; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nw + i * 32 + acc_row(r, lane);
+                    const int k = kw + j * 32 + (lane & 31);
+                    atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
+                }
+    }
     if (CS) {
         if (do_cs && (lane & 31) == 0) {
 #pragma unroll
@@ -244,18 +384,30 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
         const int maxs = (p.M + 4 * G::KR - 1) / (4 * G::KR);
         p.splits = s < 1 ? 1 : (s > maxs ? maxs : s);
     }
-    constexpr int bytes = T2_NS * T2_STAGE;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        attr = true;
-    }
+    constexpr int bytes = (is_split<T>::value ? T2_NSP : T2_NS) * T2_STAGE;   // (the pipelined form's ring; the other split forms use three of the four slots)
+    const char* e8 = getenv("MFVIT_TN2_W8");                 // both read at every launch (A/B runs in one process)
+    const char* eil = getenv("MFVIT_TN2_IL");
+    const bool w8 = !(e8 && atoi(e8) == 0), il = !(eil && atoi(eil) == 0);
     ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * p.N * p.K, 0, st);
-    if (p.cs0)
-        MFVIT_LAUNCH((gemm_tn_glds_kernel<T, true>), dim3(tiles * p.splits), dim3(256), bytes, st, p);
-    else
-        MFVIT_LAUNCH((gemm_tn_glds_kernel<T, false>), dim3(tiles * p.splits), dim3(256), bytes, st, p);
+    auto go = [&](auto cs, auto w, auto i) {
+        constexpr bool CS = decltype(cs)::value, W8 = decltype(w)::value, IL = decltype(i)::value;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<T, CS, W8, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            attr = true;
+        }
+        MFVIT_LAUNCH((gemm_tn_glds_kernel<T, CS, W8, IL>), dim3(tiles * p.splits), dim3(W8 ? 512 : 256), bytes, st, p);
+    };
+    auto go2 = [&](auto cs, auto w) {
+        if (il) go(cs, w, std::true_type{});
+        else go(cs, w, std::false_type{});
+    };
+    auto go1 = [&](auto cs) {
+        if (w8) go2(cs, std::true_type{});
+        else go2(cs, std::false_type{});
+    };
+    if (p.cs0) go1(std::true_type{});
+    else go1(std::false_type{});
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
