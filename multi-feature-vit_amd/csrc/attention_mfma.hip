@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<
 template <typename T, int PITCH>
 __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename Vec4<T>::elem* __restrict__ out,
                                                             const typename Vec4<T>::elem* __restrict__ dout, const float* __restrict__ lse,
-                                                            typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale) {
+                                                            typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale, int nbh) {
     typedef AttnT<T> A;
     typedef typename A::E E;
     typedef typename A::frag_t frag_t;
@@ -239,55 +239,102 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
     char* dOs = Vs + Tpad * PITCH;
     float* Ls = (float*)(dOs + Tpad * PITCH);
     float* Ds = Ls + Tpad;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);  // the heads of one image share an XCD: their row pieces share L2 lines
-    const int b = bid / H, h = bid % H;
+    // PERSISTENT over the (image, head) pairs: the workgroup's four LDS images (129 KB for split bf16) allow one workgroup per CU, so a
+    // workgroup per pair left every CU idle while its ~129 KB came in cold (measured: 6 rounds x ~6 us of the 148 us launch).  Now each
+    // workgroup walks through its pairs and fetches the NEXT pair's row pieces into registers (5 x 16 B per chunk, 4 chunks per thread)
+    // before it starts the two compute phases of the current one; they go to LDS when the phases are done.
+    const int npair = nbh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long hs = (long)H * HD * EP, rs = 3 * hs, os = hs;
-    const E* base = qkv + (long)b * Tn * rs + h * HD * EP;
-    E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
-    const E* obase = out + (long)b * Tn * os + h * HD * EP;
-    const E* dobase = dout + (long)b * Tn * os + h * HD * EP;
-    // one fused staging pass: the five loads of a row piece (Q, K, V, dO, O) are issued together - staged image by image, each image
-    // paid its own HBM round trip before the next one's loads went out (operands are cold inside the training step)
-    for (int q = threadIdx.x; q < Tpad * CPR; q += blockDim.x) {  // CPR lanes per row, 16 B each
-        const int t = q / CPR, cidx = q % CPR;
-        uint4 vq = make_uint4(0, 0, 0, 0), vk = vq, vv = vq, vd = vq;
-        float D = 0.f, L = -1e30f;                                 // padded queries: p = exp2(-1e30 c) = 0
-        if (t < Tn) {
-            const E* rp = base + (long)t * rs + 8 * cidx;
-            vq = *(const uint4*)rp;
-            vk = *(const uint4*)(rp + hs);
-            vv = *(const uint4*)(rp + 2 * hs);
-            vd = *(const uint4*)(dobase + (long)t * os + 8 * cidx);
-            if (cidx == 0) L = -lse[((long)b * H + h) * Tn + t] / scale;
-            if (cidx < 4) {   // D = sum_d dO[d] O[d]: the lane of (hi) chunk cidx covers 8 d's (split: both parts of dO and O)
-                union { uint4 u; frag_t b8; } cv;
-                cv.u = vd;
-                const frag_t o = *(const frag_t*)(obase + (long)t * os + 8 * cidx);
-                if constexpr (A::SP) {
-                    const frag_t dl = *(const frag_t*)(dobase + (long)t * os + 32 + 8 * cidx);
-                    const frag_t ol = *(const frag_t*)(obase + (long)t * os + 32 + 8 * cidx);
+    constexpr int NCH = 4;                                             // 16-byte chunks per thread and image (Tpad * CPR <= 4 * 512)
+    constexpr int RSTEP = 512 / CPR;                                   // rows between a thread's chunks
+    const int t0 = threadIdx.x / CPR, cidx = threadIdx.x % CPR;
+    uint4 pq[NCH], pk[NCH], pv[NCH], pd[NCH], po[NCH];
+    float pl[NCH];
+    auto fetch = [&](int vi) __attribute__((always_inline)) {
+        const int bid = xcd_remap(vi, npair);                          // the heads of one image share an XCD: their row pieces share L2 lines
+        const int b = bid / H, h = bid % H;
+        const E* base = qkv + (long)b * Tn * rs + h * HD * EP;
+        const E* obase = out + (long)b * Tn * os + h * HD * EP;
+        const E* dobase = dout + (long)b * Tn * os + h * HD * EP;
+        // chunk i of this thread: row t0 + RSTEP i, 16-byte piece cidx - ONE per-lane address per tensor, the rows of the other chunks are a
+        // uniform stride away (per-chunk addresses were spilled, and every scratch reload waits for ALL loads in flight: the prefetch ran
+        // one chunk at a time)
+        const E* rp = base + (long)t0 * rs + 8 * cidx;
+        const E* dp_ = dobase + (long)t0 * os + 8 * cidx;
+        const E* op_ = obase + (long)t0 * os + 8 * cidx;
+        const float* lp = lse + ((long)b * H + h) * Tn + t0;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) D = fmaf((float)cv.b8[j] + (float)dl[j], (float)o[j] + (float)ol[j], D);
-                } else {
+        for (int i = 0; i < NCH; ++i) {
+            pq[i] = pk[i] = pv[i] = pd[i] = po[i] = make_uint4(0, 0, 0, 0);
+            pl[i] = 1e30f;                                             // (raw lse; no arithmetic on a loaded value here: it would wait for the loads)
+            if (t0 + RSTEP * i < Tn) {                                 // (Tn <= Tpad <= RSTEP * NCH: checked by the launcher)
+                pq[i] = *(const uint4*)(rp + (long)(RSTEP * i) * rs);
+                pk[i] = *(const uint4*)(rp + (long)(RSTEP * i) * rs + hs);
+                pv[i] = *(const uint4*)(rp + (long)(RSTEP * i) * rs + 2 * hs);
+                pd[i] = *(const uint4*)(dp_ + (long)(RSTEP * i) * os);
+                po[i] = *(const uint4*)(op_ + (long)(RSTEP * i) * os);
+                if (cidx == 0) pl[i] = lp[RSTEP * i];
+            }
+        }
+    };
+    // registers -> LDS images; D = sum_d dO[d] O[d] per row (split: both parts of dO and O - lane cidx < 4 holds the hi parts of 8 d's, lane
+    // cidx + 4 the lo parts of the same d's)
+    float pD[NCH];
+    // D of the fetched rows (lane cidx == 0 holds it).  Split tensors: lane cidx < 4 holds the hi parts of 8 d's, lane cidx ^ 4 the lo parts of the
+    // same d's: every lane completes O = hi + lo with ONE exchange of its raw 16 bytes (4 cross-lane moves) and multiplies it with its own
+    // part of dO; the sum over the row's 8 lanes adds the hi and lo parts of dO.
+    auto reduce_D = [&]() __attribute__((always_inline)) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) D = fmaf((float)cv.b8[j], (float)o[j], D);
+        for (int i = 0; i < NCH; ++i) {
+            union { uint4 u; frag_t f; } cd, co, cx;
+            cd.u = pd[i];
+            co.u = po[i];
+            float of[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) of[j] = (float)co.f[j];
+            if constexpr (A::SP) {
+                cx.u.x = __shfl_xor(po[i].x, 4, 64);
+                cx.u.y = __shfl_xor(po[i].y, 4, 64);
+                cx.u.z = __shfl_xor(po[i].z, 4, 64);
+                cx.u.w = __shfl_xor(po[i].w, 4, 64);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) of[j] += (float)cx.f[j];
+            }
+            float D = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) D = fmaf((float)cd.f[j], of[j], D);
+            D += __shfl_xor(D, 1, 64);
+            D += __shfl_xor(D, 2, 64);
+            if constexpr (A::SP) D += __shfl_xor(D, 4, 64);
+            pD[i] = D;
+        }
+    };
+    auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int t = t0 + RSTEP * i;
+            if (t < Tpad) {
+                *(uint4*)(Qs + t * PITCH + 16 * cidx) = pq[i];
+                *(uint4*)(Ks + t * PITCH + 16 * cidx) = pk[i];
+                *(uint4*)(Vs + t * PITCH + 16 * cidx) = pv[i];
+                *(uint4*)(dOs + t * PITCH + 16 * cidx) = pd[i];
+                if (cidx == 0) {
+                    Ds[t] = -pD[i];
+                    Ls[t] = t < Tn ? -pl[i] / scale : -1e30f;          // padded queries: p = exp2(-1e30 c) = 0
                 }
             }
         }
-        *(uint4*)(Qs + t * PITCH + 16 * cidx) = vq;
-        *(uint4*)(Ks + t * PITCH + 16 * cidx) = vk;
-        *(uint4*)(Vs + t * PITCH + 16 * cidx) = vv;
-        *(uint4*)(dOs + t * PITCH + 16 * cidx) = vd;
-        D += __shfl_xor(D, 1, 64);
-        D += __shfl_xor(D, 2, 64);
-        if constexpr (A::SP) D += __shfl_xor(D, 4, 64);
-        if (cidx == 0) {
-            Ds[t] = -D;
-            Ls[t] = L;
-        }
-    }
+    };
+    fetch(blockIdx.x);
+    for (int vi = blockIdx.x; vi < npair; vi += gridDim.x) {
+    const int bid = xcd_remap(vi, npair);
+    const int b = bid / H, h = bid % H;
+    E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
+    reduce_D();
+    stage();
     __syncthreads();
+    if (vi + (int)gridDim.x < npair) fetch(vi + gridDim.x);
     const float c = scale * 1.4426950408889634f;
     const int nt = Tpad >> 5;
     // ---------------- phase A: dQ, wave = query tile
@@ -324,8 +371,12 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
                 dq = mma3<T>(tr_frag<T>(Ks, PITCH, kt * 32, s, lane, 0), tr_frag<T>(Ks, PITCH, kt * 32, s, lane, LO), sh, sl, dq);
             }
         }
-        const int q = qt * 32 + (lane & 31);
-        if (q < Tn) store_tile_T<T>(dbase + (long)q * rs, dq, scale, lane);
+        // (store addresses from a laundered lane id: carried across the persistent loop they were spilled, and the reload - placed right behind
+        // the prefetch - waited for every load in flight)
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        const int q = qt * 32 + (lane_s & 31);
+        if (q < Tn) store_tile_T<T>(dbase + (long)q * rs, dq, scale, lane_s);
     }
     // ---------------- phase B: dK, dV, wave = key tile
     for (int kt = wave; kt < nt; kt += 8) {
@@ -370,11 +421,15 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
                 dk = mma3<T>(tr_frag<T>(Qs, PITCH, qt * 32, s, lane, 0), tr_frag<T>(Qs, PITCH, qt * 32, s, lane, LO), sh, sl, dk);
             }
         }
-        const int k = kt * 32 + (lane & 31);
+        int lane_s = lane;
+        asm volatile("" : "+v"(lane_s));
+        const int k = kt * 32 + (lane_s & 31);
         if (k < Tn) {
-            store_tile_T<T>(dbase + (long)k * rs + hs, dk, scale, lane);
-            store_tile_T<T>(dbase + (long)k * rs + 2 * hs, dv, 1.0f, lane);
+            store_tile_T<T>(dbase + (long)k * rs + hs, dk, scale, lane_s);
+            store_tile_T<T>(dbase + (long)k * rs + 2 * hs, dv, 1.0f, lane_s);
         }
+    }
+    __syncthreads();                                               // every wave is done with the images before the next pair overwrites them
     }
 }
 
@@ -429,12 +484,19 @@ template <typename T> int launch_bwd_t(const void* qkv, const void* out, const v
     }
     {
         ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
+        // one persistent workgroup per CU (the LDS images allow no second one): a multiple of 8 so that a workgroup's pairs stay on its XCD
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+            return n & ~7;
+        }();
+        const int grid = B * H < cus ? B * H : cus;
         if (wide)
-            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RSB>), dim3(B * H), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
-                         (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
+            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RSB>), dim3(grid), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
+                         (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD), B * H);
         else
-            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RB>), dim3(B * H), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
-                         (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD));
+            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RB>), dim3(grid), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
+                         (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD), B * H);
         MFVIT_CHECK_LAUNCH();
     }
     if (dbias) {
@@ -452,6 +514,7 @@ bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward) {
     const int Tpad = (Tn + 31) & ~31;
     const int rb = dtype == MFVIT_BF16X3 ? 128 : 64;
     const int bytes = backward ? 4 * Tpad * rb + 2 * Tpad * 4 : Tpad * (rb + 16) + Tpad * rb;
+    if (backward && Tpad * (rb / 16) > 4 * 512) return false;      // the backward keeps 4 chunks per thread and image in registers
     return bytes <= 160 * 1024;
 }
 

@@ -188,22 +188,25 @@ def _stock_wrappers(rank, world):
         if step == 0:                                                # averaged, still scaled gradients: DDP's buckets vs GradSync's
             res["grad"] = max(_err(pa[k].grad, pb[k].grad) for k in names)
             res["grad_is_mean"] = float(pa["predictor.0.weight"].grad.abs().max()) > 0
+            sig = {k: pb[k].grad.abs() > 1e-3 * pb[k].grad.abs().max() for k in names}     # elements whose gradient is not rounding noise
         sc_a.step(opt_a)
         sc_a.update()
         sc_b.step(opt_b)
         sc_b.update()
+        if step == 0:
+            # after ONE update: Adam's first step is lr x sign(g) for every element, so the elements whose gradient is not rounding noise
+            # (the float atomics of the weight-gradient kernels add in a different order in every launch) must agree to 5 % of an update
+            far = sum(int(((pa[k].detach() - pb[k].detach()).abs()[sig[k]] > 5e-5).sum()) for k in names)
+            tot = sum(int(sig[k].sum()) for k in names)
+            res.update(param_far_fraction=far / max(tot, 1), significant=tot / sum(pb[k].numel() for k in names))
         res[f"logits{step}"] = _err(la, lb)
         res[f"loss{step}"] = abs(float(loss_a.detach()) - float(loss_b.detach())) / abs(float(loss_b.detach()))
     moved = max(float((pb[k].detach() - init[k]).abs().max()) for k in names)
-    # Adam normalises every element's update to ~lr: where a gradient element is rounding noise its sign may differ between the two
-    # reduction orders, so compare the bulk (fraction of elements further apart than 5% of one update) and the worst element (<= 2 lr x 2 steps)
-    far, tot, worst = 0, 0, 0.0
-    for k in names:
-        d = (pa[k].detach() - pb[k].detach()).abs()
-        far += int((d > 5e-5).sum())
-        tot += d.numel()
-        worst = max(worst, float(d.max()))
-    res.update(param_far_fraction=far / tot, param_worst=worst, moved=moved, scale_a=float(sc_a.get_scale()), scale_b=float(sc_b.get_scale()),
+    # after two: the second forward ran on weights that differ where the first update followed the sign of a rounding-noise gradient, and this
+    # step is badly conditioned at random initialisation (see tests/test_moco_gpu.py: a 6e-3 forward difference comes back as 10 % on the
+    # gradients) - bounded only by what flipped signs can cost, 2 lr x 2 steps
+    worst = max(float((pa[k].detach() - pb[k].detach()).abs().max()) for k in names)
+    res.update(param_worst=worst, moved=moved, scale_a=float(sc_a.get_scale()), scale_b=float(sc_b.get_scale()),
                queue=_err(ma.queue, mb.queue), queue_ptr=(int(ma.queue_ptr), int(mb.queue_ptr)))
     return res
 
@@ -250,8 +253,8 @@ def test_two_ranks_syncbn_shufflebn_gradsync():
         st = r["stock"]
         assert st["grad"] < 2e-3 and st["grad_is_mean"], (rank, st)
         # step 0 runs on identical weights: same logits bit for bit, gradients equal to reduction-order rounding.  Step 1 runs on
-        # weights that differ where Adam normalised rounding-noise gradients (measured: 0.3 % of the elements further apart than 5 % of
-        # one update, logits 1.4e-3 - 2.4e-3, loss 1.6e-4, the fp16 keys written to the queue 1e-2)
+        # weights that differ where Adam normalised rounding-noise gradients (measured: 0.3 - 7 % of ALL elements further apart than 5 % of
+        # one update, depending on the run; logits 1.4e-3 - 2.4e-3, loss 1.6e-4, the fp16 keys written to the queue 1e-2)
         assert st["logits0"] < 1e-6 and st["loss0"] < 1e-6 and st["logits1"] < 1e-2 and st["loss1"] < 1e-3, (rank, st)
-        assert st["moved"] > 5e-4 and st["param_far_fraction"] < 1e-2 and st["param_worst"] <= 4.2e-3, (rank, st)
+        assert st["moved"] > 5e-4 and st["param_far_fraction"] < 1e-3 and st["significant"] > 0.05 and st["param_worst"] <= 4.2e-3, (rank, st)
         assert st["scale_a"] == st["scale_b"] and st["queue"] < 3e-2 and st["queue_ptr"][0] == st["queue_ptr"][1], (rank, st)
