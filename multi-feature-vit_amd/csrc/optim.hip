@@ -53,6 +53,15 @@ __global__ __launch_bounds__(256) void lars_update_kernel(const long* __restrict
     }
 }
 // flag bit0: decoupled weight decay (AdamW); step-dependent constants are precomputed on the host
+__device__ __forceinline__ void adam_elem(float& pv, float gv, float& mv, float& vv, bool decoupled, float lr, float beta1, float beta2, float eps,
+                                          float wd, float bc1, float bc2_sqrt) {
+    if (decoupled) pv *= 1.f - lr * wd; else gv = fmaf(wd, pv, gv);
+    mv = fmaf(beta1, mv, (1.f - beta1) * gv);
+    vv = fmaf(beta2, vv, (1.f - beta2) * gv * gv);
+    pv = pv - (lr / bc1) * mv / (sqrtf(vv) / bc2_sqrt + eps);
+}
+// 28 bytes of HBM traffic per element (p, g, m, v in; p, m, v out) and nothing else: 16-byte accesses, two independent groups per thread in
+// flight (the 4-byte form ran at 2.2 TB/s: 0.56 ms per step for the 45 M parameters of the two-encoder model)
 __global__ __launch_bounds__(256) void adam_kernel(const long* __restrict__ tab, float lr, float beta1, float beta2, float eps, float wd,
                                                    float bc1, float bc2_sqrt) {
     const long* e = tab + (long)blockIdx.x * CH;
@@ -62,14 +71,40 @@ __global__ __launch_bounds__(256) void adam_kernel(const long* __restrict__ tab,
     float* v = (float*)e[4];
     const long n = e[5];
     const bool decoupled = e[6] & 1;
-    for (long i = threadIdx.x; i < n; i += 256) {
-        float pv = p[i], gv = g[i];
-        if (decoupled) pv *= 1.f - lr * wd; else gv = fmaf(wd, pv, gv);
-        const float mv = fmaf(beta1, m[i], (1.f - beta1) * gv);
-        const float vv = fmaf(beta2, v[i], (1.f - beta2) * gv * gv);
+    long done = 0;
+    if ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0) {
+        const long n4 = n >> 2;
+        float4* p4 = (float4*)p;
+        const float4* g4 = (const float4*)g;
+        float4* m4 = (float4*)m;
+        float4* v4 = (float4*)v;
+        for (long i = threadIdx.x; i < n4; i += 512) {
+            const long j = i + 256;
+            const bool two = j < n4;
+            float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
+            float4 pb = pa, gb = ga, mb = ma, vb = va;
+            if (two) { pb = p4[j]; gb = g4[j]; mb = m4[j]; vb = v4[j]; }
+            adam_elem(pa.x, ga.x, ma.x, va.x, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
+            adam_elem(pa.y, ga.y, ma.y, va.y, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
+            adam_elem(pa.z, ga.z, ma.z, va.z, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
+            adam_elem(pa.w, ga.w, ma.w, va.w, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
+            p4[i] = pa; m4[i] = ma; v4[i] = va;
+            if (two) {
+                adam_elem(pb.x, gb.x, mb.x, vb.x, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
+                adam_elem(pb.y, gb.y, mb.y, vb.y, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
+                adam_elem(pb.z, gb.z, mb.z, vb.z, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
+                adam_elem(pb.w, gb.w, mb.w, vb.w, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
+                p4[j] = pb; m4[j] = mb; v4[j] = vb;
+            }
+        }
+        done = n4 << 2;
+    }
+    for (long i = done + threadIdx.x; i < n; i += 256) {
+        float pv = p[i], mv = m[i], vv = v[i];
+        adam_elem(pv, g[i], mv, vv, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
         m[i] = mv;
         v[i] = vv;
-        p[i] = pv - (lr / bc1) * mv / (sqrtf(vv) / bc2_sqrt + eps);
+        p[i] = pv;
     }
 }
 __global__ __launch_bounds__(256) void sgd_kernel(const long* __restrict__ tab, float lr, float momentum, float wd, int first) {

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from ._lib import check, lib, ptr, stream
 
-CHUNK = 1 << 16
+CHUNK = 1 << 14          # elements per table row = per workgroup (45 M parameters: ~2,800 workgroups of 256 threads)
 
 
 def _bump_versions(params):
