@@ -342,8 +342,11 @@ def timed_region(run, steps, warmup, world, dev):
     t0 = time.perf_counter()
     for _ in range(steps):
         loss, _ = run.step()
+    t_host = time.perf_counter() - t0                       # the host has queued every step (stderr only: how far it runs ahead of the GPU)
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench] host queued {steps} steps in {1e3 * t_host:.1f} ms of the {1e3 * dt:.1f} ms they took", file=sys.stderr)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

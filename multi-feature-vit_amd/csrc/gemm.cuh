@@ -290,6 +290,16 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[i], bh[j], acc[i][j]);
         } else if constexpr (SPLIT) {
+            compute_hooked<false>(ta, tb, wm, wn, lane, acc, [](int) {});
+        } else {
+            compute_plain(ta, tb, wm, wn, lane, acc);
+        }
+    }
+    // split bf16: the same MFMAs with `side(t)` called behind MFMA number t (0 .. 6 TM TN - 1): the interleaved main loop hangs its global
+    // loads and LDS stores there, one at a time
+    template <bool HOOKED, typename F>
+    static __device__ __forceinline__ void compute_hooked(const char* ta, const char* tb, int wm, int wn, int lane, f32x16 (&acc)[TM][TN], F side) {
+        {
             // split product: per 16-wide k step  acc += a_lo b_hi + a_hi b_lo + a_hi b_hi  (3 MFMAs from 4 fragments; the fragments
             // of step 1 are read while the 12 - 18 MFMAs of step 0 run).  MFMA steps 0, 1 of the row are the hi parts, 2, 3 the lo
             // parts (KTile<sbf16>).
@@ -320,20 +330,18 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
                 }
                 if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(al[s][i], bh[s][j], acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[s][i], bl[s][j], acc[i][j]);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<T>::mma(ah[s][i], bh[s][j], acc[i][j]);
+                for (int t = 0; t < 3 * TM * TN; ++t) {
+                    const int term = t / (TM * TN), i = (t % (TM * TN)) / TN, j = t % TN;
+                    acc[i][j] = MmaTraits<T>::mma(term == 0 ? al[s][i] : ah[s][i], term == 1 ? bl[s][j] : bh[s][j], acc[i][j]);
+                    side(s * 3 * TM * TN + t);
+                    if (HOOKED) __builtin_amdgcn_sched_barrier(0);
+                }
                 if (PIPE) __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
+        }
+    }
+    static __device__ __forceinline__ void compute_plain(const char* ta, const char* tb, int wm, int wn, int lane, f32x16 (&acc)[TM][TN]) {
+        {
             // fragments double-buffered by hand: the LDS reads of sub-step s+1 are issued before the MFMAs of sub-step s (left to
             // itself the compiler waits right behind each read, which at 1-2 waves per SIMD exposes the LDS latency every sub-step)
             typename MmaTraits<T>::frag_t a[2][TM], b[2][TN];
@@ -412,7 +420,7 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN> struct NtLoop {
 // per-thread offsets - no address VALU in the loop) and the waits are explicit counted `s_waitcnt vmcnt`, so the compiler neither
 // sinks the loads into the MFMAs nor puts its own conservative vmcnt(0) on the loop-carried register reuse (what defeated the
 // C++-level attempts at a deeper pipeline, see NtLoop).  The K loop is unrolled D times: static register-set indices.
-template <typename T, int BM, int BN, int BKB, int WM, int WN, int D> struct NtLoopDeep {
+template <typename T, int BM, int BN, int BKB, int WM, int WN, int D, bool IL = false> struct NtLoopDeep {
     typedef NtLoop<T, BM, BN, BKB, WM, WN> Base;
     static constexpr int NT = Base::NT, BK = Base::BK, TM = Base::TM, TN = Base::TN;
     typedef typename Base::TA TA;
@@ -510,6 +518,30 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN, int D> struct NtL
                 if (!(ab & 4)) __syncthreads();
                 cur ^= 1;
 #else
+                if constexpr (IL && Base::SPLIT && !HALF && D == 2) {
+                    // interleaved form: the loads of tile kt + 2 go out one behind each of the first MFMAs, then the wait for tile kt + 1
+                    // (requested a whole iteration ago), then its LDS stores one behind each of the later MFMAs - instead of a burst of
+                    // loads in front of the MFMAs and a burst of ds_write_b128 (13 LDS-path cycles each) behind them, during which this
+                    // workgroup's matrix pipe share idles
+                    constexpr int NMF = 6 * Base::TM * Base::TN;     // MFMAs per K tile and wave
+                    static_assert(NL <= NMF / 2, "one load / one store per MFMA gap");
+                    char* nxt = lds + (cur ^ 1) * STAGE_BYTES;
+                    const long off = tile_off(kt0 + d + D);
+                    Base::template compute_hooked<true>(ta, ta + TA::BYTES, wm, wn, lane, acc, [&](int t) __attribute__((always_inline)) {
+                        if (t < NL) {
+                            if (t < NB) gload(st[d][NA + t], gW + off, vb[t]);
+                            else gload(st[d][t - NB], gA + off, va[t - NB]);
+                        }
+                        if (t == NMF / 2 - 1) wait_set<NL*(D - 1)>(st[(d + 1) % D]);
+                        if (t >= NMF / 2 && t < NMF / 2 + NL) {
+                            const int i = t - NMF / 2;
+                            if (i < NA) *(u32x4*)(nxt + ra[i]) = st[(d + 1) % D][i];
+                            else *(u32x4*)(nxt + rb[i - NA]) = st[(d + 1) % D][i];
+                        }
+                    });
+                    __syncthreads();
+                    cur ^= 1;
+                } else {
                 issue(st[d], kt0 + d + D);                   // set d is free: tile kt0 + d went to LDS one iteration ago
                 __builtin_amdgcn_sched_barrier(0);
                 Base::compute(ta, ta + TA::BYTES, wm, wn, lane, acc);
@@ -517,6 +549,7 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN, int D> struct NtL
                 put(st[(d + 1) % D], lds + (cur ^ 1) * STAGE_BYTES);
                 __syncthreads();
                 cur ^= 1;
+                }
 #endif
             }
         }

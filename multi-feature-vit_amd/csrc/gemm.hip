@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
     const int bid = xcd_remap(blockIdx.x, ntn * ntm);
     const int m0 = (bid / ntn) * BM, n0 = (bid % ntn) * BN;
     f32x16 acc[Loop::TM][Loop::TN];
-    if constexpr (DEEP > 0) {
+    if constexpr (DEEP == 12) {          // two K tiles in flight, loads / LDS stores interleaved with the MFMAs (split bf16)
+        NtLoopDeep<T, BM, BN, BKB, WM, WN, 2, true>::run(p, m0, n0, lds, acc);
+    } else if constexpr (DEEP > 0) {
         NtLoopDeep<T, BM, BN, BKB, WM, WN, DEEP>::run(p, m0, n0, lds, acc);
     } else if constexpr (std::is_same<T, bf16>::value) {
         if (p.y_f32 == 99) NtLoopGlds<BM, BN, WM, WN, 4>::run(p, m0, n0, lds, acc);   // LDS-DMA main loop (bf16)
@@ -980,7 +982,24 @@ template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStrea
 #ifdef MFVIT_ABLATE
         { const char* e = getenv("MFVIT_ABLATE_BITS"); p.splits = e ? atoi(e) : 0; }
 #endif
-        if (deep == 2 && p.y_f32 != 99 && p.K * EP / Loop::BK >= 2 && (p.K * EP / Loop::BK) % 2 == 0 && fits) {
+        const bool deep_ok = deep == 2 && p.y_f32 != 99 && p.K * EP / Loop::BK >= 2 && (p.K * EP / Loop::BK) % 2 == 0 && fits;
+        if constexpr (is_split<T>::value) {
+            // interleaved loads / LDS stores (default; MFVIT_NT_IL=0: the burst form; read at every launch for A/B runs in one process).
+            // Measured inside the step (rocprofv3, serialized streams): fc1 + GELU 138.3 -> 133.1 us, fc2-dgrad 122.7 -> 114.7, qkv 84.0 -> 79.6,
+            // proj-dgrad 35.0 -> 32.2; results bit-identical (same MFMA order).
+            const char* eil = getenv("MFVIT_NT_IL");
+            if (deep_ok && !(eil && atoi(eil) == 0)) {
+                static bool a12 = false;
+                if (!a12) {
+                    (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+                    a12 = true;
+                }
+                MFVIT_LAUNCH((gemm_nt_tile_kernel<T, EPI, 12>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), lds_bytes, st, p);
+                MFVIT_CHECK_LAUNCH();
+                return MFVIT_OK;
+            }
+        }
+        if (deep_ok) {
             MFVIT_LAUNCH((gemm_nt_tile_kernel<T, EPI, 2>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), lds_bytes, st, p);
             MFVIT_CHECK_LAUNCH();
             return MFVIT_OK;

@@ -10,6 +10,11 @@ from mfvit._lib import source_hash  # noqa: E402
 def klass(name):
     if "gemm_tn_kernel" in name or "gemm_tn_glds_kernel" in name:
         return "gemm_tn_wgrad"
+    if "gemm_rowp_kernel" in name:
+        # the tall-tile row kernel: <0> residual + LayerNorm forward, <1> LayerNorm backward, >= 10 the (opt-in) plain linears
+        m = re.search(r"gemm_rowp_kernel(?:ILi|<)(\d+)", name)
+        mode = int(m.group(1)) if m else 0
+        return "gemm_nt_row_res_ln" if mode == 0 else "gemm_nt_row_lnbwd" if mode == 1 else "gemm_nt_tile"
     if "gemm_nt_row_kernel" in name:
         # first template argument = element type, second = the epilogue (0: residual + LayerNorm forward, 1: LayerNorm backward)
         return "gemm_nt_row_res_ln" if re.search(r"gemm_nt_row_kernelI(DF16b|DF16_|f|NS_5sbf16E)Li0E", name) or re.search(r"gemm_nt_row_kernel<[^,]+, 0,", name) else "gemm_nt_row_lnbwd"

@@ -10,7 +10,9 @@ ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.g
 ev.sort()
 # the timed region = from the end of optimizer launch number <warmup> to the end of launch <warmup + steps> (one adam launch per step)
 warm, steps = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (3, 8)
-ad = [e for e in ev if "adam_kernel" in e[2]]
+ad_all = [e for e in ev if "adam_kernel" in e[2]]
+per_step = int(os.environ.get("ADAM_PER_STEP", "3"))      # optimizer launches per step = param groups (bench.py CaRun: fusion + heads, encoder 1, encoder 2)
+ad = ad_all[per_step - 1::per_step]                        # the LAST optimizer launch of every step
 t0, t1 = ad[warm - 1][1], ad[warm + steps - 1][1]
 ev = [e for e in ev if e[0] >= t0 and e[1] <= t1]
 pts = []
@@ -24,6 +26,8 @@ tot = t1 - t0
 print(f"window {tot/1e6:.2f} ms = {steps} steps of {tot/1e6/steps:.2f} ms, {len(ev)} kernels")
 for k in sorted(hist): print(f"  {k} kernels in flight: {100*hist[k]/tot:5.1f} %")
 def cls(n):
+    if "gemm_rowp_kernel" in n:
+        return "gemm_rowp_kernel" + ("<bwd>" if "<1>" in n else "<fwd>" if "<0>" in n else "<tile>")
     for key in ("gemm_nt_row_kernel", "gemm_nt_tile_kernel", "gemm_tn_glds_kernel", "gemm_tn_kernel", "attn_bwd", "attn_fwd", "adam", "x_stream"):
         if key in n:
             if key == "gemm_nt_row_kernel": return key + ("<bwd>" if ", 1, " in n.split("(")[0] else "<fwd>")
