@@ -1117,6 +1117,14 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
     return MFVIT_OK;
 }
 
+// out[n][k] += sum over `splits` partial matrices [N][K] (the weight-gradient kernels' plain-store path)
+int tn_partial_reduce(const float* part, int splits, int N, int K, float* out, long ldo, hipStream_t st) {
+    const long total4 = (long)N * K / 4;
+    MFVIT_LAUNCH(tn_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, part, splits, N, K, out, ldo);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
 // dst_q[c] += sum_g part[g][q * ncols + c]  for q < nq.  Grid: (column groups of 64) x (chunks of 32 partial rows); every block
 // adds its chunk sum with one atomic per column, so an address sees G / 32 adds instead of G.
 __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int G, int ncols, int nq, float* d0, float* d1,

@@ -344,16 +344,33 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
         }
     }
     if (!W8 || kh == 0) {
+        if (p.cpart) {
+            // split partials as PLAIN stores into scratch [split][N][K] (a register of a 32 x 32 accumulator = two 128-byte row segments: full store
+            // rate), summed into out0 by tn_reduce_kernel: the float atomics of this tile (64 KB per workgroup, 16.5 MB per launch at the
+            // ~1.3 TB/s atomics run at) were 10 - 13 us at the end of every launch, with nothing left to overlap them
+            float* part = p.cpart + (long)split * p.N * p.K;
 #pragma unroll
-        for (int i = 0; i < NL; ++i)
+            for (int i = 0; i < NL; ++i)
 #pragma unroll
-            for (int j = 0; j < NL; ++j)
+                for (int j = 0; j < NL; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = nw + i * 32 + acc_row(r, lane);
-                    const int k = kw + j * 32 + (lane & 31);
-                    atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = nw + i * 32 + acc_row(r, lane);
+                        const int k = kw + j * 32 + (lane & 31);
+                        __builtin_nontemporal_store(acc[i][j][r], part + (long)n * p.K + k);
+                    }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+#pragma unroll
+                for (int j = 0; j < NL; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int n = nw + i * 32 + acc_row(r, lane);
+                        const int k = kw + j * 32 + (lane & 31);
+                        atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
+                    }
+        }
     }
     if (CS) {
         if (do_cs && (lane & 31) == 0) {
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
 
 bool gemm_tn_glds_supported(int dtype, const GemmP& p) {
     static const int on = [] { const char* e = getenv("MFVIT_TN_GLDS"); return e ? atoi(e) : 1; }();
-    if (!on || (dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || p.nb > 1 || p.orow_in || p.cpart) return false;
+    if (!on || (dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || p.nb > 1 || p.orow_in) return false;
     if (p.N % 128 || p.K % 128 || p.M < 4096) return false;     // 128 x 128 LOGICAL tiles in every mode
     if (p.lda % 8 || p.ldw % 8) return false;
     return true;
@@ -384,6 +401,13 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
         const int maxs = (p.M + 4 * G::KR - 1) / (4 * G::KR);
         p.splits = s < 1 ? 1 : (s > maxs ? maxs : s);
     }
+    {   // no empty split (the kernel derives the same chunk from p.splits): every split writes its partial tile
+        int chunk = (p.M + p.splits - 1) / p.splits;
+        chunk = (chunk + G::KR - 1) / G::KR * G::KR;
+        p.splits = (p.M + chunk - 1) / chunk;
+    }
+    // p.cpart (optional scratch of >= 384 tiles of 128 x 128 floats): split partials as plain stores + one reduce pass
+    if (p.splits < 2 || p.ldo0 % 4 || (long)tiles * p.splits > 384) p.cpart = nullptr;
     constexpr int bytes = (is_split<T>::value ? T2_NSP : T2_NS) * T2_STAGE;   // (the pipelined form's ring; the other split forms use three of the four slots)
     const char* e8 = getenv("MFVIT_TN2_W8");                 // both read at every launch (A/B runs in one process)
     const char* eil = getenv("MFVIT_TN2_IL");
@@ -409,6 +433,7 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     if (p.cs0) go1(std::true_type{});
     else go1(std::false_type{});
     MFVIT_CHECK_LAUNCH();
+    if (p.cpart) return tn_partial_reduce(p.cpart, p.splits, p.N, p.K, (float*)p.out0, p.ldo0, st);
     return MFVIT_OK;
 }
 

@@ -477,9 +477,10 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     float* gmid = (float*)(ws + W.gmid);
     float* colscr = (float*)(ws + W.colscratch);
     float* colpart = (float*)(ws + W.colpart);
-    // split partials of the wgrad GEMMs through scratch instead of float atomics: opt-in (MFVIT_TN_PART=1).  Measured inside the
-    // four-stream step the extra reduce launch per wgrad costs more (-4 %) than the atomics it replaces (they are fire-and-forget and
-    // overlap the tail of the kernel); what it buys is a deterministic dW.
+    // split partials of the wgrad GEMMs through scratch (plain stores + one reduce launch) instead of float atomics: opt-in (MFVIT_TN_PART=1;
+    // what it buys is a deterministic dW).  Measured inside the step, round 3, with the store path in the LDS-DMA wgrad kernel itself: class
+    // average 77.2 -> 80.8 us including the reduce launch, step 30.85 -> 31.0 ms (profiles/r03_wgrad_ab.txt) - the atomics of a launch (16.5 MB)
+    // are fire-and-forget and overlap the tail of the kernel and the head of the next one.
     static const bool tn_part = [] { const char* e = getenv("MFVIT_TN_PART"); return e && e[0] == '1'; }();
     float* tnpart = tn_part ? (float*)(ws + W.tnpart) : nullptr;
     // dY buffers by layer parity (the embed stage counts as layer -1 -> parity 1)
