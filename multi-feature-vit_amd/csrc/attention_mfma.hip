@@ -16,6 +16,8 @@
 // Backward (flash-style recompute from the saved log-sum-exp, two phases, no atomics, deterministic):
 //   phase A (wave = query tile): dS^T[key][q] -> dQ^T[d][q] += K^T x dS^T       (lse_q, D_q are per-lane scalars)
 //   phase B (wave = key tile)  : P[q][key], dS[q][key] -> dV^T[d][key] += dO^T x P ; dK^T[d][key] += Q^T x dS
+#include <stdlib.h>
+
 #include "common.cuh"
 #include "prof.h"
 
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
     char* dOs = Vs + Tpad * PITCH;
     float* Ls = (float*)(dOs + Tpad * PITCH);
     float* Ds = Ls + Tpad;
+    char* Os = (char*)(Ds + Tpad);                                     // O rows of the NEXT pair (unpadded, A::RB bytes each): only D needs them
     // PERSISTENT over the (image, head) pairs: the workgroup's four LDS images (129 KB for split bf16) allow one workgroup per CU, so a
     // workgroup per pair left every CU idle while its ~129 KB came in cold (measured: 6 rounds x ~6 us of the 148 us launch).  Now each
     // workgroup walks through its pairs and fetches the NEXT pair's row pieces into registers (5 x 16 B per chunk, 4 chunks per thread)
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
     constexpr int NCH = 4;                                             // 16-byte chunks per thread and image (Tpad * CPR <= 4 * 512)
     constexpr int RSTEP = 512 / CPR;                                   // rows between a thread's chunks
     const int t0 = threadIdx.x / CPR, cidx = threadIdx.x % CPR;
-    uint4 pq[NCH], pk[NCH], pv[NCH], pd[NCH], po[NCH];
+    uint4 pq[NCH], pk[NCH], pv[NCH], pd[NCH];
     float pl[NCH];
     auto fetch = [&](int vi) __attribute__((always_inline)) {
         const int bid = xcd_remap(vi, npair);                          // the heads of one image share an XCD: their row pieces share L2 lines
@@ -262,19 +265,39 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
         // one chunk at a time)
         const E* rp = base + (long)t0 * rs + 8 * cidx;
         const E* dp_ = dobase + (long)t0 * os + 8 * cidx;
-        const E* op_ = obase + (long)t0 * os + 8 * cidx;
         const float* lp = lse + ((long)b * H + h) * Tn + t0;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            pq[i] = pk[i] = pv[i] = pd[i] = po[i] = make_uint4(0, 0, 0, 0);
+            pq[i] = pk[i] = pv[i] = pd[i] = make_uint4(0, 0, 0, 0);
             pl[i] = 1e30f;                                             // (raw lse; no arithmetic on a loaded value here: it would wait for the loads)
             if (t0 + RSTEP * i < Tn) {                                 // (Tn <= Tpad <= RSTEP * NCH: checked by the launcher)
                 pq[i] = *(const uint4*)(rp + (long)(RSTEP * i) * rs);
                 pk[i] = *(const uint4*)(rp + (long)(RSTEP * i) * rs + hs);
                 pv[i] = *(const uint4*)(rp + (long)(RSTEP * i) * rs + 2 * hs);
                 pd[i] = *(const uint4*)(dp_ + (long)(RSTEP * i) * os);
-                po[i] = *(const uint4*)(op_ + (long)(RSTEP * i) * os);
                 if (cidx == 0) pl[i] = lp[RSTEP * i];
+            }
+        }
+        // the O rows go global -> LDS directly (LDS-DMA, lane-linear destination = the unpadded [row][piece] image): 16 registers per thread
+        // less to carry through the compute phases - with them the split-bf16 variant spilled, and every scratch reload waits for ALL loads
+        // in flight.  Rows past Tn re-fetch row Tn - 1 (finite; their D is never used).
+        const unsigned lbase_o = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)Os + (unsigned)wave * 1024u);
+        const unsigned long long ob = (unsigned long long)obase;       // uniform: scalar base + 32-bit per-lane byte offsets, derived HERE from a
+        const unsigned ob_lo = __builtin_amdgcn_readfirstlane((unsigned)ob), ob_hi = __builtin_amdgcn_readfirstlane((unsigned)(ob >> 32));
+        const char* sb = (const char*)(((unsigned long long)ob_hi << 32) | ob_lo);   // laundered lane id (carried across the loop they were spilled,
+        int tl = t0, cl = cidx;                                                     // and a reload between the loads waits for all of them)
+        asm volatile("" : "+v"(tl), "+v"(cl));
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int t = tl + RSTEP * i;
+            t = t < Tn ? t : Tn - 1;
+            const unsigned voff = ((unsigned)t * (unsigned)os + 8u * (unsigned)cl) * (unsigned)sizeof(E);
+            if (RSTEP * i < Tpad) {                                     // (uniform: whole waves)
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "v"(voff), "s"(sb), "s"(lbase_o + (unsigned)i * 8192u)
+                             : "memory");
             }
         }
     };
@@ -288,16 +311,14 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             union { uint4 u; frag_t f; } cd, co, cx;
+            const int t = t0 + RSTEP * i;
             cd.u = pd[i];
-            co.u = po[i];
+            co.u = *(const uint4*)(Os + ((t < Tpad ? t : 0) * CPR + cidx) * 16);
             float of[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) of[j] = (float)co.f[j];
-            if constexpr (A::SP) {
-                cx.u.x = __shfl_xor(po[i].x, 4, 64);
-                cx.u.y = __shfl_xor(po[i].y, 4, 64);
-                cx.u.z = __shfl_xor(po[i].z, 4, 64);
-                cx.u.w = __shfl_xor(po[i].w, 4, 64);
+            if constexpr (A::SP) {                                      // the other part of the same 8 d's: piece cidx ^ 4 of the row
+                cx.u = *(const uint4*)(Os + ((t < Tpad ? t : 0) * CPR + (cidx ^ 4)) * 16);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) of[j] += (float)cx.f[j];
             }
@@ -331,9 +352,11 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
     const int bid = xcd_remap(vi, npair);
     const int b = bid / H, h = bid % H;
     E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's O pieces have landed ...
+    __syncthreads();                                                   // ... and everybody else's
     reduce_D();
     stage();
-    __syncthreads();
+    __syncthreads();                                                   // (also: Os may be refilled)
     if (vi + (int)gridDim.x < npair) fetch(vi + gridDim.x);
     const float c = scale * 1.4426950408889634f;
     const int nt = Tpad >> 5;
@@ -474,8 +497,8 @@ template <typename T> int launch_bwd_t(const void* qkv, const void* out, const v
     typedef typename Vec4<T>::elem E;
     constexpr int RSB = AttnT<T>::RSB, RB = AttnT<T>::RB;
     const int Tpad = (Tn + 31) & ~31;
-    const bool wide = 4 * Tpad * RSB + 2 * Tpad * 4 <= 160 * 1024;
-    const int bytes = 4 * Tpad * (wide ? RSB : RB) + 2 * Tpad * 4;
+    const bool wide = 4 * Tpad * RSB + 2 * Tpad * 4 + Tpad * RB <= 160 * 1024;
+    const int bytes = 4 * Tpad * (wide ? RSB : RB) + 2 * Tpad * 4 + Tpad * RB;      // Q, K, V, dO images, lse / D rows, the next pair's O rows
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -490,7 +513,8 @@ template <typename T> int launch_bwd_t(const void* qkv, const void* out, const v
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
             return n & ~7;
         }();
-        const int grid = B * H < cus ? B * H : cus;
+        const char* eg = getenv("MFVIT_ATTN_BWD_PERSIST");             // 0: one workgroup per pair (A/B switch, read at every launch)
+        const int grid = (B * H < cus || (eg && atoi(eg) == 0)) ? B * H : cus;
         if (wide)
             MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RSB>), dim3(grid), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
                          (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD), B * H);
@@ -513,7 +537,7 @@ bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward) {
     if ((dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || HDim != HD || Tn < 1) return false;
     const int Tpad = (Tn + 31) & ~31;
     const int rb = dtype == MFVIT_BF16X3 ? 128 : 64;
-    const int bytes = backward ? 4 * Tpad * rb + 2 * Tpad * 4 : Tpad * (rb + 16) + Tpad * rb;
+    const int bytes = backward ? 4 * Tpad * rb + 2 * Tpad * 4 + Tpad * rb : Tpad * (rb + 16) + Tpad * rb;
     if (backward && Tpad * (rb / 16) > 4 * 512) return false;      // the backward keeps 4 chunks per thread and image in registers
     return bytes <= 160 * 1024;
 }
