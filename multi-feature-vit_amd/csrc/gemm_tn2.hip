@@ -368,6 +368,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
                     for (int r = 0; r < 16; ++r) {
                         const int n = nw + i * 32 + acc_row(r, lane);
                         const int k = kw + j * 32 + (lane & 31);
+                        if (p.rows_per_wg >= 2) {          // (timing experiment MFVIT_TN2_ATOMX=2 / 3: the same sum in 2 / 3 atomics per element)
+                            const float v = acc[i][j][r] / (float)p.rows_per_wg;
+                            for (int q = 0; q < p.rows_per_wg; ++q) atomicAdd(out + (long)n * p.ldo0 + k, v);
+                        } else
                         atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
                     }
         }
@@ -409,6 +413,7 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     // p.cpart (optional scratch of >= 384 tiles of 128 x 128 floats): split partials as plain stores + one reduce pass
     if (p.splits < 2 || p.ldo0 % 4 || (long)tiles * p.splits > 384) p.cpart = nullptr;
     constexpr int bytes = (is_split<T>::value ? T2_NSP : T2_NS) * T2_STAGE;   // (the pipelined form's ring; the other split forms use three of the four slots)
+    { const char* ex = getenv("MFVIT_TN2_ATOMX"); p.rows_per_wg = ex ? atoi(ex) : 0; }
     const char* e8 = getenv("MFVIT_TN2_W8");                 // both read at every launch (A/B runs in one process)
     const char* eil = getenv("MFVIT_TN2_IL");
     const bool w8 = !(e8 && atoi(e8) == 0), il = !(eil && atoi(eil) == 0);
