@@ -91,10 +91,17 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wq = wave & 3, kh = wave >> 2;                 // output quadrant; half of the stage's reduction rows (W8)
     const int wm = wq >> 1, wn = wq & 1;
+    // PAIRED launch (p.res_mod = N2 > 0): a second weight gradient with the same reduction rows and the same K appended along N - its tiles
+    // come behind the first one's, the split count is common.  (qkv: 27 tiles and proj: 9 tiles give 36 x 7 = 252 workgroups in ONE launch instead
+    // of 243 + 252 in two: half the float atomics, 12.5 us per launch, and one prologue.)  Second set: A2 = aux / ldaux, X2 = res_t / ldres_t,
+    // out2 = out1 / ldo1; the bias column sums belong to the first.
     const int ntk = p.K * EP / TW;
-    const int tiles = ntk * (p.N * EP / TW);
+    const int tiles1 = ntk * (p.N * EP / TW);
+    const int tiles = tiles1 + ntk * (p.res_mod * EP / TW);
     const int lin = xcd_remap(blockIdx.x, gridDim.x);        // each XCD gets a contiguous run of the split-major block order
-    const int split = lin / tiles, tile = lin % tiles;
+    const int split = lin / tiles, tile_all = lin % tiles;
+    const bool second = tile_all >= tiles1;                  // (block-uniform)
+    const int tile = second ? tile_all - tiles1 : tile_all;
     const int n0 = (tile / ntk) * TW, k0 = (tile % ntk) * TW;   // STORAGE columns
     int chunk = (p.M + p.splits - 1) / p.splits;
     chunk = (chunk + KR - 1) / KR * KR;
@@ -102,8 +109,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
     const int mend = min(p.M, mbeg + chunk);
     if (mbeg >= mend) return;
     const int nst = (mend - mbeg + KR - 1) / KR;
-    const E16* A = (const E16*)p.A;
-    const E16* X = (const E16*)p.W;
+    const E16* A = (const E16*)(second ? p.aux : p.A);
+    const E16* X = (const E16*)(second ? p.res_t : p.W);
+    const long lda_ = second ? p.ldaux : p.lda, ldw_ = second ? p.ldres_t : p.ldw;
 
     // LDS-DMA g = wave + NWV i (i = 0 .. NI-1) of an operand fills rows RPI g .. RPI g + RPI - 1: lane -> row RPI g + lane / CPR, chunk
     // position lane % CPR, which receives source chunk (lane % CPR) ^ (4 * (row & 3))   (NWV RPI i is a multiple of 4)
@@ -117,13 +125,13 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
         for (int i = 0; i < NI; ++i) {
             int m = mrow + NWV * RPI * i;
             m = m < p.M ? m : p.M - 1;                        // never read past the tensor (clamped rows are zeroed below)
-            t2_glds16(A + (long)m * p.lda + n0 + lch * 8, sa + i * NWV * 1024);
+            t2_glds16(A + (long)m * lda_ + n0 + lch * 8, sa + i * NWV * 1024);
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             int m = mrow + NWV * RPI * i;
             m = m < p.M ? m : p.M - 1;
-            t2_glds16(X + (long)m * p.ldw + k0 + lch * 8, sb + i * NWV * 1024);
+            t2_glds16(X + (long)m * ldw_ + k0 + lch * 8, sb + i * NWV * 1024);
         }
     };
 
@@ -137,8 +145,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
         int m = mbeg + stc * KR + lrow + NWV * RPI * i;
         m = m < p.M ? m : p.M - 1;
         const unsigned dst = lbase + (unsigned)slot * T2_STAGE + (d >= NI ? T2_TILE : 0) + i * NWV * 1024;
-        if (d < NI) t2_glds16(A + (long)m * p.lda + n0 + lch * 8, dst);
-        else t2_glds16(X + (long)m * p.ldw + k0 + lch * 8, dst);
+        if (d < NI) t2_glds16(A + (long)m * lda_ + n0 + lch * 8, dst);
+        else t2_glds16(X + (long)m * ldw_ + k0 + lch * 8, dst);
     };
 
     f32x16 acc[NL][NL], bacc[NL];
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
     frag_t ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (E16)1.0f;
-    const bool do_cs = CS && k0 == 0 && wn == 0;             // column sums of A (= bias gradient): k-tile 0, wn 0 waves (each k half its own rows)
+    const bool do_cs = CS && !second && k0 == 0 && wn == 0;             // column sums of A (= bias gradient): k-tile 0, wn 0 waves (each k half its own rows)
 
     // the bias-column-sum MFMAs are selected ONCE per wave (template flag), not per k-step: a branch inside the hot loop splits it
     // into basic blocks and serialises the ds_read -> MFMA pipeline (measured: 72 vs 52 us on the kernels that carry a bias sum)
@@ -319,7 +327,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
         else main_loop(std::false_type{});
     }
     const int nw = n0 / EP + wm * 64, kw = k0 / EP + wn * 64;   // LOGICAL origin of this wave's 64 x 64 tile
-    float* out = (float*)p.out0;
+    float* out = (float*)(second ? p.out1 : p.out0);
+    const long ldo_ = second ? p.ldo1 : p.ldo0;
     if constexpr (W8) {
         // the second k half hands its 64 x 64 quadrant to the first through LDS (4 quadrants x 4 tiles x 16 registers x 64 lanes x 4 B = 64 KB
         // of the ring: every wave is past its last fragment read and every LDS-DMA has landed)
@@ -370,9 +379,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
                         const int k = kw + j * 32 + (lane & 31);
                         if (p.rows_per_wg >= 2) {          // (timing experiment MFVIT_TN2_ATOMX=2 / 3: the same sum in 2 / 3 atomics per element)
                             const float v = acc[i][j][r] / (float)p.rows_per_wg;
-                            for (int q = 0; q < p.rows_per_wg; ++q) atomicAdd(out + (long)n * p.ldo0 + k, v);
+                            for (int q = 0; q < p.rows_per_wg; ++q) atomicAdd(out + (long)n * ldo_ + k, v);
                         } else
-                        atomicAdd(out + (long)n * p.ldo0 + k, acc[i][j][r]);
+                        atomicAdd(out + (long)n * ldo_ + k, acc[i][j][r]);
                     }
         }
     }
@@ -396,9 +405,22 @@ bool gemm_tn_glds_supported(int dtype, const GemmP& p) {
     return true;
 }
 
+// may `b` ride along with `a` in one launch?  (same reduction rows and K, no bias sums / partial scratch / batch on b)
+bool gemm_tn_pair_supported(int dtype, const GemmP& a, const GemmP& b) {
+    // opt-in (MFVIT_TN_PAIR=1).  Measured inside the step (profiles/r03_wgrad_ab.txt): the weight-gradient class 7.77 -> 7.32 ms per step in the serialized
+    // pass, as the saved atomics predict - but the TIMED two-stream step 30.20 -> 30.30 ms: dWproj alone was a short side-stream kernel that filled
+    // gaps beside the data-gradient chain; folded into dWqkv it waits for the attention backward and runs as one longer launch that owns the chip.
+    const char* e = getenv("MFVIT_TN_PAIR");
+    if (!(e && atoi(e) != 0)) return false;
+    if (!gemm_tn_glds_supported(dtype, a) || !gemm_tn_glds_supported(dtype, b)) return false;
+    if (a.M != b.M || a.K != b.K || b.cs0 || a.cpart || b.cpart || a.splits > 0 || b.splits > 0 || a.res_mod || b.res_mod) return false;
+    return true;
+}
+
 template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     typedef T2Geo<T> G;
-    const int tiles = (p.N / 128) * (p.K / 128);
+    const int tiles = ((p.N + p.res_mod) / 128) * (p.K / 128);          // res_mod = N of the paired second GEMM (0: none)
+    if (p.res_mod) p.cpart = nullptr;                                   // (the plain-store partial path is single-GEMM)
     if (p.splits <= 0) {
         static const int target = [] { const char* e = getenv("MFVIT_TN2_TARGET"); return e ? atoi(e) : 256; }();
         int s = target / tiles;                              // one workgroup per CU (96 KB of LDS): tiles x splits <= 256
@@ -417,7 +439,7 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     const char* e8 = getenv("MFVIT_TN2_W8");                 // both read at every launch (A/B runs in one process)
     const char* eil = getenv("MFVIT_TN2_IL");
     const bool w8 = !(e8 && atoi(e8) == 0), il = !(eil && atoi(eil) == 0);
-    ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * p.N * p.K, 0, st);
+    ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * (p.N + p.res_mod) * p.K, 0, st);
     auto go = [&](auto cs, auto w, auto i) {
         constexpr bool CS = decltype(cs)::value, W8 = decltype(w)::value, IL = decltype(i)::value;
         static bool attr = false;
@@ -440,6 +462,15 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     MFVIT_CHECK_LAUNCH();
     if (p.cpart) return tn_partial_reduce(p.cpart, p.splits, p.N, p.K, (float*)p.out0, p.ldo0, st);
     return MFVIT_OK;
+}
+
+// a and b in one launch (gemm_tn_pair_supported)
+int gemm_tn_glds_pair(int dtype, GemmP a, const GemmP& b, hipStream_t st) {
+    a.aux = b.A; a.ldaux = b.lda;
+    a.res_t = b.W; a.ldres_t = b.ldw;
+    a.out1 = b.out0; a.ldo1 = b.ldo0;
+    a.res_mod = b.N;
+    return gemm_tn_glds(dtype, a, st);
 }
 
 int gemm_tn_glds(int dtype, GemmP p, hipStream_t st) {

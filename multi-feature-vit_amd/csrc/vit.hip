@@ -577,6 +577,8 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 gyp = ws + W.dtmp;
             }
             MFVIT_TRY(fork());
+            GemmP pend_proj = zero_gemm();                        // dWproj: launched here, or held back to ride along with dWqkv (one launch for both)
+            bool have_pend = false;
             {   // dWproj += gmid^T attn
                 GemmP p = zero_gemm();
                 p.A = gyp; p.lda = D * e; p.W = b + W.attn; p.ldw = D * e;
@@ -584,7 +586,12 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 if (rdrop) p.cs0 = gb + L.proj_b;
                 p.out0 = gb + L.proj_w; p.ldo0 = D;
                 p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
-                MFVIT_TRY(gemm_tn(d.dtype, p, wst));
+                if (!rdrop && !tnpart) {
+                    pend_proj = p;
+                    have_pend = true;
+                } else {
+                    MFVIT_TRY(gemm_tn(d.dtype, p, wst));
+                }
             }
             {   // dattn = gmid Wproj
                 GemmP p = zero_gemm();
@@ -607,7 +614,14 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.cs0 = gb + L.qkv_b;
                 p.out0 = gb + L.qkv_w; p.ldo0 = D;
                 p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
-                MFVIT_TRY(gemm_tn(d.dtype, p, wst));
+                // dWproj rides along when the LDS-DMA kernel takes both (same rows, same K = 384: 27 + 9 tiles x 7 splits = 252 workgroups): the
+                // float atomics of one launch (16.5 MB, 12.5 us) and one prologue less per block
+                if (have_pend && gemm_tn_pair_supported(d.dtype, p, pend_proj)) {
+                    MFVIT_TRY(gemm_tn_glds_pair(d.dtype, p, pend_proj, wst));
+                } else {
+                    if (have_pend) MFVIT_TRY(gemm_tn(d.dtype, pend_proj, wst));
+                    MFVIT_TRY(gemm_tn(d.dtype, p, wst));
+                }
             }
             if (use_side && hipEventRecord(ss.done[l & 63], ss.s) != hipSuccess) return MFVIT_ELAUNCH;
             MFVIT_TRY(wait_layer(l + 1));                         // fc2-wgrad of layer l+1 reads the gxT copy written next
