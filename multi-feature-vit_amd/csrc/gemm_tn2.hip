@@ -407,11 +407,9 @@ bool gemm_tn_glds_supported(int dtype, const GemmP& p) {
 
 // may `b` ride along with `a` in one launch?  (same reduction rows and K, no bias sums / partial scratch / batch on b)
 bool gemm_tn_pair_supported(int dtype, const GemmP& a, const GemmP& b) {
-    // opt-in (MFVIT_TN_PAIR=1).  Measured inside the step (profiles/r03_wgrad_ab.txt): the weight-gradient class 7.77 -> 7.32 ms per step in the serialized
-    // pass, as the saved atomics predict - but the TIMED two-stream step 30.20 -> 30.30 ms: dWproj alone was a short side-stream kernel that filled
-    // gaps beside the data-gradient chain; folded into dWqkv it waits for the attention backward and runs as one longer launch that owns the chip.
-    const char* e = getenv("MFVIT_TN_PAIR");
-    if (!(e && atoi(e) != 0)) return false;
+    // (policy - when to pair - lives with the caller, vit.hip.  Measured inside the step, profiles/r03_wgrad_ab.txt: the weight-gradient class 7.77 -> 7.32 ms per
+    // step in the serialized pass, as the saved atomics predict; with the weight gradients on a side stream the TIMED step loses 0.1 ms - dWproj alone was a short
+    // kernel that filled gaps beside the data-gradient chain - on the caller's stream it gains 0.13 ms.)
     if (!gemm_tn_glds_supported(dtype, a) || !gemm_tn_glds_supported(dtype, b)) return false;
     if (a.M != b.M || a.K != b.K || b.cs0 || a.cpart || b.cpart || a.splits > 0 || b.splits > 0 || a.res_mod || b.res_mod) return false;
     return true;

@@ -197,8 +197,11 @@ GemmP zero_gemm() {
     return p;
 }
 
-// Weight-gradient GEMMs are leaves of the backward graph: they run on a second (library-owned, lazily created) HIP stream
-// beside the dgrad chain, ordered by events.  MFVIT_WGRAD_STREAM=0 keeps everything on the caller's stream.
+// Weight-gradient GEMMs are leaves of the backward graph: they CAN run on a second (library-owned, lazily created) HIP stream beside the
+// dgrad chain, ordered by events (MFVIT_WGRAD_STREAM=1).  Default since round 3: the caller's stream.  The side stream was worth 3 - 4 % while the
+// weight-gradient and row kernels left half of every CU's LDS and issue slots free (round 2); now they are one-workgroup-per-CU kernels that own
+// the chip while they run, nothing co-resides with them, and the second queue only adds event waits and a worse launch order: measured on one box,
+// three alternating repeats, 31.25 / 31.33 / 31.36 ms per step with the side stream, 30.81 / 30.80 / 30.86 without (profiles/r03_streams_ab.txt).
 struct SideStream {
     hipStream_t owner = nullptr;    // caller stream this side stream is paired with
     hipStream_t s = nullptr;
@@ -221,7 +224,7 @@ SideStream& side_stream(hipStream_t caller) {
     }
     SideStream& x = *px;
     if (!x.s) {
-        static const bool enabled = [] { const char* e = getenv("MFVIT_WGRAD_STREAM"); return !(e && e[0] == '0'); }();
+        static const bool enabled = [] { const char* e = getenv("MFVIT_WGRAD_STREAM"); return e && e[0] == '1'; }();
         if (enabled && hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&x.in, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&x.end, hipEventDisableTiming) == hipSuccess) {
@@ -586,7 +589,10 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 if (rdrop) p.cs0 = gb + L.proj_b;
                 p.out0 = gb + L.proj_w; p.ldo0 = D;
                 p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
-                if (!rdrop && !tnpart) {
+                // held back by default when the weight gradients run on the caller's stream (nothing to overlap: one launch less is a pure gain,
+                // 30.81 -> 30.68 ms per step); MFVIT_TN_PAIR=0 / 1 forces it off / on
+                static const int pair_mode = [] { const char* e = getenv("MFVIT_TN_PAIR"); return e ? atoi(e) : -1; }();
+                if (!rdrop && !tnpart && (pair_mode == 1 || (pair_mode < 0 && !use_side))) {
                     pend_proj = p;
                     have_pend = true;
                 } else {
