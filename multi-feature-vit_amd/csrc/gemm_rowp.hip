@@ -136,13 +136,29 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         return *(const bf16x8*)(lds + (stage & 1) * RP_WSTAGE + (48 * wave + 16 * j) * 128 + off);
     };
 
+    // Forward epilogue mode: the accumulators START as the residual rows.  The 39 MB of residual rows are then fetched here, under the latency of
+    // the first operand stages, instead of in the epilogue, where nothing overlaps them (the epilogue is exposed HBM streaming: 116 MB per launch
+    // became 77).  Sum order: res + products + bias instead of products + bias + res - one f32 rounding apart.
     f32x4v acc[RP_MF][3];
 #pragma unroll
-    for (int i = 0; i < RP_MF; ++i)
+    for (int i = 0; i < RP_MF; ++i) {
+        int r0 = 16 * i + fr;
+        r0 = r0 < rows ? r0 : rows - 1;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < 3; ++j) {
+            if constexpr (REPI == REPI_RES_LN) {
+                // (the load result IS the accumulator: no arithmetic on it here - that would wait for each row's loads in turn; the bias joins in
+                // the epilogue)
+                const int n = 48 * wave + 4 * fq + 16 * j;
+                f32x4v rv = {0.f, 0.f, 0.f, 0.f};
+                if (p.res) rv = *(const f32x4v*)(p.res + (unsigned)(m0 + r0) * (unsigned)p.ldres + n);
+                acc[i][j] = rv;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+            }
+        }
+    }
 
     // prologue.  Inside a training step W is cold, and every CU walks through it in lockstep: each stage would be a first touch served at HBM
     // latency (measured inside the step: fc2 + LN 123 us against 98 us on a warm W).  So first the CUs of an XCD (blockIdx & 7: round-robin
@@ -436,23 +452,23 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         const float invN = 1.0f / (float)RP_N;
         float part[RP_MF];
         fresh_lane();
-        // v = acc + bias + residual
+        // v = (residual + products) + bias: the residual rows were the accumulators' initial values
+        f32x4v bj[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            bj[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bj[j] = *(const f32x4v*)(p.bias + ncol0 + 16 * j);
+        }
 #pragma unroll
         for (int i = 0; i < RP_MF; ++i) {
-            const unsigned m = (unsigned)row_of(i);
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int n = ncol0 + 16 * j;
-                f32x4v b = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) b = *(const f32x4v*)(p.bias + n);
-                if (p.res) rv = *(const f32x4v*)(p.res + m * (unsigned)p.ldres + n);
+            for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    acc[i][j][r] += b[r] + rv[r];
+                    acc[i][j][r] += bj[j][r];
                     s += acc[i][j][r];
                 }
-            }
             part[i] = s;
         }
         row_total(part, red);
