@@ -1091,6 +1091,13 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
         const int maxs = (p.M + 4 * KR - 1) / (4 * KR);  // at least 4 stages per split
         p.splits = s < 1 ? 1 : (s > maxs ? maxs : s);
     }
+    {   // no empty split (the kernel derives the same chunk from p.splits): with the plain-store partial path every split must write its tile -
+        // an empty one used to return early and the reduce pass summed whatever the scratch held (MFVIT_TN_PART=1 at M where 28 splits of
+        // KR-rounded chunks overshoot M: caught by the switch-matrix run of round 3)
+        int chunk = (p.M + p.splits - 1) / p.splits;
+        chunk = (chunk + KR - 1) / KR * KR;
+        p.splits = (p.M + chunk - 1) / chunk;
+    }
     const bool xcd1d = p.splits > 1 && p.nb <= 1;
     constexpr int bytes = 2 * (STile<T, 128, KR>::BYTES * 2);
     static bool attr_set = false;

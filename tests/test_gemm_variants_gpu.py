@@ -100,6 +100,28 @@ def test_weight_gradient_variants(monkeypatch, M, tag, w8, il):
             assert rel(out2, 2 * ref) < 2e-5, (tag, name, split, w8, il, "accumulate")
 
 
+@pytest.mark.parametrize("M", [128 * 197, 64 * 197, 4096 + 40, 901])
+def test_weight_gradient_with_partial_scratch(M):
+    """The plain-store split-partial path (scratch given: `mfvit_linear_wgrad_ws`, MFVIT_TN_PART=1 inside the encoder) at row counts where the
+    KR-rounded split chunks overshoot M: every split must write its partial tile (an empty split used to leave stale scratch in the sum)."""
+    g = _gen(53)
+    scratch = torch.full((ops.WGRAD_SCRATCH_FLOATS,), float("nan"), device=DEV)       # stale scratch must never reach the result
+    for name, n, k in (("proj", D, D), ("fc1", F, D)):
+        a32, b32 = rn(g, M, n, sc=.1), rn(g, M, k)
+        for kind in ("split", "bf16", "fp32"):
+            if kind == "split":
+                a, b = sp(a32), sp(b32)
+                ref = ops.split_unpack(a).double().T @ ops.split_unpack(b).double()
+            elif kind == "bf16":
+                a, b = a32.bfloat16(), b32.bfloat16()
+                ref = a.double().T @ b.double()
+            else:
+                a, b = a32, b32
+                ref = a.double().T @ b.double()
+            out = ops.linear_wgrad(a, b, scratch=scratch, split=kind == "split")
+            assert bool(torch.isfinite(out).all()) and rel(out, ref) < 2e-5, (M, name, kind, rel(out, ref))
+
+
 @pytest.mark.parametrize("M,tag", SHAPES[:2])
 @pytest.mark.parametrize("switch,value", [("MFVIT_PP", "2"), ("MFVIT_ROWT", "1")])
 def test_opt_in_linear_kernels_match_the_tile_kernel(monkeypatch, M, tag, switch, value):
