@@ -1,0 +1,118 @@
+// Do matrix work and HBM streaming overlap on this part, or do they share one (power) budget?
+// Kernel A: the pure-MFMA loop of tools/mfma_ceiling.hip (one wave per SIMD on every CU, no memory traffic).  Kernel B: a streaming copy
+// (16-byte loads + stores, grid-stride, a buffer far larger than the Infinity Cache).  Timed: A alone, B alone, A and B started together on two
+// streams.  "free overlap" would give max(tA, tB); a shared budget gives something near tA + tB.
+//   hipcc --offload-arch=gfx950 -O3 tools/overlap_probe.hip -o tools/overlap_probe && tools/overlap_probe [random|zero] [copy GB]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__global__ __launch_bounds__(256) void mfma_loop(const bf16x8* __restrict__ in, float* __restrict__ out, int iters, long long* cyc) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long c0 = __builtin_readcyclecounter();
+    bf16x8 a[8], b[8];
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = in[(gid * 16 + 2 * i) & 0xffff];
+        b[i] = in[(gid * 16 + 2 * i + 1) & 0xffff];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[i], acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[gid] = s;
+    if (gid == 0) *cyc = __builtin_readcyclecounter() - c0;
+}
+
+__global__ __launch_bounds__(256) void stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4, int passes) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (int p = 0; p < passes; ++p)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+int main(int argc, char** argv) {
+    const bool zero = argc > 1 && !strcmp(argv[1], "zero");
+    const double gb = argc > 2 ? atof(argv[2]) : 2.0;             // bytes read per pass (the same again written)
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    bf16x8* in;
+    float* out;
+    long long* cyc;
+    hipMalloc(&cyc, 8);
+    hipMalloc(&in, 65536 * sizeof(bf16x8));
+    hipMalloc(&out, (size_t)cus * 256 * sizeof(float));
+    unsigned short* h = (unsigned short*)malloc(65536 * 16);
+    unsigned x = 12345u;
+    for (int i = 0; i < 65536 * 8; ++i) {
+        x = x * 1664525u + 1013904223u;
+        const float f = zero ? 0.f : ((int)(x >> 8) % 2001 - 1000) * 1e-3f;
+        unsigned u;
+        memcpy(&u, &f, 4);
+        h[i] = (unsigned short)(u >> 16);
+    }
+    hipMemcpy(in, h, 65536 * 16, hipMemcpyHostToDevice);
+    const size_t n4 = (size_t)(gb * 1e9 / 16);
+    float4 *src, *dst;
+    hipMalloc(&src, n4 * 16);
+    hipMalloc(&dst, n4 * 16);
+    hipMemset(src, 1, n4 * 16);
+    hipStream_t sa, sb;
+    hipStreamCreateWithFlags(&sa, hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+    hipEvent_t a0, a1, b0, b1;
+    hipEventCreate(&a0); hipEventCreate(&a1); hipEventCreate(&b0); hipEventCreate(&b1);
+    const int copy_blocks = cus * 4;                               // 4 copy workgroups per CU beside the one MFMA workgroup
+    auto runA = [&](int iters) { hipLaunchKernelGGL(mfma_loop, dim3(cus), dim3(256), 0, sa, in, out, iters, cyc); };
+    auto runB = [&](int passes) { hipLaunchKernelGGL(stream_copy, dim3(copy_blocks), dim3(256), 0, sb, src, dst, n4, passes); };
+    // calibrate: A alone and B alone, ~3 ms each
+    runA(2000); runB(1);
+    hipDeviceSynchronize();
+    float ms;
+    hipEventRecord(a0, sa); runA(10000); hipEventRecord(a1, sa); hipEventSynchronize(a1); hipEventElapsedTime(&ms, a0, a1);
+    const int iters = (int)(10000 * 3.0 / ms);
+    hipEventRecord(b0, sb); runB(1); hipEventRecord(b1, sb); hipEventSynchronize(b1); hipEventElapsedTime(&ms, b0, b1);
+    const int passes = ms < 3.0 ? (int)(3.0 / ms + 0.5) : 1;
+    float tA = 1e30f, tB = 1e30f, tAB = 1e30f, tA_in = 0, tB_in = 0;
+    long long cyc_alone = 0, cyc_both = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(a0, sa); runA(iters); hipEventRecord(a1, sa); hipEventSynchronize(a1); hipEventElapsedTime(&ms, a0, a1);
+        if (ms < tA) { tA = ms; hipMemcpy(&cyc_alone, cyc, 8, hipMemcpyDeviceToHost); }
+        hipEventRecord(b0, sb); runB(passes); hipEventRecord(b1, sb); hipEventSynchronize(b1); hipEventElapsedTime(&ms, b0, b1);
+        if (ms < tB) tB = ms;
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        hipDeviceSynchronize();
+        hipEventRecord(a0, sa); hipEventRecord(b0, sb);
+        runA(iters); runB(passes);
+        hipEventRecord(a1, sa); hipEventRecord(b1, sb);
+        hipEventSynchronize(a1); hipEventSynchronize(b1);
+        float x0, x1, x2, x3;
+        hipEventElapsedTime(&x0, a0, a1); hipEventElapsedTime(&x1, b0, b1); hipEventElapsedTime(&x2, a0, b1); hipEventElapsedTime(&x3, b0, a1);
+        float wall = x0;
+        if (x1 > wall) wall = x1;
+        if (x2 > wall) wall = x2;
+        if (x3 > wall) wall = x3;
+        if (wall < tAB) { tAB = wall; tA_in = x0; tB_in = x1; hipMemcpy(&cyc_both, cyc, 8, hipMemcpyDeviceToHost); }
+    }
+    const double flop = 2.0 * 32 * 32 * 16 * 8.0 * iters * cus * 4;
+    const double bytes = 2.0 * n4 * 16 * passes;
+    printf("{\"operands\": \"%s\", \"mfma_alone_ms\": %.3f, \"mfma_alone_tflops\": %.0f, \"mfma_alone_clock_mhz\": %.0f, \"copy_alone_ms\": %.3f, \"copy_alone_tbs\": %.2f, "
+           "\"together_wall_ms\": %.3f, \"mfma_kernel_ms_together\": %.3f, \"copy_kernel_ms_together\": %.3f, \"mfma_clock_mhz_together\": %.0f, "
+           "\"sum_ms\": %.3f, \"max_ms\": %.3f, \"wall_over_sum\": %.3f, \"wall_over_max\": %.3f}\n",
+           zero ? "zero" : "random", tA, flop / tA / 1e9, (double)cyc_alone / (tA * 1e-3) / 1e6, tB, bytes / tB / 1e9, tAB, tA_in, tB_in,
+           (double)cyc_both / (tA_in * 1e-3) / 1e6, tA + tB, tA > tB ? tA : tB, tAB / (tA + tB), tAB / (tA > tB ? tA : tB));
+    return 0;
+}
