@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void mfma_loop(const bf16x8* __restrict__ in, 
     if (gid == 0) *cyc = __builtin_readcyclecounter() - c0;
 }
 
-__global__ __launch_bounds__(256) void stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4, int passes) {
+__global__ __launch_bounds__(256) void stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4, int passes, int prio) {
+    if (prio) __builtin_amdgcn_s_setprio(3);                       // (third argument 1: the copy waves at the highest wave priority)
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (int p = 0; p < passes; ++p)
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void stream_copy(const float4* __restrict__ sr
 int main(int argc, char** argv) {
     const bool zero = argc > 1 && !strcmp(argv[1], "zero");
     const double gb = argc > 2 ? atof(argv[2]) : 2.0;             // bytes read per pass (the same again written)
+    const int prio = argc > 3 ? atoi(argv[3]) : 0;
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
@@ -76,7 +78,7 @@ int main(int argc, char** argv) {
     hipEventCreate(&a0); hipEventCreate(&a1); hipEventCreate(&b0); hipEventCreate(&b1);
     const int copy_blocks = cus * 4;                               // 4 copy workgroups per CU beside the one MFMA workgroup
     auto runA = [&](int iters) { hipLaunchKernelGGL(mfma_loop, dim3(cus), dim3(256), 0, sa, in, out, iters, cyc); };
-    auto runB = [&](int passes) { hipLaunchKernelGGL(stream_copy, dim3(copy_blocks), dim3(256), 0, sb, src, dst, n4, passes); };
+    auto runB = [&](int passes) { hipLaunchKernelGGL(stream_copy, dim3(copy_blocks), dim3(256), 0, sb, src, dst, n4, passes, prio); };
     // calibrate: A alone and B alone, ~3 ms each
     runA(2000); runB(1);
     hipDeviceSynchronize();
@@ -109,10 +111,10 @@ int main(int argc, char** argv) {
     }
     const double flop = 2.0 * 32 * 32 * 16 * 8.0 * iters * cus * 4;
     const double bytes = 2.0 * n4 * 16 * passes;
-    printf("{\"operands\": \"%s\", \"mfma_alone_ms\": %.3f, \"mfma_alone_tflops\": %.0f, \"mfma_alone_clock_mhz\": %.0f, \"copy_alone_ms\": %.3f, \"copy_alone_tbs\": %.2f, "
+    printf("{\"operands\": \"%s\", \"copy_prio\": %d, \"mfma_alone_ms\": %.3f, \"mfma_alone_tflops\": %.0f, \"mfma_alone_clock_mhz\": %.0f, \"copy_alone_ms\": %.3f, \"copy_alone_tbs\": %.2f, "
            "\"together_wall_ms\": %.3f, \"mfma_kernel_ms_together\": %.3f, \"copy_kernel_ms_together\": %.3f, \"mfma_clock_mhz_together\": %.0f, "
            "\"sum_ms\": %.3f, \"max_ms\": %.3f, \"wall_over_sum\": %.3f, \"wall_over_max\": %.3f}\n",
-           zero ? "zero" : "random", tA, flop / tA / 1e9, (double)cyc_alone / (tA * 1e-3) / 1e6, tB, bytes / tB / 1e9, tAB, tA_in, tB_in,
+           zero ? "zero" : "random", prio, tA, flop / tA / 1e9, (double)cyc_alone / (tA * 1e-3) / 1e6, tB, bytes / tB / 1e9, tAB, tA_in, tB_in,
            (double)cyc_both / (tA_in * 1e-3) / 1e6, tA + tB, tA > tB ? tA : tB, tAB / (tA + tB), tAB / (tA > tB ? tA : tB));
     return 0;
 }
