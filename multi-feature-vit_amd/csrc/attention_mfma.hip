@@ -292,7 +292,9 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
             int t = tl + RSTEP * i;
             t = t < Tn ? t : Tn - 1;
             const unsigned voff = ((unsigned)t * (unsigned)os + 8u * (unsigned)cl) * (unsigned)sizeof(E);
-            if (RSTEP * i < Tpad) {                                     // (uniform: whole waves)
+            // wave-exact guard: a wave covers 64 / CPR whole rows and Tpad is a multiple of 32, so a wave's 1 KB piece lies entirely inside or
+            // entirely outside the Tpad * RB bytes of Os (a block-uniform guard let waves 4 - 7 of the last chunk write past the allocation)
+            if (RSTEP * i + (__builtin_amdgcn_readfirstlane(wave) * 64) / CPR < Tpad) {
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep)

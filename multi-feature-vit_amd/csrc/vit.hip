@@ -767,6 +767,16 @@ int mfvit_linear_wgrad_ws(int dtype, const void* dy, int64_t lddy, const void* x
     p.cpart = scratch;
     return gemm_tn(dtype, p, (hipStream_t)stream);
 }
+int mfvit_linear_wgrad_pair(int dtype, const void* dy_a, int64_t lddy_a, const void* x_a, int64_t ldx_a, float* dw_a, int64_t lddw_a, float* dbias_a,
+                            int Na, const void* dy_b, int64_t lddy_b, const void* x_b, int64_t ldx_b, float* dw_b, int64_t lddw_b, int Nb, int M, int K,
+                            mfvit_stream_t stream) {
+    if (!dy_a || !x_a || !dw_a || !dy_b || !x_b || !dw_b) return MFVIT_EINVAL;
+    GemmP a = zero_gemm(), b = zero_gemm();
+    a.A = dy_a; a.lda = lddy_a; a.W = x_a; a.ldw = ldx_a; a.M = M; a.N = Na; a.K = K; a.out0 = dw_a; a.ldo0 = lddw_a; a.cs0 = dbias_a;
+    b.A = dy_b; b.lda = lddy_b; b.W = x_b; b.ldw = ldx_b; b.M = M; b.N = Nb; b.K = K; b.out0 = dw_b; b.ldo0 = lddw_b;
+    if (!gemm_tn_pair_supported(dtype, a, b)) return MFVIT_ENOSYS;
+    return gemm_tn_glds_pair(dtype, a, b, (hipStream_t)stream);
+}
 int mfvit_linear_res_ln_fwd(int dtype, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res,
                             int64_t ldres, float* x_out, void* y, int y_f32, const float* gamma, const float* beta, float eps,
                             float* mean, float* rstd, int M, int K, mfvit_stream_t stream) {

@@ -111,6 +111,26 @@ def linear_wgrad(dy, x, out=None, scratch=None, split=False):
     return out
 
 
+def linear_wgrad_pair(dy_a, x_a, dy_b, x_b, want_dbias=True, split=False):
+    """Two weight gradients over the same M rows and the same K in ONE launch (the encoder backward's dWqkv + dWproj):
+    returns (dW_a [Na,K], dbias_a [Na] or None, dW_b [Nb,K]), all f32.  Raises MfvitError (ENOSYS) for shapes the paired kernel
+    does not take (M < 4096, N / K not multiples of 128, f32)."""
+    require_cuda(dy_a, x_a, dy_b, x_b)
+    code = _code_of(dy_a, split)
+    e = 2 if split else 1
+    M, Na, Nb = dy_a.shape[0], dy_a.shape[1] // e, dy_b.shape[1] // e
+    K = x_a.shape[1] // e
+    if dy_b.shape[0] != M or x_a.shape[0] != M or x_b.shape[0] != M or x_b.shape[1] // e != K:
+        raise _lib.MfvitError("linear_wgrad_pair: the two GEMMs must share M and K")
+    dw_a = torch.zeros(Na, K, device=dy_a.device, dtype=torch.float32)
+    dw_b = torch.zeros(Nb, K, device=dy_a.device, dtype=torch.float32)
+    db_a = torch.zeros(Na, device=dy_a.device, dtype=torch.float32) if want_dbias else None
+    check(lib().mfvit_linear_wgrad_pair(code, ptr(dy_a), dy_a.stride(0), ptr(x_a), x_a.stride(0), ptr(dw_a), dw_a.stride(0), ptr(db_a), Na,
+                                        ptr(dy_b), dy_b.stride(0), ptr(x_b), x_b.stride(0), ptr(dw_b), dw_b.stride(0), Nb, M, K, stream()),
+          "mfvit_linear_wgrad_pair")
+    return dw_a, db_a, dw_b
+
+
 def linear_res_ln_fwd(a, w, bias, res, gamma, beta, eps, y_f32=False, split=False):
     """x_out = a @ w.T + bias + res ; y = LayerNorm(x_out).  Returns (x_out f32, y, mean, rstd)."""
     require_cuda(a, w, res)

@@ -100,6 +100,32 @@ def test_weight_gradient_variants(monkeypatch, M, tag, w8, il):
             assert rel(out2, 2 * ref) < 2e-5, (tag, name, split, w8, il, "accumulate")
 
 
+@pytest.mark.parametrize("M,tag", SHAPES)
+@pytest.mark.parametrize("kind", ["split", "bf16", "fp16"])
+def test_paired_weight_gradient_launch(M, tag, kind):
+    """`gemm_tn_glds_pair` (csrc/gemm_tn2.hip) through `mfvit_linear_wgrad_pair`: dWqkv (+ d qkv.bias column sums) and dWproj of a timm
+    attention block in ONE launch - the default of the timed encoder backward at M >= 4096 - against float64 dY^T X on the rounded
+    operands for BOTH outputs and the bias sums, at the bench's M, a ragged M and a small one."""
+    g = _gen(71)
+    dqkv32, y132 = rn(g, M, 3 * D, sc=.1), rn(g, M, D)
+    gmid32, attn32 = rn(g, M, D, sc=.1), rn(g, M, D)
+    if kind == "split":
+        pk, up = sp, (lambda t: ops.split_unpack(t).double())
+    else:
+        dt = torch.bfloat16 if kind == "bf16" else torch.float16
+        pk, up = (lambda t: t.to(dt)), (lambda t: t.double())
+    dqkv, y1, gmid, attn = pk(dqkv32), pk(y132), pk(gmid32), pk(attn32)
+    dw_a, db_a, dw_b = ops.linear_wgrad_pair(dqkv, y1, gmid, attn, split=kind == "split")
+    ra, rb, rbias = up(dqkv).T @ up(y1), up(gmid).T @ up(attn), up(dqkv).sum(0)
+    errs = dict(dWqkv=rel(dw_a, ra), dWproj=rel(dw_b, rb), dbias=rel(db_a, rbias))
+    assert errs["dWqkv"] < 2e-5 and errs["dWproj"] < 2e-5 and errs["dbias"] < 2e-4, (tag, kind, errs)
+    # and the same numbers as the two single launches it replaces (same tiles, same split chunks; float atomics: rounding-level agreement)
+    sa, sb = ops.linear_wgrad(dqkv, y1, split=kind == "split"), ops.linear_wgrad(gmid, attn, split=kind == "split")
+    assert rel(dw_a, sa) < 2e-6 and rel(dw_b, sb) < 2e-6, (tag, kind)
+    with pytest.raises(Exception):                                       # shapes the paired kernel does not take are refused, not mis-computed
+        ops.linear_wgrad_pair(dqkv[:1000], y1[:1000], gmid[:1000], attn[:1000], split=kind == "split")
+
+
 @pytest.mark.parametrize("M", [128 * 197, 64 * 197, 4096 + 40, 901])
 def test_weight_gradient_with_partial_scratch(M):
     """The plain-store split-partial path (scratch given: `mfvit_linear_wgrad_ws`, MFVIT_TN_PART=1 inside the encoder) at row counts where the

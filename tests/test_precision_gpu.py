@@ -194,7 +194,9 @@ ATT_MODES = MODES + [Bf16Mode()]
 @pytest.mark.parametrize("B,T,H", [(2, 197, 12), (3, 50, 12), (1, 256, 12),      # whole-head-in-LDS kernels (attention_mfma.hip)
                                    (1, 577, 12),                                 # 384^2 inputs: split bf16 streams (attention_tiled.hip)
                                    (2, 394, 4), (1, 130, 4),                     # TransFuser-GPT heads: 4 x 96 over 394 joint tokens (tiled)
-                                   (2, 197, 6), (1, 1200, 12)])                  # head_dim 64; a sequence beyond the LDS images (tiled)
+                                   (2, 197, 6), (1, 1200, 12),                   # head_dim 64; a sequence beyond the LDS images (tiled)
+                                   (45, 197, 12)])                               # B * H = 540 > 2 x #CUs, not a multiple of it: the PERSISTENT
+                                                                                 # multi-pair loops of both directions with a ragged tail
 def test_attention_fwd_bwd(mode, B, T, H):
     from mfvit import ops
     D = 384
@@ -282,6 +284,34 @@ def test_backward_all_parameters(precision, tol, stop_grad_conv1):
             worst = (name, e)
         assert e < tol, (name, e)
     log(f"backward[{precision},stop_grad_conv1={stop_grad_conv1}] worst {worst[0]} err={worst[1]:.2e}")
+
+
+@pytest.mark.parametrize("precision,tol_f,tol_g", [("bf16x3", 1e-4, 2e-3), ("fp16", 6e-3, 2e-2), ("bf16", 4e-2, 8e-2)])
+def test_backward_on_the_size_gated_kernels_against_the_oracle(precision, tol_f, tol_g):
+    """B = 24 images = 4,728 token rows (>= 4,096) and B * H = 288 (image, head) pairs (> #CUs): the encoder takes the kernels the TIMED step
+    runs - the tall-tile row kernels of csrc/gemm_rowp.hip, the LDS-DMA weight gradients with dWproj riding along with dWqkv
+    (`gemm_tn_glds_pair`), the persistent multi-pair attention loops - and every parameter gradient is compared with the float64 CPU
+    oracle (depth 2 keeps it in seconds).  The B <= 3 oracle tests run the small-M kernels only."""
+    B, depth = 24, 2
+    m, p = build(precision, 521, depth=depth)
+    x = rng_tensor(522, (B, 3, 224, 224))
+    r = rng_tensor(523, (B, 197, 384))
+    pd = {k: v.double().requires_grad_(k != "pos_embed") for k, v in p.items()}
+    f_ref = ref_vit.features3d(pd, x.double())
+    (f_ref * r.double()).sum().backward()
+    f = m.features3D(x.to("cuda:0"))
+    (f * r.to("cuda:0")).sum().backward()
+    e_f = rel_err(f, f_ref)
+    worst = ("", 0.0)
+    for name, prm in m.named_parameters():
+        if name == "pos_embed" or name.startswith("head"):
+            continue
+        e = rel_err(prm.grad, pd[name].grad)
+        if e > worst[1]:
+            worst = (name, e)
+        assert e < tol_g, (name, e)
+    log(f"size-gated backward[{precision}, B={B}, depth {depth}] features {e_f:.2e} worst grad {worst[0]} {worst[1]:.2e}")
+    assert e_f < tol_f
 
 
 def test_fp16_encoder_forward():
