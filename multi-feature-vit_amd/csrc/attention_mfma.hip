@@ -16,6 +16,8 @@
 // Backward (flash-style recompute from the saved log-sum-exp, two phases, no atomics, deterministic):
 //   phase A (wave = query tile): dS^T[key][q] -> dQ^T[d][q] += K^T x dS^T       (lse_q, D_q are per-lane scalars)
 //   phase B (wave = key tile)  : P[q][key], dS[q][key] -> dV^T[d][key] += dO^T x P ; dK^T[d][key] += Q^T x dS
+#include <limits.h>
+#include <type_traits>
 #include <stdlib.h>
 
 #include "common.cuh"
@@ -218,6 +220,489 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<
             store_tile_T<T>(out + (((long)b * Tn + q) * H * HD + h * HD) * EP, o, 1.0f / lsum, lane);
             if (lane < 32) lse[((long)b * H + h) * Tn + q] = (m2 + log2f(lsum)) * 0.6931471805599453f;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Forward, PERSISTENT and pair-synchronous with a producer wave (round 4).
+//
+// What the cycle stamps of the first persistent attempts showed (tools/attn_stamps.py, profiles/r04_attn_fwd_stamps.txt):
+//   * the kernel above is not short of bandwidth: a wave needs ~2,400 cycles per 32 x 32 tile step whose ~170 vector and 12 matrix
+//     instructions issue in ~800 - it waits for LDS fragments it has just requested, and the two waves of a SIMD sit in the same phase
+//     (both in the score MFMAs, then both in the softmax), so the matrix and the vector pipe take turns instead of running together;
+//   * the row's output stores (8-byte pieces at a 1.5 KB row stride: 32 partial lines per instruction) hold the CU's vector-memory path
+//     for ~3,000 cycles and the NEXT loads queue behind them for as long again;
+//   * LDS-DMA issued in a burst by the computing waves blocks them until the memory path has taken every piece.
+// Hence this structure - one 8-wave workgroup per CU walking through its (image, head) pairs:
+//   * waves 0 .. 6 each own one 32-query ROW TILE of the current pair (T = 197: exactly 7); wave 7 is the PRODUCER: it streams the next
+//     pair's K and V into the other LDS slot by LDS-DMA (global_load_lds_dwordx4, paced), waits for them, and meets the others at the one
+//     barrier per pair.  Nobody else ever waits for a K / V byte, and a blocked DMA issue blocks nothing but the producer.
+//   * per key tile ONE software-pipelined step, hand-ordered (sched_barrier after every group): the K fragments of tile t + 1 and the V
+//     fragments of tile t are requested first; the six score MFMAs of tile t + 1 are spread over the exp2 work of tile t, the six PV MFMAs
+//     of tile t over its hi / lo packing and the row maximum of tile t + 1 - every MFMA has vector work behind it, every fragment is
+//     requested a block before its use.  Online softmax per tile with a LAZY maximum (rescale only when a tile exceeds the reference by
+//     2^24: p stays f32 until the split, whose relative precision does not depend on the scale).
+//   * the finished row goes through a wave-private LDS tile and leaves as four 16-byte-per-lane stores of WHOLE 128-byte lines.
+//   * LDS images are UNPADDED (an LDS-DMA writes 1 KB lane-linear), 16-byte chunks XOR-swizzled through the DMA's per-lane SOURCE
+//     address: K by (row >> 1) & 7 (split: 128-B rows; plain 64-B rows: (row >> 2) & 3) - the b128 row reads are conflict free; V (split)
+//     swaps the hi / lo halves of rows 2, 3 (mod 4) - the four rows of a transposing read fall into four disjoint 64-B bank windows
+//     (the padded image of the kernel above is 2-way conflicted there).  The swizzles depend on the lane only: they fold into 4 + 2
+//     per-lane offsets, tile / k-step / slot offsets stay immediates or uniform adds.
+//   * An image holds Timg = Tn rounded up to the DMA piece (8 / 16 rows), not to 32: reads of the last key tile run past it into what
+//     follows (K: masked to -inf whatever the bytes; V: probability exactly 0 times FINITE bytes - the overrun regions are zeroed once,
+//     afterwards they hold zeros or another pair's finite K rows).
+template <typename T> struct RingGeo {
+    static constexpr bool SP = is_split<T>::value;
+    static constexpr int RB = AttnT<T>::RB;    // bytes per image row
+    static constexpr int CPR = RB / 16;        // 16-byte chunks per row
+    static constexpr int RPP = 64 / CPR;       // rows per LDS-DMA piece (one wave instruction = 1 KB)
+    static constexpr int SPB = RB + 16;        // pitch of the output staging tile
+    static constexpr int NCW = 7;              // computing waves (wave 7 produces)
+    static __host__ __device__ int timg(int Tn) { return (Tn + RPP - 1) / RPP * RPP; }
+    static __host__ __device__ int pad_bytes(int Tn) { return (((Tn + 31) & ~31) - timg(Tn)) * RB; }
+    static __host__ __device__ int lds_bytes(int Tn) { return 2 * 2 * timg(Tn) * RB + pad_bytes(Tn) + NCW * 32 * SPB; }
+    static __device__ __forceinline__ int kswz(int row) { return SP ? (row >> 1) & 7 : (row >> 2) & 3; }
+    static __device__ __forceinline__ int vswz(int row) { return SP ? ((row >> 1) & 1) << 2 : 0; }
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_off)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+#ifdef MFVIT_ATTN_STAMP
+// diagnostic build only (tools/attn_stamps.py): cycle stamps of workgroups 0 and 37, [2][16 rounds][8 waves][32 points]
+__device__ unsigned long long* g_attn_stamps = nullptr;
+#define ATTN_STAMP(i)                                                                                                            \
+    do {                                                                                                                         \
+        if (g_attn_stamps && (blockIdx.x == 0 || blockIdx.x == 37) && rnd_no < 16) {                                             \
+            const unsigned long long t__ = __builtin_amdgcn_s_memtime();                                                         \
+            if (lane == 0) g_attn_stamps[(((blockIdx.x ? 1 : 0) * 16 + rnd_no) * 8 + wave) * 32 + (i)] = t__;                   \
+        }                                                                                                                        \
+    } while (0)
+#else
+#define ATTN_STAMP(i) do {} while (0)
+#endif
+#define ATTN_SB() __builtin_amdgcn_sched_barrier(0)
+#if defined(MFVIT_ATTN_STAMP) && defined(MFVIT_ATTN_STAMP_FINE)
+#define ATTN_FSTAMP(i) do { if (JOB < 0 && t == 4) ATTN_STAMP(i); } while (0)
+#else
+#define ATTN_FSTAMP(i) do {} while (0)
+#endif
+// the other half-wave's value (lane ^ 32) by v_permlane32_swap: VALU only - a ds_bpermute would sit in the LDS queue behind the fragment reads
+__device__ __forceinline__ float xhalf(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>::elem* __restrict__ qkv, typename Vec4<T>::elem* __restrict__ out,
+                                                          float* __restrict__ lse, int Tn, int H, float scale, int npair) {
+    typedef AttnT<T> A;
+    typedef RingGeo<T> G;
+    typedef typename A::E E;
+    typedef typename A::frag_t frag_t;
+    constexpr int EP = A::EP, RB = G::RB, CPR = G::CPR, RPP = G::RPP, LO = A::SP ? 1 : 0, SPB = G::SPB, NCW = G::NCW;
+    constexpr int NQK = A::SP ? 6 : 2;                                 // MFMAs of one score tile / of one PV tile
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int nt = (Tn + 31) >> 5;                                     // row tiles = key tiles per pair (<= NCW: checked by the launcher)
+    const int Timg = G::timg(Tn);
+    const int img = Timg * RB, slotb = 2 * img;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long hs = (long)H * HD * EP, rs = 3 * hs;
+    const int npl = (npair - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // pairs of this workgroup: blockIdx.x + k * gridDim.x
+    const int NP = 2 * (Timg / RPP);                                   // LDS-DMA pieces per pair
+    char* stage = lds + 2 * slotb + G::pad_bytes(Tn) + wave * (32 * SPB);
+    {   // the V overrun of slot 0 (= the head of slot 1) and of slot 1 (= the pad behind it) start out as zeros
+        const int pad = G::pad_bytes(Tn);
+        for (int i = threadIdx.x * 16; i < pad; i += 512 * 16) {
+            *(uint4*)(lds + slotb + i) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(lds + 2 * slotb + i) = make_uint4(0, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        ATTN_SB();
+    }
+    auto pair_bid = [&](int k) __attribute__((always_inline)) {
+        return xcd_remap((int)blockIdx.x + k * (int)gridDim.x, npair);                 // the pairs of a workgroup stay on its XCD
+    };
+    // LDS-DMA piece pi (0 .. NP - 1: K image pieces, then V image pieces) of the pair at `base` into slot `slot`
+    auto dma_piece = [&](const E* base, int slot, int pi) __attribute__((always_inline)) {
+        const int which = pi >= (NP >> 1) ? 1 : 0;
+        const int pj = pi - which * (NP >> 1);
+        const int row = pj * RPP + lane / CPR, cpos = lane % CPR;
+        const int cc = cpos ^ (which ? G::vswz(row) : G::kswz(row));                  // the chunk that belongs at this LDS position
+        const int rowc = row < Tn ? row : Tn - 1;                                      // image rows past Tn: a finite copy of the last row
+        glds16(base + (long)rowc * rs + (1 + which) * hs + 8 * cc, (unsigned)slot * (unsigned)slotb + (unsigned)which * (unsigned)img + (unsigned)pj * 1024u);
+    };
+    auto load_q = [&](const E* base, int qt, frag_t (&qf)[2], frag_t (&ql)[2]) __attribute__((always_inline)) {
+        const int q = qt * 32 + (lane & 31);
+        const int qc = q < Tn ? q : Tn - 1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qf[s] = *(const frag_t*)(base + (long)qc * rs + 16 * s + 8 * (lane >> 5));
+            if constexpr (A::SP) ql[s] = *(const frag_t*)(base + (long)qc * rs + 32 + 16 * s + 8 * (lane >> 5));
+            else ql[s] = qf[s];
+        }
+    };
+    // "use" the prefetched Q registers right behind the explicit wait: the compiler then places ITS wait for these loads here, in front of
+    // the row's stores - left to the first MFMA of the next round it would be a vmcnt(0) that also waits for those stores
+    auto touch_q = [](frag_t (&qf)[2], frag_t (&ql)[2]) __attribute__((always_inline)) {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            union { frag_t f; u32x4_t u; } x, y;
+            x.f = qf[s];
+            y.f = ql[s];
+            asm volatile("" : "+v"(x.u), "+v"(y.u));
+            qf[s] = x.f;
+            ql[s] = y.f;
+        }
+    };
+    const bool producer = wave == NCW;
+    const bool act = wave < nt;                                        // this wave owns row tile `wave` of every pair
+    frag_t qnf[2], qnl[2];
+    {   // prologue: everybody brings in pair 0
+        const int bid = pair_bid(0);
+        const E* base = qkv + (long)(bid / H) * Tn * rs + (bid % H) * HD * EP;
+        if (act) load_q(base, wave, qnf, qnl);
+        for (int pi = wave; pi < NP; pi += 8) dma_piece(base, 0, pi);
+        wait_vm<0>();
+        touch_q(qnf, qnl);
+    }
+    const float c = scale * 1.4426950408889634f;
+    // per-lane LDS byte offsets (from the start of a slot) of this lane's K row fragments [part][k-step] and V transposing reads [part]
+    int koff[2][2], voff[2];
+    {
+        const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) koff[part][s] = r * RB + 16 * (((A::SP ? 4 * part : 0) + 2 * s + hh) ^ G::kswz(r));
+        const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3, vr = 4 * hh + q4;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) voff[part] = img + vr * RB + (((A::SP ? 64 * part : 0) + 32 * g1 + 8 * p4) ^ (16 * G::vswz(vr)));
+    }
+    constexpr int RPI = 64 / CPR;                                      // rows per output store instruction (whole lines: CPR lanes x 16 B per row)
+    constexpr int NST = 32 / RPI;                                      // store instructions per row tile
+    // the PREVIOUS pair's row waits in the staging tile: its NST stores (and the log-sum-exp) leave one per key-tile step of the current
+    // pair - a burst of stores at the end of a row held the vector-memory path for ~3,000 cycles, and the next loads queued behind it
+    // (first pair: nothing is pending yet - the steps then send the unwritten staging tile to the row's OWN output lines, which the same wave
+    // overwrites with the real row one pair later, in program order)
+    E* pend_out = nullptr;
+    int pend_rows = 1;                                                 // valid rows of the pending tile
+    auto flush_one = [&](int i) __attribute__((always_inline)) {
+        const int r = i * RPI + lane / CPR, ch = lane % CPR;
+        if (r < pend_rows) {
+            const uint4 v = *(const uint4*)(stage + r * SPB + 16 * ch);
+            *(uint4*)((char*)(pend_out + (long)r * H * HD * EP) + 16 * ch) = v;
+        }
+    };
+    int rnd_no = -1;
+    (void)rnd_no;
+    for (int kp = 0; kp < npl; ++kp) {
+        ++rnd_no;
+        ATTN_STAMP(10);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                  // pair kp has landed (producer's wait), slot (kp + 1) & 1 is free
+        ATTN_SB();
+        ATTN_STAMP(0);
+        const int bid = pair_bid(kp);
+        const int b = bid / H, h = bid % H;
+        const int bidn = pair_bid(kp + 1 < npl ? kp + 1 : kp);
+        const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
+        if (producer) {
+            if (kp + 1 < npl) {
+                for (int pi = 0; pi < NP; ++pi) {
+                    dma_piece(basen, (kp + 1) & 1, pi);
+                    __builtin_amdgcn_s_sleep(1);                       // paced: ~50 pieces over the round, never a burst
+                }
+                wait_vm<0>();
+            }
+            continue;
+        }
+        if (!act) continue;
+        frag_t qf[2], ql[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { qf[s] = qnf[s]; ql[s] = qnl[s]; }
+        if (kp == 0) {
+            pend_out = out + (((long)b * Tn + wave * 32) * H * HD + h * HD) * EP;
+            pend_rows = Tn - wave * 32 < 32 ? Tn - wave * 32 : 32;
+        }
+        // running per-lane LDS addresses of the current key tile (advanced by one tile per step: tile offsets stay immediates)
+        const char* slot = lds + (kp & 1) * slotb;
+        const char* ka[2][2];
+        const char* va[2];
+#pragma unroll
+        for (int part = 0; part <= LO; ++part) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) ka[part][s] = slot + koff[part][s];
+            va[part] = slot + voff[part];
+        }
+        float m2 = -INFINITY, lsum = 0.f;
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        // ---- fragment reads: K row fragments of the tile `dt` tiles ahead of the running address, V transposed fragments likewise
+        auto read_k = [&](frag_t (&kf)[2][2], int dt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int part = 0; part <= LO; ++part) kf[part][s] = *(const frag_t*)(ka[part][s] + dt * 32 * RB);
+        };
+        auto read_v = [&](frag_t (&vf)[2][2], int dt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int part = 0; part <= LO; ++part) {
+                    union { struct { s16x4 a, b; } s2; frag_t v; } u;
+                    const char* p0 = va[part] + (dt * 32 + 16 * s) * RB;
+                    u.s2.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p0);
+                    u.s2.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 8 * RB));
+                    vf[part][s] = u.v;
+                }
+        };
+        // MFMA number i of a tile product: split: k-step i / 3, terms lo * hi, hi * lo, hi * hi; plain: k-step i
+        auto mma_i = [&](int i, const frag_t (&a)[2][2], const frag_t (&bh)[2], const frag_t (&bl)[2], f32x16& acc) __attribute__((always_inline)) {
+            if constexpr (A::SP) {
+                const int s = i / 3, term = i % 3;
+                acc = MmaTraits_mma(term == 0 ? a[1][s] : a[0][s], term == 1 ? bl[s] : bh[s], acc);
+            } else {
+                acc = MmaTraits_mma(a[0][i], bh[i], acc);
+            }
+        };
+        auto max16 = [&](const f32x16& sc) __attribute__((always_inline)) {   // (v_max3 by hand: fmaxf on MFMA results gets a canonicalising v_max each)
+            float cm;
+            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(cm) : "v"(sc[0]), "v"(sc[1]), "v"(sc[2]));
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(cm) : "v"(cm), "v"(sc[r]), "v"(sc[r + 1]));
+            asm("v_max_f32 %0, %1, %2" : "=v"(cm) : "v"(cm), "v"(sc[15]));
+            return cm;
+        };
+        auto mask_tile = [&](f32x16& sc, int kt) __attribute__((always_inline)) {
+            const int lim = Tn - kt * 32;                              // (uniform) valid keys of this tile
+            if (lim < 32) {                                            // keys past Tn: whatever bytes the image overrun holds
+                const int lr = lim - 4 * (lane >> 5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = (r & 3) + 8 * (r >> 2) >= lr ? -INFINITY : sc[r];
+            }
+        };
+        // One key tile.  `cur` holds S^T of tile t, `nxt` receives S^T of tile t + 1 (K fragments fin_k), the PV product of tile t uses fin_v;
+        // the fragments of the NEXT step (K of tile t + 2, V of tile t + 1) are requested in the middle of this one into fout_k / fout_v.
+        // cmax = this lane's maximum over cur (unscaled), produced by the previous step.
+        // Side jobs ride on the first steps (JOB = step number 0 .. 3, -1: none): step i sends out store i of the pending tile (i < NST), step 0
+        // the pending log-sum-exp, steps 1 and 2 fetch the next pair's Q fragments - all compile-time, the step bodies stay straight-line.
+        auto step = [&](f32x16& cur, f32x16& nxt, frag_t (&fin_k)[2][2], frag_t (&fin_v)[2][2], frag_t (&fout_k)[2][2], frag_t (&fout_v)[2][2],
+                        int t, float& cmax, auto job) __attribute__((always_inline)) {
+            constexpr int JOB = decltype(job)::value;
+            {   // running maximum, lazily: rescale only when this tile exceeds the reference by more than 2^24 in the probabilities
+                const float cm = fmaxf(cmax, xhalf(cmax)) * c;
+                if (__builtin_amdgcn_ballot_w64(cm > m2 + 24.f) != 0) {
+                    const float mn = fmaxf(m2, cm);
+                    const float alpha = __builtin_amdgcn_exp2f(m2 - mn);
+                    m2 = mn;
+                    lsum *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+                }
+            }
+            ATTN_SB();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nxt[r] = 0.f;
+            auto ex = [&](int r0, int r1) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = r0; r < r1; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(cur[r], c, -m2));
+                    cur[r] = pr;
+                    lsum += pr;
+                }
+            };
+            frag_t ph[2], pl[2];
+            auto pk = [&](int s) __attribute__((always_inline)) {
+                pack8<T>(cur, s, ph[s], pl[s]);
+                if constexpr (!A::SP) pl[s] = ph[s];
+            };
+            // (branch-free: rows past the tile's end repeat its last row - same bytes to the same address; the Q fetch of the last pair
+            // repeats the current one)
+            const int srow = min(JOB * RPI + lane / CPR, pend_rows - 1);   // row of the pending tile this step sends out
+            uint4 sv = make_uint4(0, 0, 0, 0);
+            if constexpr (JOB >= 0 && JOB < NST) sv = *(const uint4*)(stage + srow * SPB + 16 * (lane % CPR));
+            auto side = [&]() __attribute__((always_inline)) {
+                if constexpr (JOB >= 0 && JOB < NST) *(uint4*)((char*)(pend_out + (long)srow * H * HD * EP) + 16 * (lane % CPR)) = sv;
+                if constexpr (JOB == 1 || JOB == 2) {
+                    constexpr int s = JOB - 1;
+                    const int q = wave * 32 + (lane & 31);
+                    const int qc = q < Tn ? q : Tn - 1;
+                    qnf[s] = *(const frag_t*)(basen + (long)qc * rs + 16 * s + 8 * (lane >> 5));
+                    if constexpr (A::SP) qnl[s] = *(const frag_t*)(basen + (long)qc * rs + 32 + 16 * s + 8 * (lane >> 5));
+                    else qnl[s] = qnf[s];
+                }
+            };
+            // score MFMAs of tile t + 1 under the exp2 work of tile t
+            if constexpr (A::SP) {
+                ATTN_FSTAMP(11);
+                mma_i(0, fin_k, qf, ql, nxt); ex(0, 3); ATTN_SB();
+                ATTN_FSTAMP(12);
+                mma_i(1, fin_k, qf, ql, nxt); ex(3, 6); ATTN_SB();
+                ATTN_FSTAMP(13);
+                mma_i(2, fin_k, qf, ql, nxt); ex(6, 8); ATTN_SB();
+                ATTN_FSTAMP(14);
+                mma_i(3, fin_k, qf, ql, nxt); pk(0); ATTN_SB();
+                ATTN_FSTAMP(15);
+                read_k(fout_k, 2);
+                read_v(fout_v, 1);
+                ATTN_SB();
+                ATTN_FSTAMP(16);
+                mma_i(4, fin_k, qf, ql, nxt); ex(8, 11); ATTN_SB();
+                ATTN_FSTAMP(17);
+                mma_i(5, fin_k, qf, ql, nxt); ex(11, 14); ATTN_SB();
+                ATTN_FSTAMP(18);
+                // PV MFMAs of tile t under the rest of its exp2 / packing and the row maximum of tile t + 1
+                mma_i(0, fin_v, ph, pl, o); ex(14, 16); ATTN_SB();
+                ATTN_FSTAMP(19);
+                mma_i(1, fin_v, ph, pl, o); pk(1); ATTN_SB();
+                ATTN_FSTAMP(20);
+                mma_i(2, fin_v, ph, pl, o); ATTN_SB();
+                side();
+                mma_i(3, fin_v, ph, pl, o); ATTN_SB();
+                mma_i(4, fin_v, ph, pl, o); ATTN_SB();
+                mma_i(5, fin_v, ph, pl, o); ATTN_SB();
+                ATTN_FSTAMP(21);
+                mask_tile(nxt, t + 1);
+                cmax = max16(nxt);
+                ATTN_FSTAMP(22);
+            } else {
+                mma_i(0, fin_k, qf, ql, nxt); ex(0, 8); ATTN_SB();
+                read_k(fout_k, 2);
+                read_v(fout_v, 1);
+                ATTN_SB();
+                mma_i(1, fin_k, qf, ql, nxt); pk(0); ex(8, 16); ATTN_SB();
+                mma_i(0, fin_v, ph, pl, o); pk(1); ATTN_SB();
+                side();
+                mma_i(1, fin_v, ph, pl, o); ATTN_SB();
+                mask_tile(nxt, t + 1);
+                cmax = max16(nxt);
+            }
+            // advance the running addresses by one key tile
+#pragma unroll
+            for (int part = 0; part <= LO; ++part) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) ka[part][s] += 32 * RB;
+                va[part] += 32 * RB;
+            }
+        };
+        // The LAST key tile: no next tile to score, and only the accumulator rows that hold keys below Tn are worked on - row group g
+        // (registers 4 g .. 4 g + 3 = keys 8 g .. 8 g + 7 of the tile) is skipped when 8 g >= the tile's valid keys, a whole k-step of the PV
+        // product when both its groups are (T = 197: 5 keys left - one group of four, one k-step of two).
+        auto last_step = [&](f32x16& cur, frag_t (&fin_v)[2][2], int t, float cmax) __attribute__((always_inline)) {
+            {
+                const float cm = fmaxf(cmax, xhalf(cmax)) * c;
+                if (__builtin_amdgcn_ballot_w64(cm > m2 + 24.f) != 0) {
+                    const float mn = fmaxf(m2, cm);
+                    const float alpha = __builtin_amdgcn_exp2f(m2 - mn);
+                    m2 = mn;
+                    lsum *= alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+                }
+            }
+            const int ng = (Tn - t * 32 + 7) >> 3;                     // (uniform) row groups with a valid key: 1 .. 4
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (2 * s < ng) {
+#pragma unroll
+                    for (int g = 2 * s; g < 2 * s + 2; ++g) {
+                        if (g < ng) {
+#pragma unroll
+                            for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                                const float pr = __builtin_amdgcn_exp2f(fmaf(cur[r], c, -m2));   // (masked keys: exp2(-inf) = 0)
+                                cur[r] = pr;
+                                lsum += pr;
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 4 * g; r < 4 * g + 4; ++r) cur[r] = 0.f;
+                        }
+                    }
+                    frag_t ph, pl;
+                    pack8<T>(cur, s, ph, pl);
+                    if constexpr (!A::SP) pl = ph;
+                    o = mma3<T>(fin_v[0][s], fin_v[LO][s], ph, pl, o);
+                }
+            }
+        };
+        f32x16 sA, sB;
+        float cmax;
+        frag_t fk0[2][2], fv0[2][2], fk1[2][2], fv1[2][2];
+        {   // S^T of tile 0; fragments of step 0 (K of tile 1, V of tile 0)
+            frag_t kf[2][2];
+            read_k(kf, 0);
+            read_k(fk0, 1);
+            read_v(fv0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sA[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NQK; ++i) mma_i(i, kf, qf, ql, sA);
+            mask_tile(sA, 0);
+            cmax = max16(sA);
+        }
+        ATTN_STAMP(2);
+        // (nt >= 4: checked by the launcher)
+        step(sA, sB, fk0, fv0, fk1, fv1, 0, cmax, std::integral_constant<int, 0>{});
+        step(sB, sA, fk1, fv1, fk0, fv0, 1, cmax, std::integral_constant<int, 1>{});
+        step(sA, sB, fk0, fv0, fk1, fv1, 2, cmax, std::integral_constant<int, 2>{});
+        step(sB, sA, fk1, fv1, fk0, fv0, 3, cmax, std::integral_constant<int, 3>{});
+        // (steps 0 .. 3 were full steps: nt >= 5, checked by the launcher; tiles 4 .. nt - 2 likewise, tile nt - 1 is the last)
+        int t = 4;
+        for (; t + 2 < nt; t += 2) {
+            step(sA, sB, fk0, fv0, fk1, fv1, t, cmax, std::integral_constant<int, -1>{});
+            step(sB, sA, fk1, fv1, fk0, fv0, t + 1, cmax, std::integral_constant<int, -1>{});
+        }
+        if (t + 1 < nt) {
+            step(sA, sB, fk0, fv0, fk1, fv1, t, cmax, std::integral_constant<int, -1>{});
+            last_step(sB, fv1, t + 1, cmax);
+        } else {
+            last_step(sA, fv0, t, cmax);
+        }
+        ATTN_STAMP(3);
+        lsum += xhalf(lsum);
+        // ---- the row goes into the wave's staging tile: lane (q, h) writes its 8-byte pieces; it leaves during the next pair's steps
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (the pending tile has been read out)
+        {
+            const float inv = 1.0f / lsum;
+            char* srow = stage + (lane & 31) * SPB;
+            typedef typename Vec4<T>::type V4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                V4 oh, ol;
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    E h0, h1, l0, l1;
+                    cvt_pair<E, A::SP>(o[4 * g + j] * inv, o[4 * g + j + 1] * inv, h0, h1, l0, l1);
+                    oh[j] = h0;
+                    oh[j + 1] = h1;
+                    if constexpr (A::SP) { ol[j] = l0; ol[j + 1] = l1; }
+                }
+                *(V4*)(srow + (8 * g + 4 * (lane >> 5)) * 2) = oh;
+                if constexpr (A::SP) *(V4*)(srow + 64 + (8 * g + 4 * (lane >> 5)) * 2) = ol;
+            }
+        }
+        pend_out = out + (((long)b * Tn + wave * 32) * H * HD + h * HD) * EP;
+        pend_rows = Tn - wave * 32 < 32 ? Tn - wave * 32 : 32;
+        if (lane < pend_rows) lse[((long)b * H + h) * Tn + wave * 32 + lane] = (m2 + log2f(lsum)) * 0.6931471805599453f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vm<0>();                                                  // the next pair's Q fragments have landed; the stores in front of them left half a row ago
+        touch_q(qnf, qnl);
+        ATTN_SB();
+        ATTN_STAMP(4);
+    }
+    if (!producer && act) {                                            // the last row
+        for (int i = 0; i < NST; ++i) flush_one(i);
     }
 }
 
@@ -483,8 +968,33 @@ __global__ __launch_bounds__(256) void colsum_t_kernel(const typename Vec4<T>::e
     }
 }
 
+int attn_cus() {   // CUs of the CURRENT device, rounded down to a multiple of 8 (a persistent workgroup's pairs stay on its XCD)
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    return n & ~7;
+}
+// A/B switch read from the environment: once per process, or at every launch when MFVIT_AB_LIVE=1 (the in-process A/B tools set it)
+int ab_switch(const char* name, int dflt, int& cache) {
+    static const bool live = [] { const char* e = getenv("MFVIT_AB_LIVE"); return e && e[0] == '1'; }();
+    if (cache == INT_MIN || live) { const char* e = getenv(name); cache = e ? atoi(e) : dflt; }
+    return cache;
+}
+
 template <typename T> int launch_fwd_t(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
     typedef typename Vec4<T>::elem E;
+    {   // persistent pair-synchronous kernel: enough pairs to fill every CU twice, 5 - 7 row tiles per pair (one per computing wave)
+        static int sw = INT_MIN;
+        const int cus = attn_cus();
+        const int nt = (Tn + 31) >> 5;
+        const int bytes = RingGeo<T>::lds_bytes(Tn);
+        if (ab_switch("MFVIT_ATTN_FWD_RING", 1, sw) && B * H >= 2 * cus && nt >= 5 && nt <= RingGeo<T>::NCW && bytes <= 160 * 1024) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
+            MFVIT_LAUNCH((attn_fwd_pp_kernel<T>), dim3(cus), dim3(512), bytes, st, (const E*)qkv, (E*)out, lse, Tn, H, 1.0f / sqrtf((float)HD), B * H);
+            MFVIT_CHECK_LAUNCH();
+            return MFVIT_OK;
+        }
+    }
     const int Tpad = (Tn + 31) & ~31;
     const int bytes = Tpad * (AttnT<T>::RSB + AttnT<T>::RB);
     static bool attr = false;
@@ -570,3 +1080,9 @@ int attn_bwd_mfma(int dtype, const void* qkv, const void* out, const void* dout,
 }
 
 }  // namespace mfvit
+
+#ifdef MFVIT_ATTN_STAMP
+extern "C" int mfvit_debug_attn_stamps(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(mfvit::g_attn_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
