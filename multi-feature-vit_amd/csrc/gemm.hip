@@ -1152,7 +1152,56 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
         if (d) atomicAdd(d + c % ncols, s);
     }
 }
+#define MFVIT_TRY_RC(expr) do { int rc__ = (expr); if (rc__ != MFVIT_OK) return rc__; } while (0)
+// The same for a BATCH of partial buffers in one launch (blockIdx.z = job): the encoder backward gives every row-kernel launch of a call its
+// own partial buffer and reduces them all at the end of the call - one launch instead of 25 (round 3: 50 launches of 4.4 us + their
+// boundaries per step).
+__global__ __launch_bounds__(256) void colpart_reduce_batch_kernel(ColpartBatch b) {
+    const ColpartJob& j = b.job[blockIdx.z];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int g0 = blockIdx.y * 32;
+    if (g0 >= j.G) return;
+    __shared__ float sm[4][64];
+    float s = 0.f;
+    if (c < j.nq * j.ncols) {
+        const int g1 = g0 + 32 < j.G ? g0 + 32 : j.G;
+        for (int g2 = g0 + sub; g2 < g1; g2 += 4) s += j.part[(long)g2 * j.nq * j.ncols + c];
+    }
+    sm[sub][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sub == 0 && c < j.nq * j.ncols) {
+        s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+        float* d = j.d[c / j.ncols];
+        if (d) atomicAdd(d + c % j.ncols, s);
+    }
+}
+static thread_local ColpartBatch* g_colpart_batch = nullptr;
+ColpartBatch* colpart_batch_begin(ColpartBatch* b) {
+    ColpartBatch* prev = g_colpart_batch;
+    if (b) b->n = 0;
+    g_colpart_batch = b;
+    return prev;
+}
+int colpart_batch_flush(hipStream_t st) {
+    ColpartBatch* b = g_colpart_batch;
+    if (!b || b->n == 0) return MFVIT_OK;
+    int gmax = 0, cmax = 0;
+    for (int i = 0; i < b->n; ++i) {
+        gmax = b->job[i].G > gmax ? b->job[i].G : gmax;
+        cmax = b->job[i].nq * b->job[i].ncols > cmax ? b->job[i].nq * b->job[i].ncols : cmax;
+    }
+    MFVIT_LAUNCH(colpart_reduce_batch_kernel, dim3((cmax + 63) / 64, (gmax + 31) / 32, b->n), dim3(256), 0, st, *b);
+    b->n = 0;
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
 int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float* d1, float* d2, hipStream_t st) {
+    if (ColpartBatch* b = g_colpart_batch) {                  // deferred: reduced by colpart_batch_flush (every job has its OWN partial buffer)
+        if (b->n == ColpartBatch::MAXJ) MFVIT_TRY_RC(colpart_batch_flush(st));
+        ColpartJob& j = b->job[b->n++];
+        j.part = part; j.G = G; j.ncols = ncols; j.nq = nq; j.d[0] = d0; j.d[1] = d1; j.d[2] = d2;
+        return MFVIT_OK;
+    }
     MFVIT_LAUNCH(colpart_reduce_kernel, dim3((nq * ncols + 63) / 64, (G + 31) / 32), dim3(256), 0, st, part, G, ncols, nq, d0, d1, d2);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;

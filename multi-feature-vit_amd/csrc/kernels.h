@@ -27,6 +27,12 @@ int gemm_tn(int dtype, const GemmP& p, hipStream_t st);
 bool gemm_tn_glds_supported(int dtype, const GemmP& p);   // gemm_tn2.hip
 int gemm_tn_glds(int dtype, GemmP p, hipStream_t st);
 int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float* d1, float* d2, hipStream_t st);
+// deferred / batched form: between colpart_batch_begin(&batch) and colpart_batch_begin(previous) every colpart_reduce call of this thread
+// is queued (its partial buffer must stay untouched until the flush) and colpart_batch_flush reduces all queued jobs in ONE launch
+struct ColpartJob { const float* part; float* d[3]; int G, ncols, nq; };
+struct ColpartBatch { static constexpr int MAXJ = 32; int n; ColpartJob job[MAXJ]; };
+ColpartBatch* colpart_batch_begin(ColpartBatch* b);
+int colpart_batch_flush(hipStream_t st);
 bool gemm_tn_pair_supported(int dtype, const GemmP& a, const GemmP& b);   // gemm_tn2.hip: two weight gradients in one launch
 int gemm_tn_glds_pair(int dtype, GemmP a, const GemmP& b, hipStream_t st);
 int tn_partial_reduce(const float* part, int splits, int N, int K, float* out, long ldo, hipStream_t st);   // out += sum of the split partials [splits][N][K]

@@ -135,7 +135,7 @@ struct WsLayout {
     size_t blk0, blk_stride;    // per block (depth or 1 copies):
     size_t y1, qkv, attn, lse, xmid, st2, y2, hpre, hact;
     // backward scratch
-    size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart, tnpart;
+    size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart, colpart_stride = 0, tnpart;
     size_t dtmp;                // token-input mode with residual dropout: [M][D] of the operand type (branch output before the dropout; masked dY)
     size_t pp_stride;           // distance between the two ping-pong copies of gxT / gmidT / dhpre / dqkv (0 = none)
     size_t total;
@@ -177,7 +177,8 @@ WsLayout ws_layout(const Dims& d) {
             size_t a = ((M + 63) / 64 + 256) * 3 * D, b2 = ((M + 127) / 128) * F, c2 = 256 * 3 * D;   // row kernels: <= M/64 + 256 blocks (balanced rows)
             size_t n = a > b2 ? a : b2;
             n = n > c2 ? n : c2;
-            W.colpart = o; o += align256(n * 4);
+            W.colpart = o; o += (2 * nl + 2) * align256(n * 4);          // one partial buffer per row-kernel launch of a backward call (batched reduce)
+            W.colpart_stride = align256(n * 4);
         }
         // split partials of the weight-gradient GEMMs (side stream, one GEMM at a time): splits * N * K floats, and
         // tiles * splits <= 384 blocks of 128 x 128  =>  at most 384 * 16384 floats
@@ -479,7 +480,16 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     float* gx = (float*)(ws + W.gx);
     float* gmid = (float*)(ws + W.gmid);
     float* colscr = (float*)(ws + W.colscratch);
-    float* colpart = (float*)(ws + W.colpart);
+    // column-sum partials: every row-kernel launch of this call writes its own buffer, ONE batched launch reduces them (before the embedding
+    // stage, which reads a sum, and at the end of the call); with residual dropout (intermediate sums are consumed at once) nothing is deferred
+    int colpart_used = 0;
+    auto next_colpart = [&]() { return (float*)(ws + W.colpart + (size_t)(colpart_used++ % (2 * d.depth + 2)) * W.colpart_stride); };
+    ColpartBatch cbatch;
+    struct BatchScope {
+        ColpartBatch* prev; bool on;
+        BatchScope(ColpartBatch* b, bool on_) : on(on_) { if (on) prev = colpart_batch_begin(b); }
+        ~BatchScope() { if (on) colpart_batch_begin(prev); }
+    } batch_scope(&cbatch, !(d.p_resid > 0.f));
     // split partials of the wgrad GEMMs through scratch (plain stores + one reduce launch) instead of float atomics: opt-in (MFVIT_TN_PART=1;
     // what it buys is a deterministic dW).  Measured inside the step, round 3, with the store path in the LDS-DMA wgrad kernel itself: class
     // average 77.2 -> 80.8 us including the reduce launch, step 30.85 -> 31.0 ms (profiles/r03_wgrad_ab.txt) - the atomics of a launch (16.5 MB)
@@ -514,7 +524,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
             if (!dfeatures) return MFVIT_EINVAL;
             MFVIT_TRY(ln_bwd_rows(d.dtype, d.D, dfeatures, D, xbuf(d.depth), D, stat(d.depth), stat(d.depth) + d.M, params + L.norm_w,
                                   nullptr, 0, gx, D, pp(W.gxT, d.depth - 1), D * e, dparams + L.norm_w, dparams + L.norm_b,
-                                  rdrop ? colscr + D : gblk(d.depth - 1) + L.fc2_b, colpart, d.M, 1, 0, st));
+                                  rdrop ? colscr + D : gblk(d.depth - 1) + L.fc2_b, next_colpart(), d.M, 1, 0, st));
         } else if (s >= 0) {
             const int l = s;
             char* b = blk(l);
@@ -571,7 +581,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 if (lean_grad) { p.res_t = gxT; p.ldres_t = D * e; p.out0 = nullptr; }
                 else { p.res = gx; p.ldres = D; p.out0 = gmid; }
                 p.ldo0 = D; p.out1 = gmidT; p.ldo1 = D * e;
-                p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = rdrop ? colscr + D : gb + L.proj_b; p.cpart = colpart;
+                p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = rdrop ? colscr + D : gb + L.proj_b; p.cpart = next_colpart();
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
             const void* gyp = gmidT;                              // dY of proj
@@ -642,10 +652,11 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 if (lean_grad) { p.res_t = gmidT; p.ldres_t = D * e; p.out0 = l == 0 ? gx : nullptr; }     // (the embedding stage reads gx)
                 else { p.res = gmid; p.ldres = D; p.out0 = gx; }
                 p.ldo0 = D; p.out1 = pp(W.gxT, l - 1); p.ldo1 = D * e;
-                p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = (l > 0 && !rdrop) ? gblk(l - 1) + L.fc2_b : colscr; p.cpart = colpart;
+                p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = (l > 0 && !rdrop) ? gblk(l - 1) + L.fc2_b : colscr; p.cpart = next_colpart();
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
         } else if (d.tok) {
+            MFVIT_TRY(colpart_batch_flush(st));
             // token-input embedding stage: gx = d x_0 = d tokens; d pos_emb = sum over the batch (fuseattention.py:187)
             if (d.p_embd > 0.f)      // d (tokens + pos_emb) = d x_0 * mask / (1 - p)
                 MFVIT_TRY(mask_scale_rows(d.dtype, true, gx, D, gx, D, make_drop(d.p_embd, d.seed, 1), d.M, d.D, st));
@@ -653,6 +664,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 return MFVIT_ELAUNCH;
             if (d.use_pos) MFVIT_TRY(batch_sum(gx, dparams + L.pos, d.B, (long)d.T * D, st));
         } else {
+            MFVIT_TRY(colpart_batch_flush(st));                   // (colscr, read below, is one of the deferred sums)
             // embed stage: gx = d x_0.  d cls_token = sum_b gx[b,0]; d pe_b = sum over patch rows; d pe_w = gx_patch^T patches.
             // pos_embed is a fixed table (requires_grad = False upstream): no gradient.
             MFVIT_TRY(colsum_rows(gx, D, dparams + L.cls, d.B, d.T, 0, d.D, st));
@@ -670,6 +682,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
             }
         }
     }
+    MFVIT_TRY(colpart_batch_flush(st));
     if (use_side) {   // join: everything the side stream did is ordered before whatever the caller queues next
         if (hipEventRecord(ss.end, ss.s) != hipSuccess || hipStreamWaitEvent(st, ss.end, 0) != hipSuccess) return MFVIT_ELAUNCH;
     }
