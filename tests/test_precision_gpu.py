@@ -215,6 +215,28 @@ def test_attention_fwd_bwd(mode, B, T, H):
     assert e_o < mode.tol and e_l < 1e-5 and e_d < t and e_b < t
 
 
+@pytest.mark.parametrize("mode", ATT_MODES, ids=[m.name for m in ATT_MODES])
+def test_attention_persistent_kernels_behind_their_switches(monkeypatch, mode):
+    """The persistent producer-wave attention kernels that are NOT the default for a precision (csrc/attention_mfma.hip: the forward for the
+    plain 16-bit types, MFVIT_ATTN_FWD_RING=2; the backward without register prefetch, MFVIT_ATTN_BWD_PP=1) against float64 at B * H = 540."""
+    from mfvit import ops
+    monkeypatch.setenv("MFVIT_AB_LIVE", "1")
+    monkeypatch.setenv("MFVIT_ATTN_FWD_RING", "2")
+    monkeypatch.setenv("MFVIT_ATTN_BWD_PP", "1")
+    B, T, H, D = 45, 197, 12, 384
+    qkv, dout = rnd((B, T, 3 * D), 27), rnd((B, T, D), 28)
+    qd = mode.rounded(qkv).requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qd, H)
+    out, lse = ops.attention_fwd(mode.pack(qkv), H, split=mode.split)
+    e_o, e_l = rel_err(mode.unpack(out), o_ref), rel_err(lse, lse_ref)
+    o_ref.backward(mode.rounded(dout))
+    dqkv, dbias = ops.attention_bwd(mode.pack(qkv), out, mode.pack(dout), lse, H, split=mode.split)
+    e_d, e_b = rel_err(mode.unpack(dqkv), qd.grad), rel_err(dbias, qd.grad.sum((0, 1)))
+    log(f"attention persistent kernels[{mode.name},B={B}] out {e_o:.2e} lse {e_l:.2e} dqkv {e_d:.2e} dbias {e_b:.2e}")
+    t = 2e-4 if mode.split else (4e-3 if mode.name == "fp16" else 2e-2)
+    assert e_o < mode.tol and e_l < 1e-5 and e_d < t and e_b < t
+
+
 def test_layernorm_rows_split_and_f16():
     from mfvit import ops
     rows, N = 333, 384
