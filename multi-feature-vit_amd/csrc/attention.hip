@@ -224,10 +224,9 @@ template <typename T, int HD>
 static int launch_fwd(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
     const int bytes = 2 * Tn * HD * 4;
     if (bytes > 160 * 1024) return MFVIT_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)attn_fwd_exact_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
     MFVIT_LAUNCH((attn_fwd_exact_kernel<T, HD>), dim3(B * H), dim3(256), bytes, st, (const T*)qkv, (T*)out, lse, Tn, H,
@@ -240,10 +239,9 @@ static int launch_bwd(const void* qkv, const void* out, const void* dout, const 
                       hipStream_t st) {
     const int bytes = 2 * Tn * HD * 4 + 2 * Tn * 4;
     if (bytes > 160 * 1024) return MFVIT_EINVAL;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_exact_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
     MFVIT_LAUNCH((attn_bwd_exact_kernel<T, HD>), dim3(B * H), dim3(256), bytes, st, (const T*)qkv, (const T*)out, (const T*)dout, lse,

@@ -1410,17 +1410,7 @@ __global__ __launch_bounds__(256) void colsum_t_kernel(const typename Vec4<T>::e
     }
 }
 
-int attn_cus() {   // CUs of the CURRENT device, rounded down to a multiple of 8 (a persistent workgroup's pairs stay on its XCD)
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-    return n & ~7;
-}
-// A/B switch read from the environment: once per process, or at every launch when MFVIT_AB_LIVE=1 (the in-process A/B tools set it)
-int ab_switch(const char* name, int dflt, int& cache) {
-    static const bool live = [] { const char* e = getenv("MFVIT_AB_LIVE"); return e && e[0] == '1'; }();
-    if (cache == INT_MIN || live) { const char* e = getenv(name); cache = e ? atoi(e) : dflt; }
-    return cache;
-}
+int attn_cus() { return device_cus() & ~7; }   // CUs of the CURRENT device, a multiple of 8 (a persistent workgroup's pairs stay on its XCD)
 
 template <typename T> int launch_fwd_t(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
     typedef typename Vec4<T>::elem E;
@@ -1431,7 +1421,7 @@ template <typename T> int launch_fwd_t(const void* qkv, void* out, float* lse, i
         const int bytes = RingGeo<T>::lds_bytes(Tn);
         // Default: split bf16 only (53 vs 57 - 60 us at the bench shape); the plain 16-bit types are faster on the per-pair kernel (27.5 vs 30 us:
         // their steps are too short for the per-step overheads of the pipeline) - MFVIT_ATTN_FWD_RING=2 forces the persistent kernel for them too.
-        const int want = ab_switch("MFVIT_ATTN_FWD_RING", 1, sw);
+        const int want = env_switch("MFVIT_ATTN_FWD_RING", 1, sw);
         if ((want == 2 || (want == 1 && is_split<T>::value)) && B * H >= 2 * cus && nt >= 5 && nt <= RingGeo<T>::NCW && bytes <= 160 * 1024) {
             (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
@@ -1442,8 +1432,8 @@ template <typename T> int launch_fwd_t(const void* qkv, void* out, float* lse, i
     }
     const int Tpad = (Tn + 31) & ~31;
     const int bytes = Tpad * (AttnT<T>::RSB + AttnT<T>::RB);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
     MFVIT_LAUNCH((attn_fwd_mfma_kernel<T>), dim3(B * H), dim3(256), bytes, st, (const E*)qkv, (E*)out, lse, Tn, H, 1.0f / sqrtf((float)HD));
     MFVIT_CHECK_LAUNCH();
@@ -1456,11 +1446,10 @@ template <typename T> int launch_bwd_t(const void* qkv, const void* out, const v
     const int Tpad = (Tn + 31) & ~31;
     const bool wide = 4 * Tpad * RSB + 2 * Tpad * 4 + Tpad * RB <= 160 * 1024;
     const int bytes = 4 * Tpad * (wide ? RSB : RB) + 2 * Tpad * 4 + Tpad * RB;      // Q, K, V, dO images, lse / D rows, the next pair's O rows
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
     }
     {   // producer-wave kernel without register prefetch: enough pairs to fill every CU twice, 4 - 7 tiles per pair
         static int sw = INT_MIN;
@@ -1468,7 +1457,7 @@ template <typename T> int launch_bwd_t(const void* qkv, const void* out, const v
         const int nt = (Tn + 31) >> 5;
         const int b2 = BwdGeo<T>::lds_bytes(Tn);
         // OPT-IN (MFVIT_ATTN_BWD_PP=1): measured 160 us against 150 - 155 us of the register-prefetch kernel below at the bench shape
-        if (ab_switch("MFVIT_ATTN_BWD_PP", 0, sw) && B * H >= 2 * cus2 && nt >= 4 && nt <= BwdGeo<T>::NCW && b2 <= 160 * 1024) {
+        if (env_switch("MFVIT_ATTN_BWD_PP", 0, sw) && B * H >= 2 * cus2 && nt >= 4 && nt <= BwdGeo<T>::NCW && b2 <= 160 * 1024) {
             (void)hipFuncSetAttribute((const void*)attn_bwd_pp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             {
                 ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
@@ -1487,13 +1476,9 @@ template <typename T> int launch_bwd_t(const void* qkv, const void* out, const v
     {
         ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
         // one persistent workgroup per CU (the LDS images allow no second one): a multiple of 8 so that a workgroup's pairs stay on its XCD
-        static const int cus = [] {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-            return n & ~7;
-        }();
-        const char* eg = getenv("MFVIT_ATTN_BWD_PERSIST");             // 0: one workgroup per pair (A/B switch, read at every launch)
-        const int grid = (B * H < cus || (eg && atoi(eg) == 0)) ? B * H : cus;
+        const int cus = attn_cus();
+        static int swp = INT_MIN;                                      // MFVIT_ATTN_BWD_PERSIST=0: one workgroup per pair
+        const int grid = (B * H < cus || env_switch("MFVIT_ATTN_BWD_PERSIST", 1, swp) == 0) ? B * H : cus;
         if (wide)
             MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RSB>), dim3(grid), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
                          (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD), B * H);

@@ -443,11 +443,10 @@ template <typename T, int NB> int tl_launch_fwd(const void* qkv, void* out, floa
     typedef TG<T, NB> G;
     typedef typename G::E E;
     const int bytes = 2 * TL_CH * G::PITCH;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)attn_tiled_fwd_kernel<T, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute((const void*)attn_tiled_fwd_kernel<T, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        attr = true;
     }
     const int nblk = (Tn + TL_BLK - 1) / TL_BLK;
     ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * G::HD, 0, st);
@@ -465,13 +464,12 @@ template <typename T, int NB> int tl_launch_bwd(const void* qkv, const void* out
     typedef TG<T, NB> G;
     typedef typename G::E E;
     const int bytes_q = 2 * TL_CH * G::PITCH, bytes_kv = 2 * TL_CH * G::PITCH + 2 * TL_CH * 4;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)attn_tiled_bwd_dq_kernel<T, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_q);
         (void)hipFuncSetAttribute((const void*)attn_tiled_bwd_dkv_kernel<T, NB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_kv);
         (void)hipFuncSetAttribute((const void*)attn_tiled_bwd_dq_kernel<T, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_q);
         (void)hipFuncSetAttribute((const void*)attn_tiled_bwd_dkv_kernel<T, NB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_kv);
-        attr = true;
     }
     const int nblk = (Tn + TL_BLK - 1) / TL_BLK;
     const float scale = 1.0f / sqrtf((float)G::HD);

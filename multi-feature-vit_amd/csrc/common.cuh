@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#include <limits.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/mfvit.h"
 
@@ -226,6 +228,38 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + loc;
+}
+
+// A one-time action PER DEVICE (hipFuncSetAttribute is a per-device setting: a process-wide flag left a second GPU with the 64 KB LDS default).
+struct PerDeviceOnce {
+    unsigned long long done = 0;
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;      // unknown device: just do it again
+        const unsigned long long bit = 1ull << dev;
+        if (done & bit) return false;
+        done |= bit;
+        return true;
+    }
+};
+// compute units of the CURRENT device (cached per device)
+inline int device_cus() {
+    static int cache[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev] = n;
+    }
+    return cache[dev];
+}
+// A/B switch from the environment: read ONCE per process into the caller's static cache (INT_MIN = unread), or at every launch when
+// MFVIT_AB_LIVE=1 (the in-process A/B tools and the kernel-variant tests set it) - no getenv on the launch path otherwise.
+inline int env_switch(const char* name, int dflt, int& cache) {
+    static const bool live = [] { const char* e = getenv("MFVIT_AB_LIVE"); return e && e[0] == '1'; }();
+    if (cache == INT_MIN || live) { const char* e = getenv(name); cache = e ? atoi(e) : dflt; }
+    return cache;
 }
 
 // Launch wrapper: clears whatever sticky error code earlier, unrelated runtime calls of this thread left behind (the host

@@ -482,8 +482,8 @@ static int xattn_core_forward(int ndir, const FusLayout& L, const FusWs& W, cons
     }
     {
         const size_t lds = (size_t)(5 * T + 4 * NH * D) * 4;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)x_stream_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        static PerDeviceOnce attr;
+        if (attr.first()) { (void)hipFuncSetAttribute((const void*)x_stream_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         ProfScope ps(PROF_XATTN_FWD, 0, 2.0 * B * T * D * 4 * 2, st);
         MFVIT_LAUNCH(x_stream_fwd_kernel, dim3(B, ndir), dim3(256), lds, st, f_cxr, f_enh, params, L, eps_pre, scale, B, T,
                            ws + W.kq, ws + W.u, ws + W.a, ws + W.st);
@@ -578,8 +578,8 @@ static int xattn_core_backward(int ndir, const FusLayout& L, const FusWs& W, con
     }
     {
         const size_t lds = (size_t)(8 * T + 4 * 5 * D) * 4;
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)x_stream_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        static PerDeviceOnce attr;
+        if (attr.first()) { (void)hipFuncSetAttribute((const void*)x_stream_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         ProfScope ps(PROF_XATTN_BWD, 0, 2.0 * B * T * D * 4 * 3, st);
         MFVIT_LAUNCH(x_stream_bwd_kernel, dim3(B, ndir), dim3(256), lds, st, f_cxr, f_enh, params, L, scale, B, T, ws + W.kq, ws + W.a,
                            ws + W.st, ws + W.du, ws + W.dkq, ws + W.dz0p, dparams, df_cxr, df_enh);

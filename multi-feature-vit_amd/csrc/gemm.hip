@@ -967,12 +967,11 @@ template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStrea
     const int nwg = (p.N / 128) * ((p.M + 127) / 128);
     constexpr int epi_bytes = 128 * (128 * (int)sizeof(T) * EP + 16);
     constexpr int lds_bytes = Loop::LDS_BYTES > epi_bytes ? Loop::LDS_BYTES : epi_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if constexpr (sizeof(T) == 2)
             (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
     }
     ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
     if constexpr (sizeof(T) == 2) {
@@ -987,13 +986,11 @@ template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStrea
             // interleaved loads / LDS stores (default; MFVIT_NT_IL=0: the burst form; read at every launch for A/B runs in one process).
             // Measured inside the step (rocprofv3, serialized streams): fc1 + GELU 138.3 -> 133.1 us, fc2-dgrad 122.7 -> 114.7, qkv 84.0 -> 79.6,
             // proj-dgrad 35.0 -> 32.2; results bit-identical (same MFMA order).
-            const char* eil = getenv("MFVIT_NT_IL");
-            if (deep_ok && !(eil && atoi(eil) == 0)) {
-                static bool a12 = false;
-                if (!a12) {
+            static int sw_il = INT_MIN;
+            if (deep_ok && env_switch("MFVIT_NT_IL", 1, sw_il) != 0) {
+                static PerDeviceOnce a12;
+                if (a12.first())
                     (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-                    a12 = true;
-                }
                 MFVIT_LAUNCH((gemm_nt_tile_kernel<T, EPI, 12>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), lds_bytes, st, p);
                 MFVIT_CHECK_LAUNCH();
                 return MFVIT_OK;
@@ -1043,10 +1040,9 @@ template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v
     constexpr int bytes1 = bytes0 > need2 ? bytes0 : need2;
     constexpr bool lean = WM == 1 && sizeof(T) == 2 && BM == 64;
     constexpr int bytes = lean && ROW_LEAN_LDS > bytes1 ? ROW_LEAN_LDS : bytes1;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_row_kernel<T, REPI, WM, BKB, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        attr_set = true;
     }
     ProfScope ps(REPI == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
     MFVIT_LAUNCH((gemm_nt_row_kernel<T, REPI, WM, BKB, BM>), dim3(row_grid(p, BM)), dim3(WM * 256), bytes, st, p);
@@ -1100,11 +1096,10 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
     }
     const bool xcd1d = p.splits > 1 && p.nb <= 1;
     constexpr int bytes = 2 * (STile<T, 128, KR>::BYTES * 2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        attr_set = true;
     }
     // p.cpart (optional, >= splits * N * K floats): split partials go there as plain stores and are summed by a second kernel
     if (p.nb > 1 || p.splits < 2 || p.ldo0 % 4 || (long)tiles * p.splits > 384) p.cpart = nullptr;   // scratch holds 384 tiles
@@ -1221,10 +1216,6 @@ template <int REPI> static int row_by_dtype(int dtype, const GemmP& p, hipStream
 static int tn_by_dtype(int dtype, const GemmP& p, hipStream_t st) { MFVIT_BY_DTYPE(dtype, (launch_tn<TT>(p, st))) }
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
-    if (gemm_nt_rowt_supported(dtype, epi, p)) return gemm_nt_rowt(epi, p, st);
-    if (gemm_nt_pp_supported(dtype, epi, p)) return gemm_nt_pp(epi, p, st);
-    if (gemm_nt_ws_supported(dtype, epi, p)) return gemm_nt_ws(epi, p, st);
-    if (gemm_nt_pers_supported(dtype, epi, p)) return gemm_nt_pers(dtype, epi, p, st);
     if (epi == EPI_GELU_BWD && p.cpart && p.cs0) {
         const int rc = tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
         if (rc != MFVIT_OK) return rc;

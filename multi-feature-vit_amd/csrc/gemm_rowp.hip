@@ -5,7 +5,7 @@
 // Why (round 3).  gemm_nt_row_kernel runs 394 workgroups of 64 rows, two per CU, on K tiles of HALF a split k group (64 bytes per row, so
 // that two double-buffered workgroups fit the LDS).  Measured consequences: (1) every workgroup streams the whole W[384][K] from L2 - 930 MB
 // per fc2 launch against 155 MB of activations; (2) a 64-byte K tile takes 32-byte pieces out of every 128-byte line and fetches the line
-// again for the next tile: the L2 -> CU traffic in lines is twice the bytes used (gemm_pp.hip measured the same effect on its LDS-DMA ring:
+// again for the next tile: the L2 -> CU traffic in lines is twice the bytes used (the ping-pong kernel of round 3 measured the same effect on its LDS-DMA ring:
 // half the rate); (3) 394 workgroups on 512 slots fill 77 % of the chip.  The kernels are bound by exactly that traffic, not by the matrix
 // pipe (17 - 26 % MFMA-busy) and hardly react to the clock (tools/power_probe.py: fc2 + LN 134 us on zeros vs 139 - 158 us on random data).
 // Here:
@@ -73,10 +73,10 @@ __device__ __forceinline__ void rp_dma16(unsigned voff, const char* sbase, unsig
                  : "memory");
 }
 
-// MODE: the two row-complete epilogues (REPI_RES_LN = 0, REPI_LNBWD_RES = 1; N = 384, one pass) or RP_TILE + EPI_* : the plain linears
-// (qkv, fc1 + GELU, fc2-dgrad * gelu', proj-dgrad) as `npass` passes of 384 columns over the same tile rows - the stage stream runs
-// on across the passes (no fill bubble), the outputs of pass p leave while the MFMAs of pass p + 1 run
-constexpr int RP_TILE = 10;
+// MODE: the two row-complete epilogues (REPI_RES_LN = 0, REPI_LNBWD_RES = 1; N = 384: one pass, npass = 1).  (Round 3 also ran the plain
+// linears on this kernel as `npass` passes of 384 columns, MFVIT_ROWT=1: qkv 107 - 119 us against 80 of the 128 x 128 tile kernel, fc1 + GELU
+// 144 - 152 against 135 - the 8-byte-per-lane partial-line stores of this accumulator layout cost 20 - 45 us per launch; removed in round 4,
+// the measurements stay in DESIGN.md 5.)
 // the same with 4 bytes per lane (used as a register-free "touch": the data lands in a dummy LDS line nobody reads)
 __device__ __forceinline__ void rp_dma4(unsigned voff, const char* sbase, unsigned m0v) {
     unsigned keep;
@@ -88,8 +88,7 @@ __device__ __forceinline__ void rp_dma4(unsigned voff, const char* sbase, unsign
 
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int npass) {
-    constexpr int REPI = MODE < RP_TILE ? MODE : -1;
-    constexpr int EPI = MODE >= RP_TILE ? MODE - RP_TILE : -1;
+    constexpr int REPI = MODE;
     typedef sbf16 T;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -167,12 +166,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     // area: no destination register (a register destination was copied away and reused by the compiler while the load was still in
     // flight - caught by tools/check_vmem_hazards.py - the compiler does not know an asm load is outstanding).
     const int G = npass * nk;                                          // stages of the whole tile
-    float* sbias = (float*)(lds + RP_RING);                            // tile modes: the bias vector (N <= 2048 floats)
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) {
-        // before any LDS-DMA is in flight (the compiler's own wait for these loads would otherwise drain the ring)
-        for (int n = tid; n < p.N; n += 512) sbias[n] = p.bias ? p.bias[n] : 0.f;
-        __syncthreads();
-    }
     {
         const unsigned lpr = (unsigned)(p.K / 32);                             // 128-byte lines per W row
         const unsigned lines = (unsigned)p.N * lpr;                            // all passes
@@ -282,88 +275,17 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         return m0e + (r < rows ? r : rows - 1);
     };
 
-    // ---- tile modes: the outputs of one pass (columns 384 pass .. + 383), straight from the accumulators: a lane owns 4 consecutive columns
-    // of a row, i.e. 8 bytes of the hi part and 8 of the lo part of one line (written whole by 4 lanes x 2 tiles x 2 parts; no LDS staging:
-    // the ring is busy with the next pass).  Then the accumulators start again from zero.
-    auto tile_epilogue = [&](int pass) __attribute__((always_inline)) {
-        if constexpr (EPI >= 0) {
-            typedef typename act_grad_type<T>::type AX;
-            asm volatile("" : "+s"(m0e));
-            fresh_lane();
-            const bool want_grad = EPI == EPI_BIAS_GELU && p.out0 != nullptr;
-#pragma unroll
-            for (int i = 0; i < RP_MF; ++i) {
-                const unsigned m = (unsigned)row_of(i);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int n = pass * RP_N + ncol0 + 16 * j;        // logical column of acc[i][j][0]; n .. n + 3 inside one 32-group
-                    float v[4], d[4];
-                    f32x4v b4 = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU) b4 = *(const f32x4v*)(sbias + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + b4[r];
-                    if constexpr (EPI == EPI_GELU_BWD) {
-                        const f16x4 a4 = *(const f16x4*)((const f16*)p.aux + m * (unsigned)p.ldaux + n);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] *= (float)a4[r];
-                    }
-                    if constexpr (EPI == EPI_BIAS_GELU) {
-                        if (want_grad) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) gelu_both_t<T>(v[r], v[r], d[r]);
-                            f16 a0, a1, a2, a3, u0, u1;
-                            cvt_pair<f16, false>(d[0], d[1], a0, a1, u0, u1);
-                            cvt_pair<f16, false>(d[2], d[3], a2, a3, u0, u1);
-                            f16x4 dv;
-                            dv[0] = a0; dv[1] = a1; dv[2] = a2; dv[3] = a3;
-                            *(f16x4*)((AX*)p.out0 + m * (unsigned)p.ldo0 + n) = dv;
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_t<T>(v[r]);
-                        }
-                    }
-                    bf16 h0, h1, h2, h3, l0, l1, l2, l3;
-                    cvt_pair<bf16, true>(v[0], v[1], h0, h1, l0, l1);
-                    cvt_pair<bf16, true>(v[2], v[3], h2, h3, l2, l3);
-                    bf16x4 hv, lv;
-                    hv[0] = h0; hv[1] = h1; hv[2] = h2; hv[3] = h3;
-                    lv[0] = l0; lv[1] = l1; lv[2] = l2; lv[3] = l3;
-                    void* outp = EPI == EPI_BIAS_GELU ? p.out1 : p.out0;
-                    const unsigned ldo = (unsigned)(EPI == EPI_BIAS_GELU ? p.ldo1 : p.ldo0);
-                    bf16* op = (bf16*)outp + m * ldo + 64 * (n >> 5) + (n & 31);
-                    if (p.rows_per_wg == 77) {                         // (timing experiment MFVIT_ROWT_NOSTORE=1: results invalid)
-                        asm volatile("" ::"v"(hv), "v"(lv));
-                    } else {
-                        *(bf16x4*)op = hv;
-                        *(bf16x4*)(op + 32) = lv;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-
-    {
-        int kt = 0, pass = 0;
-        for (int g = 0; g < G; g += 2) {
-            stage_body(g, wh[0], wl[0], wh[1], wl[1]);
-            advance_streams();
-            stage_body(g + 1, wh[1], wl[1], wh[0], wl[0]);             // (nk is even: checked by the launcher)
-            advance_streams();
-            kt += 2;
-            if (kt == nk) {
-                kt = 0;
-                if constexpr (EPI >= 0) tile_epilogue(pass);
-                ++pass;
-            }
-        }
+    for (int g = 0; g < G; g += 2) {
+        stage_body(g, wh[0], wl[0], wh[1], wl[1]);
+        advance_streams();
+        stage_body(g + 1, wh[1], wl[1], wh[0], wl[0]);                 // (nk is even: checked by the launcher)
+        advance_streams();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                   // the ring is free: epilogue scratch
-    if constexpr (EPI < 0)
-        if (p.rows_per_wg == 78) return;                               // (timing experiment MFVIT_ROWP_NOEPI=1: main loop only, nothing stored)
+#ifdef MFVIT_ABLATE
+    if (p.rows_per_wg == 78) return;                                   // (timing experiment MFVIT_ROWP_NOEPI=1 of an MFVIT_ABLATE build: main loop only, nothing stored)
+#endif
 
     // ------------------------------------------------------------------------------------------------ epilogues
     // acc[i][j][r] = out[m0 + 16 i + fr][48 wave + 16 j + 4 fq + r]; rows past `rows` replicate the tile's last valid row exactly (clamped
@@ -693,15 +615,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     }
 }
 
-int rp_cus() {
-    static const int n = [] {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }();
-    return n;
-}
+int rp_cus() { return device_cus(); }
 
 // rows per tile: the smallest whole number of rounds of one tile per CU that covers M with tiles of at most 112 rows, rows spread evenly
 int rp_rows_per_tile(int M, int cap = RP_TH) {
@@ -714,27 +628,28 @@ template <int MODE> constexpr int rp_cap() { return MODE == REPI_LNBWD_RES ? RP_
 template <int MODE> int launch_rowp(const GemmP& p, hipStream_t st) {
     const int rpt = rp_rows_per_tile(p.M, rp_cap<MODE>());
     const int grid = (p.M + rpt - 1) / rpt;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_rowp_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
-        attr = true;
     }
-    ProfScope ps(MODE >= RP_TILE ? PROF_GEMM_TILE : (MODE == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD), 2.0 * p.M * p.N * p.K, 0, st);
+    ProfScope ps(MODE == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
     GemmP q = p;
-    if (MODE >= RP_TILE) { const char* e = getenv("MFVIT_ROWT_NOSTORE"); q.rows_per_wg = (e && atoi(e)) ? 77 : 0; }
-    else { const char* e = getenv("MFVIT_ROWP_NOEPI"); q.rows_per_wg = (e && atoi(e)) ? 78 : 0; }
+    q.rows_per_wg = 0;
+#ifdef MFVIT_ABLATE
+    { const char* e = getenv("MFVIT_ROWP_NOEPI"); q.rows_per_wg = (e && atoi(e)) ? 78 : 0; }
+#endif
     MFVIT_LAUNCH((gemm_rowp_kernel<MODE>), dim3(grid), dim3(512), RP_LDS, st, q, rpt, p.N / RP_N);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
 
-// MFVIT_ROWP: 0 off, 1 the forward epilogue only (+ bias + residual -> LayerNorm), 2 (default) the LayerNorm-backward epilogue as well.  Read at
-// every launch (A/B runs in one process).  Measured inside the training step (serialized pass, M = 25,216): forward proj + LN 56 -> 54 us,
+// MFVIT_ROWP: 0 off, 1 the forward epilogue only (+ bias + residual -> LayerNorm), 2 (default) the LayerNorm-backward epilogue as well.  Read
+// once (at every launch under MFVIT_AB_LIVE=1: A/B runs in one process).  Measured inside the training step (serialized pass, M = 25,216): forward proj + LN 56 -> 54 us,
 // fc2 + LN 140 -> 105 us; backward class average (fc1-dgrad + qkv-dgrad) 125 -> 95 us once the epilogue fetched x by LDS-DMA (before that
 // 137 / 119 us against 139 / 112 us of gemm_nt_row); whole step 33.85 -> 32.21 ms (profiles/r03_rowp_ab.txt).
 int rowp_mode() {
-    const char* e = getenv("MFVIT_ROWP");
-    return e ? atoi(e) : 2;
+    static int sw = INT_MIN;
+    return env_switch("MFVIT_ROWP", 2, sw);
 }
 
 }  // namespace
@@ -761,34 +676,6 @@ bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
         (p.bias && (size_t)p.bias % 16) || (size_t)p.gamma % 16 || (size_t)p.beta % 16)
         return false;
     return true;
-}
-
-// The plain linears on the same kernel.  OPT-IN (MFVIT_ROWT=1; read at every launch): measured (tools/rowt_check.py, M = 25,216) qkv 107 - 119 us
-// against 79 - 85 us of the 128x128 kernel, fc1 + GELU 144 - 152 vs 135 - 142, fc2-dgrad 143 - 146 vs 122, proj-dgrad 32.8 vs 34.7.  With the output
-// stores switched off (MFVIT_ROWT_NOSTORE=1) the same launches take 82 / 123 / 99 / 23 us: the 8-byte-per-lane partial-line stores of this
-// accumulator layout cost 20 - 45 us per launch (the LDS is full: no staging into whole lines), and even without them the three-pass qkv only
-// ties the tile kernel - outputs of 116 - 232 MB per launch keep these linears on the HBM side of the ridge.
-bool gemm_nt_rowt_supported(int dtype, int epi, const GemmP& p) {
-    const char* e = getenv("MFVIT_ROWT");
-    if (dtype != MFVIT_BF16X3 || !(e && atoi(e) != 0)) return false;
-    if (epi != EPI_BIAS && epi != EPI_BIAS_GELU && epi != EPI_GELU_BWD && epi != EPI_NONE) return false;
-    if (p.N % RP_N || p.N > 2048 || p.K % 64 || p.K < 128 || p.M < 4096 || p.nb > 1) return false;
-    if (epi == EPI_GELU_BWD && (p.cs0 || !p.aux || p.ldaux % 4 || (size_t)p.aux % 8)) return false;   // column sums stay with the 128x128 kernel
-    if (epi == EPI_BIAS_GELU && (!p.out1 || p.ldo1 % 8 || (size_t)p.out1 % 16 || (p.out0 && (p.ldo0 % 4 || (size_t)p.out0 % 8)))) return false;
-    if (epi != EPI_BIAS_GELU && (!p.out0 || p.ldo0 % 8 || (size_t)p.out0 % 16)) return false;
-    if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 32) || (unsigned long long)p.N * p.ldw * 2 >= (1ull << 32)) return false;
-    if ((unsigned long long)p.M * (p.ldo0 > p.ldo1 ? p.ldo0 : p.ldo1) * 2 >= (1ull << 32)) return false;      // 32-bit element offsets
-    if (p.lda % 8 || p.ldw % 8 || (size_t)p.A % 16 || (size_t)p.W % 16) return false;
-    return true;
-}
-int gemm_nt_rowt(int epi, const GemmP& p, hipStream_t st) {
-    switch (epi) {
-        case EPI_BIAS: return launch_rowp<RP_TILE + EPI_BIAS>(p, st);
-        case EPI_BIAS_GELU: return launch_rowp<RP_TILE + EPI_BIAS_GELU>(p, st);
-        case EPI_GELU_BWD: return launch_rowp<RP_TILE + EPI_GELU_BWD>(p, st);
-        case EPI_NONE: return launch_rowp<RP_TILE + EPI_NONE>(p, st);
-    }
-    return MFVIT_EINVAL;
 }
 
 int gemm_nt_rowp(int repi, const GemmP& p, hipStream_t st) {

@@ -377,10 +377,12 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
                     for (int r = 0; r < 16; ++r) {
                         const int n = nw + i * 32 + acc_row(r, lane);
                         const int k = kw + j * 32 + (lane & 31);
-                        if (p.rows_per_wg >= 2) {          // (timing experiment MFVIT_TN2_ATOMX=2 / 3: the same sum in 2 / 3 atomics per element)
+#ifdef MFVIT_ABLATE
+                        if (p.rows_per_wg >= 2) {          // (timing experiment MFVIT_TN2_ATOMX=2 / 3 of an MFVIT_ABLATE build: the same sum in 2 / 3 atomics per element)
                             const float v = acc[i][j][r] / (float)p.rows_per_wg;
                             for (int q = 0; q < p.rows_per_wg; ++q) atomicAdd(out + (long)n * ldo_ + k, v);
                         } else
+#endif
                         atomicAdd(out + (long)n * ldo_ + k, acc[i][j][r]);
                     }
         }
@@ -433,17 +435,18 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     // p.cpart (optional scratch of >= 384 tiles of 128 x 128 floats): split partials as plain stores + one reduce pass
     if (p.splits < 2 || p.ldo0 % 4 || (long)tiles * p.splits > 384) p.cpart = nullptr;
     constexpr int bytes = (is_split<T>::value ? T2_NSP : T2_NS) * T2_STAGE;   // (the pipelined form's ring; the other split forms use three of the four slots)
-    { const char* ex = getenv("MFVIT_TN2_ATOMX"); p.rows_per_wg = ex ? atoi(ex) : 0; }
-    const char* e8 = getenv("MFVIT_TN2_W8");                 // both read at every launch (A/B runs in one process)
-    const char* eil = getenv("MFVIT_TN2_IL");
-    const bool w8 = !(e8 && atoi(e8) == 0), il = !(eil && atoi(eil) == 0);
+    p.rows_per_wg = 0;
+#ifdef MFVIT_ABLATE
+    { const char* ex = getenv("MFVIT_TN2_ATOMX"); p.rows_per_wg = ex ? atoi(ex) : 0; }   // (timing experiment: changes the rounding of dW)
+#endif
+    static int sw8 = INT_MIN, swil = INT_MIN;                // read once, or at every launch under MFVIT_AB_LIVE=1 (A/B runs in one process)
+    const bool w8 = env_switch("MFVIT_TN2_W8", 1, sw8) != 0, il = env_switch("MFVIT_TN2_IL", 1, swil) != 0;
     ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * (p.N + p.res_mod) * p.K, 0, st);
     auto go = [&](auto cs, auto w, auto i) {
         constexpr bool CS = decltype(cs)::value, W8 = decltype(w)::value, IL = decltype(i)::value;
-        static bool attr = false;
-        if (!attr) {
+        static PerDeviceOnce attr;
+        if (attr.first()) {
             (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<T, CS, W8, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            attr = true;
         }
         MFVIT_LAUNCH((gemm_tn_glds_kernel<T, CS, W8, IL>), dim3(tiles * p.splits), dim3(W8 ? 512 : 256), bytes, st, p);
     };

@@ -8,17 +8,9 @@ enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GELU_BWD = 2, EPI_NONE = 3, EPI_BIAS
 enum { REPI_RES_LN = 0, REPI_LNBWD_RES = 1 };
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st);
-bool gemm_nt_pers_supported(int dtype, int epi, const GemmP& p, bool force = false);   // gemm_pers.hip: persistent 256x128 kernel (bf16, short K)
-int gemm_nt_pers(int dtype, int epi, const GemmP& p, hipStream_t st);
-bool gemm_nt_pp_supported(int dtype, int epi, const GemmP& p);   // gemm_pp.hip: ping-pong persistent kernel (split bf16, short K)
-int gemm_nt_pp(int epi, const GemmP& p, hipStream_t st);
-bool gemm_nt_ws_supported(int dtype, int epi, const GemmP& p, bool force = false);   // gemm_ws.hip: warp-specialised persistent kernel
-int gemm_nt_ws(int epi, const GemmP& p, hipStream_t st);
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st);
 bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p);   // gemm_rowp.hip: one tall row-complete tile per CU (split bf16)
 int gemm_nt_rowp(int repi, const GemmP& p, hipStream_t st);
-bool gemm_nt_rowt_supported(int dtype, int epi, const GemmP& p);    // gemm_rowp.hip: the plain linears on the tall-tile kernel (passes of 384 columns)
-int gemm_nt_rowt(int epi, const GemmP& p, hipStream_t st);
 int input_transform(const unsigned char* src, const long long* desc, const int* tables, int n, int S, int crop, const float* mean,
                     const float* stdv, float* out, hipStream_t st);   // input.hip
 int eval_counts(const float* scores, long ld, const int64_t* labels, int n, int C, unsigned long long* conf, unsigned long long* u2,

@@ -303,8 +303,8 @@ template <typename T> int launch_fused(const void* x, long ldx, const void* wqkv
     const int Tpad = (Tn + 31) & ~31;
     const int stage = (96 + Tpad) * 128, images = Tpad * (FT<T>::PITCH + FT<T>::VPITCH);
     const int bytes = 2 * stage > images ? 2 * stage : images;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)mhsa_fused_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    static PerDeviceOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)mhsa_fused_fwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     // algorithmic flops: the projection of this head + the attention core
     ProfScope ps(PROF_ATTN_FWD, 2.0 * B * (double)Tn * 3 * H * FH * D + 4.0 * B * H * (double)Tn * Tn * FH, 0, st);
     MFVIT_LAUNCH((mhsa_fused_fwd_kernel<T>), dim3(B * H), dim3(FNT), bytes, st, (const E*)x, ldx, (const E*)wqkv, ldw, bias, (E*)qkv_out, (E*)out, lse,

@@ -739,30 +739,6 @@ int mfvit_linear_dgrad_act(int dtype, const void* dy, int64_t lddy, const void* 
     p.aux = act_grad; p.ldaux = ldg; p.out0 = dx; p.ldo0 = lddx;
     return gemm_nt_tile(dtype, EPI_GELU_BWD, p, (hipStream_t)stream);
 }
-int mfvit_linear_fwd_persistent(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
-                                int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream) {
-    if (!x || !w || !y) return MFVIT_EINVAL;
-    const int pdt = epilogue >= 100 ? MFVIT_BF16X3 : MFVIT_BF16;     // epilogue + 100: the split-bf16 instantiation (I32 operands / outputs)
-    epilogue = epilogue >= 100 ? epilogue - 100 : epilogue;
-    if (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU && epilogue != EPI_NONE) return MFVIT_EINVAL;
-    if (epilogue == EPI_BIAS_GELU && !y2) return MFVIT_EINVAL;
-    GemmP p = zero_gemm();
-    p.A = x; p.lda = ldx; p.W = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
-    p.bias = bias; p.out0 = y; p.ldo0 = ldy; p.out1 = y2; p.ldo1 = ldy2;
-    if (!gemm_nt_pers_supported(pdt, epilogue, p, true)) return MFVIT_EINVAL;
-    return gemm_nt_pers(pdt, epilogue, p, (hipStream_t)stream);
-}
-int mfvit_linear_fwd_ws(int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y, int64_t ldy,
-                        void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream) {
-    if (!x || !w || !y) return MFVIT_EINVAL;
-    if (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU && epilogue != EPI_NONE) return MFVIT_EINVAL;
-    if (epilogue == EPI_BIAS_GELU && !y2) return MFVIT_EINVAL;
-    GemmP p = zero_gemm();
-    p.A = x; p.lda = ldx; p.W = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
-    p.bias = bias; p.out0 = y; p.ldo0 = ldy; p.out1 = y2; p.ldo1 = ldy2;
-    if (!gemm_nt_ws_supported(MFVIT_BF16, epilogue, p, true)) return MFVIT_EINVAL;
-    return gemm_nt_ws(epilogue, p, (hipStream_t)stream);
-}
 int mfvit_linear_wgrad(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw, int64_t lddw, int M, int N, int K,
                        mfvit_stream_t stream) {
     if (!dy || !x || !dw) return MFVIT_EINVAL;

@@ -50,8 +50,6 @@ SIGNATURES = {
     "mfvit_gpt_backward": (I, [POINTER(VitCfg), P, P, P, P, P, P, P]),
     "mfvit_linear_fwd": (I, [I, I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
     "mfvit_linear_dgrad_act": (I, [I, P, L, P, L, P, L, P, L, I, I, I, P]),
-    "mfvit_linear_fwd_persistent": (I, [I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
-    "mfvit_linear_fwd_ws": (I, [I, P, L, P, L, P, P, L, P, L, I, I, I, P]),
     "mfvit_linear_wgrad": (I, [I, P, L, P, L, P, L, I, I, I, P]),
     "mfvit_linear_wgrad_ws": (I, [I, P, L, P, L, P, L, I, I, I, P, P]),
     "mfvit_linear_wgrad_pair": (I, [I, P, L, P, L, P, L, P, I, P, L, P, L, P, L, I, I, I, P]),

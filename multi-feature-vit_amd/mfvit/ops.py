@@ -44,11 +44,10 @@ def split_unpack(s):
     return (g[..., 0, :] + g[..., 1, :]).reshape(*lead, N2 // 2)
 
 
-def linear_fwd(x, w, bias=None, gelu=False, persistent=False, split=False, want_grad=True):
+def linear_fwd(x, w, bias=None, gelu=False, split=False, want_grad=True):
     """y = x @ w.T + bias (x [M,K], w [N,K] of the same dtype).  gelu=True returns (gelu'(y), gelu(y)); want_grad=False skips the
-    derivative (returns (None, gelu(y))).  persistent=True runs the experimental persistent 256x128 kernel (bf16; split bf16 without
-    GELU), persistent="ws" the warp-specialised one (bf16).  split=True: x, w and the results are split-bf16 storage ([M,2K], [N,2K] ->
-    [M,2N]) - except gelu'(y), which the library keeps as plain fp16 [M,N] for split tensors (it only ever multiplies a gradient)."""
+    derivative (returns (None, gelu(y))).  split=True: x, w and the results are split-bf16 storage ([M,2K], [N,2K] -> [M,2N]) - except
+    gelu'(y), which the library keeps as plain fp16 [M,N] for split tensors (it only ever multiplies a gradient)."""
     require_cuda(x, w, bias)
     code = _code_of(x, split)
     e = 2 if split else 1
@@ -61,15 +60,8 @@ def linear_fwd(x, w, bias=None, gelu=False, persistent=False, split=False, want_
         ldy = N
     else:
         y, y2, ldy = torch.empty(M, N * e, device=x.device, dtype=x.dtype), None, N * e
-    if persistent == "ws":
-        check(lib().mfvit_linear_fwd_ws(epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), ldy, ptr(y2), N, M, N, K,
-                                        stream()), "mfvit_linear_fwd_ws")
-    elif persistent:
-        check(lib().mfvit_linear_fwd_persistent(epi + (100 if split else 0), ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), ldy,
-                                                ptr(y2), N * e, M, N, K, stream()), "mfvit_linear_fwd_persistent")
-    else:
-        check(lib().mfvit_linear_fwd(code, epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), ldy, ptr(y2), N * e, M, N, K,
-                                     stream()), "mfvit_linear_fwd")
+    check(lib().mfvit_linear_fwd(code, epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), ldy, ptr(y2), N * e, M, N, K,
+                                 stream()), "mfvit_linear_fwd")
     return (y, y2) if gelu else y
 
 

@@ -12,6 +12,10 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The library reads its A/B switches (MFVIT_ROWP, MFVIT_TN2_*, MFVIT_ATTN_*, ...) once per process - unless MFVIT_AB_LIVE=1, which makes it
+# read them at every launch: the kernel-variant tests flip them with monkeypatch inside ONE pytest process.  Must be set before the first
+# launch of the process (the flag itself is read once).
+os.environ.setdefault("MFVIT_AB_LIVE", "1")
 
 
 def pytest_configure(config):

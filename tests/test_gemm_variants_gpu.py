@@ -5,8 +5,6 @@ math on the ROUNDED operands (hi + lo), at the bench's row count (M = 128 x 197 
                          x staged by LDS-DMA) vs csrc/gemm.hip gemm_nt_row (MFVIT_ROWP=0)
   weight gradient        csrc/gemm_tn2.hip: 4 / 8 waves x burst / interleaved LDS-DMA issue (MFVIT_TN2_W8, MFVIT_TN2_IL; default 1, 1 = the
                          pipelined 8-wave form with a 4-slot ring)
-  plain linears          the 128x128 tile kernel (default) vs the opt-in ping-pong persistent kernel (MFVIT_PP=2) and tall-tile kernel
-                         (MFVIT_ROWT=1)
 
 The switches are read by the library at every launch, so one process covers all of them.  Tolerances: 3e-5 of the largest output element for
 the GEMM outputs (f32 accumulation of 384 - 25,216 products of 16-bit-exact hi / lo parts), 2e-4 for the column sums over 25,216 rows."""
@@ -146,39 +144,3 @@ def test_weight_gradient_with_partial_scratch(M):
                 ref = a.double().T @ b.double()
             out = ops.linear_wgrad(a, b, scratch=scratch, split=kind == "split")
             assert bool(torch.isfinite(out).all()) and rel(out, ref) < 2e-5, (M, name, kind, rel(out, ref))
-
-
-@pytest.mark.parametrize("M,tag", SHAPES[:2])
-@pytest.mark.parametrize("switch,value", [("MFVIT_PP", "2"), ("MFVIT_ROWT", "1")])
-def test_opt_in_linear_kernels_match_the_tile_kernel(monkeypatch, M, tag, switch, value):
-    """qkv, fc1 + GELU (with and without the derivative), proj-dgrad and fc2-dgrad * gelu' on the opt-in kernels: equal to the default 128x128
-    tile kernel to accumulation-order rounding (bias enters as the accumulator's initial value there: one f32 rounding apart)."""
-    g = _gen(41)
-    x = sp(rn(g, M, D))
-    wq, bq = sp(rn(g, 3 * D, D, sc=.05)), rn(g, 3 * D)
-    w1, b1 = sp(rn(g, F, D, sc=.05)), rn(g, F)
-    wp = sp(rn(g, D, D, sc=.05))
-    w2t = sp(rn(g, F, D, sc=.05))
-    ag = (torch.rand(M, F, device=DEV, generator=g) * 1.2 - 0.1).to(torch.float16)
-    cases = [("qkv", lambda: ops.linear_fwd(x, wq, bq, split=True)),
-             ("fc1+gelu", lambda: ops.linear_fwd(x, w1, b1, gelu=True, split=True)),
-             ("fc1+gelu nograd", lambda: ops.linear_fwd(x, w1, b1, gelu=True, split=True, want_grad=False)),
-             ("proj-dgrad", lambda: ops.linear_fwd(x, wp, None, split=True)),
-             ("fc2-dgrad", lambda: ops.linear_dgrad_act(x, w2t, ag, split=True))]
-
-    def vals(o):
-        """(values, tolerance): split tensors as hi + lo; gelu'(y) is stored as fp16 - one ulp (2^-11 of values up to 1.13) where the f32
-        pre-activation differs in its last bit"""
-        o = o if isinstance(o, (tuple, list)) else (o,)
-        return [None if t is None else ((ops.split_unpack(t), 2e-5) if t.dtype == torch.bfloat16 else (t.float(), 1e-3 if t.dtype == torch.float16 else 2e-5))
-                for t in o]
-
-    for name, fn in cases:
-        monkeypatch.delenv(switch, raising=False)
-        ref = vals(fn())
-        monkeypatch.setenv(switch, value)
-        got = vals(fn())
-        for r_, g_ in zip(ref, got):
-            assert (r_ is None) == (g_ is None), name
-            if r_ is not None:
-                assert rel(g_[0], r_[0]) < g_[1], (tag, switch, name, rel(g_[0], r_[0]))

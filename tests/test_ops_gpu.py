@@ -59,29 +59,6 @@ def test_linear_fwd(dtype, M, N, K):
     assert e1 < tol(dtype) and e2 < tol(dtype)
 
 
-@pytest.mark.parametrize("variant", [True, "ws"])
-@pytest.mark.parametrize("M,N,K", [(197 * 128, 1152, 384), (197 * 33 + 5, 1536, 384), (1100, 384, 1536), (4096, 128, 128)])
-def test_linear_fwd_persistent(M, N, K, variant):
-    """The experimental persistent 256x128 kernels (csrc/gemm_pers.hip; variant "ws" = csrc/gemm_ws.hip, warp-specialised: producer
-    waves own the LDS-DMA, consumer waves the MFMAs) against the same f64 reference and, bit for bit, against the default 128x128
-    kernel (same products, same f32 accumulation order per output element)."""
-    from mfvit import ops
-    dtype = torch.bfloat16
-    x, w, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, 0.05), rnd((N,), torch.float32, 3)
-    xd, wd, bd = x.to(dev()), w.to(dev()), b.to(dev())
-    y = ops.linear_fwd(xd, wd, bd, persistent=variant)
-    ref = x.double() @ w.double().t() + b.double()
-    e = rel_err(y, ref)
-    log(f"linear_fwd_persistent[{variant},{M},{N},{K}]", e)
-    assert e < tol(dtype)
-    assert torch.equal(y, ops.linear_fwd(xd, wd, bd))
-    dact, act = ops.linear_fwd(xd, wd, bd, gelu=True, persistent=variant)
-    dact0, act0 = ops.linear_fwd(xd, wd, bd, gelu=True)
-    assert torch.equal(dact, dact0) and torch.equal(act, act0)
-    y3 = ops.linear_fwd(xd, wd, None, persistent=variant)
-    assert torch.equal(y3, ops.linear_fwd(xd, wd, None))
-
-
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,N,K", [(777, 256, 384), (197 * 4, 1152, 384), (100, 384, 1536), (31, 128, 128), (197 * 64, 1152, 384),
                                    (197 * 33 + 5, 384, 1536), (4099, 128, 128), (197 * 128, 1536, 384)])   # >= 4096 rows: LDS-DMA kernel (bf16), ragged tails

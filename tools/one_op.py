@@ -25,10 +25,6 @@ if SPLIT:
 if op == "qkv":
     x, w, b = r(M, D), r(3 * D, D, sc=.05), r(3 * D, dt=torch.float32)
     fn = lambda: ops.linear_fwd(x, w, b)
-elif op in ("qkv_pers", "fc1_pers"):
-    N = 3 * D if op == "qkv_pers" else 4 * D
-    x, w, b = r(M, D), r(N, D, sc=.05), r(N, dt=torch.float32)
-    fn = lambda: _lf(x, w, b, gelu=(op == "fc1_pers"), persistent=True, split=SPLIT)
 elif op == "fc1":
     x, w, b = r(M, D), r(4 * D, D, sc=.05), r(4 * D, dt=torch.float32)
     fn = lambda: ops.linear_fwd(x, w, b, gelu=True)

@@ -7,7 +7,6 @@ import torch
 from mfvit import ops
 dev = torch.device("cuda:0")
 M, D = 128 * 197, 384
-os.environ.setdefault("MFVIT_PP", "0")
 def mk(zero):
     f = (lambda *s: torch.zeros(*s, device=dev)) if zero else (lambda *s: torch.randn(*s, device=dev))
     x, w = ops.split_pack(f(M, D)), ops.split_pack(f(3 * D, D) * .05)
