@@ -348,7 +348,11 @@ def timed_region(run, steps, warmup, world, dev):
     if os.environ.get("RANK", "0") == "0":
         print(f"[bench] host queued {steps} steps in {1e3 * t_host:.1f} ms of the {1e3 * dt:.1f} ms they took", file=sys.stderr)
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    timed_region.rank_seconds = [dt]
     if world > 1:
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                           # per-rank times: the first multi-GPU run diagnoses its own stragglers
+        timed_region.rank_seconds = [float(x) for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t), loss
 
@@ -392,7 +396,17 @@ def main():
         run.model._two_streams = False
         lib.mfvit_set_wgrad_stream(0)
 
+    run.sync.timing = world > 1
     dt, loss = timed_region(run, args.steps, args.warmup, world, dev)
+    rank_s = list(timed_region.rank_seconds)
+    wait_ms = run.sync.finish_wait_ms() if world > 1 else 0.0
+    run.sync.timing = False
+    wait_all = [wait_ms]
+    if world > 1:
+        w = torch.tensor([wait_ms], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(w) for _ in range(world)]
+        dist.all_gather(every, w)
+        wait_all = [float(x) for x in every]
 
     # attribution pass (untimed, after the timed region): the same step with the two encoder streams and the wgrad side stream
     # serialised, every kernel class timed with HIP events on its launch stream by the library (mfvit_prof_*): each kernel's
@@ -463,10 +477,22 @@ def main():
                                         f"{args.img}x{args.img}, 2x vit_small + cross-attention fusion + CE + backward + Adam; "
                                         f"mode {args.mode} ({'full backward through both backbones' if args.mode == 'T' else 'frozen backbones (README default)'})",
                                global_batch=B * world, mode=args.mode, precision=args.precision, parallelism=f"dp{world}",
-                               streams="serialized" if args.serialize_streams else "two encoder streams + wgrad side streams",
+                               streams="serialized" if args.serialize_streams else "two encoder streams (weight gradients on the encoder's own stream)",
                                algorithmic_gflop_per_pair=GFLOP_PER_PAIR[args.mode] if args.img == 224 else None),
                    model_tflops=(GFLOP_PER_PAIR[args.mode] * B * world * args.steps / dt / 1e3) if args.img == 224 else None,
                    loss=float(loss.detach()), roofline=roof)
+        if world > 1:
+            # self-diagnosis of the data-parallel run: per-rank time of the timed region (stragglers) and how long each rank's compute stream
+            # sat inside GradSync.finish() - the part of the gradient all-reduce that the backward did not hide (includes the warm-up steps'
+            # share only if they overlapped the timed region: the events are reset by finish_wait_ms())
+            n_finish = max(args.steps + max(args.warmup, 1), 1)
+            out["data_parallel"] = dict(rank_ms_per_step=[round(1e3 * t / args.steps, 3) for t in rank_s],
+                                        rank_spread_pct=round(100.0 * (max(rank_s) - min(rank_s)) / max(rank_s), 2),
+                                        grad_sync_wait_ms_per_step=[round(w / n_finish, 3) for w in wait_all],
+                                        bucket_layers=int(os.environ.get("MFVIT_GRAD_BUCKET_LAYERS", "4")),
+                                        bucket_dtype=os.environ.get("MFVIT_GRAD_BUCKET_DTYPE", "f32"),
+                                        note="grad_sync_wait = time the compute stream spent waiting in GradSync.finish() per step (events on the "
+                                             "stream, warm-up steps included in the average): all-reduce time NOT hidden behind the backward")
         print("[bench] gpu " + json.dumps(out), file=sys.stderr, flush=True)
         ref_out = None
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is an N = 1 measurement (the other ranks would only wait for it)

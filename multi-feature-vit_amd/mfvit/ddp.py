@@ -28,6 +28,11 @@ class GradSync:
         self.world = dist.get_world_size(group) if self.enabled else 1
         # RCCL reduces with AVG in one pass; gloo (CPU tests) has no AVG: SUM then scale
         self.avg = self.enabled and dist.get_backend(group) == "nccl"
+        # diagnostics (bench.py --gpus N): with `timing = True` every finish() brackets its waits with events on the current stream, and
+        # finish_wait_ms() tells how long the compute stream sat waiting for exchanges that had not completed - the part of the
+        # all-reduce that backward did NOT hide
+        self.timing = False
+        self._wait_events = []
 
     def _all_reduce(self, t, async_op):
         """Mean over ranks, in place.  ONE call shape for every backend: RCCL reduces with AVG in a single pass; gloo (CPU tests,
@@ -109,6 +114,10 @@ class GradSync:
         """Join the exchanges issued for `owner` (an attached encoder); without an argument, all of them."""
         key = id(owner) if owner is not None else None
         rest = []
+        ev0 = None
+        if self.timing and torch.cuda.is_available() and any(key is None or k == key for k, _, _ in self.handles):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         for k, h, write_back in self.handles:
             if key is not None and k != key:
                 rest.append((k, h, write_back))
@@ -117,3 +126,14 @@ class GradSync:
             if write_back is not None:
                 write_back()
         self.handles = rest
+        if ev0 is not None:
+            ev1.record()
+            self._wait_events.append((ev0, ev1))
+
+    def finish_wait_ms(self, reset=True):
+        """Total time (ms) the current stream spent inside finish() since the last reset: waits for exchanges still on the links plus the
+        write-backs of low-precision buckets.  Call after a synchronize."""
+        t = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        if reset:
+            self._wait_events = []
+        return t

@@ -18,6 +18,52 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+# ---- optional OPERAND-ROUNDING mode (fp16 / bf16 arithmetic of the 16-bit kernels restated on the CPU) -----------------------------
+# Inside ``with rounded_matmul(torch.float16):`` every matrix product of this file (and of ref_moco's MLPs) rounds BOTH operands to
+# that type first and accumulates exactly (the caller's float64); the backward products autograd derives round their operands the same
+# way (dY included).  That is the arithmetic of the reference's autocast path (MAIN_MOCO:349,533: Linear / matmul in fp16, everything
+# else in fp32) and of the HIP 'fp16' mode (operand tensors stored in fp16, f32 accumulate, f32 residual stream / LayerNorm / softmax).
+# Used by tests/test_moco_gpu.py to bound the fp16 gradients against an oracle that makes the SAME roundings, instead of only
+# against float64 (where the ill-conditioned step shows ~10 % rounding-induced difference).
+_MM_DTYPE = None
+
+
+class _RoundedMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, dt):
+        ra, rb = a.to(dt).to(a.dtype), b.to(dt).to(b.dtype)
+        ctx.save_for_backward(ra, rb)
+        ctx.dt, ctx.sa, ctx.sb = dt, a.shape, b.shape
+        return ra @ rb
+
+    @staticmethod
+    def backward(ctx, g):
+        ra, rb = ctx.saved_tensors
+        rg = g.to(ctx.dt).to(g.dtype)
+        da = (rg @ rb.transpose(-1, -2)).sum_to_size(ctx.sa) if ctx.needs_input_grad[0] else None
+        db = (ra.transpose(-1, -2) @ rg).sum_to_size(ctx.sb) if ctx.needs_input_grad[1] else None
+        return da, db, None
+
+
+def mm(a, b):
+    """a @ b, with both operands rounded to the active ``rounded_matmul`` type (if any)."""
+    return a @ b if _MM_DTYPE is None else _RoundedMM.apply(a, b, _MM_DTYPE)
+
+
+class rounded_matmul:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _MM_DTYPE
+        self.prev, _MM_DTYPE = _MM_DTYPE, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _MM_DTYPE
+        _MM_DTYPE = self.prev
+
+
 EMBED = {"vit_small": 384, "vit_base": 768}
 DEPTH = 12
 HEADS = 12
@@ -106,7 +152,7 @@ def patch_embed(p, img):
     w = p["patch_embed.proj.weight"]
     D = w.shape[0]
     x = img.reshape(B, C, gh, PATCH, gw, PATCH).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * PATCH * PATCH)
-    return x @ w.reshape(D, -1).t() + p["patch_embed.proj.bias"]
+    return mm(x, w.reshape(D, -1).t()) + p["patch_embed.proj.bias"]
 
 
 def mhsa(p, pre, y, heads):
@@ -114,21 +160,21 @@ def mhsa(p, pre, y, heads):
     qkv Linear(D,3D,bias) -> (3,B,h,T,d); softmax(q k^T d^-1/2) v; proj."""
     B, T, D = y.shape
     d = D // heads
-    qkv = y @ p[pre + "attn.qkv.weight"].t() + p[pre + "attn.qkv.bias"]
+    qkv = mm(y, p[pre + "attn.qkv.weight"].t()) + p[pre + "attn.qkv.bias"]
     qkv = qkv.reshape(B, T, 3, heads, d).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0], qkv[1], qkv[2]
-    a = (q @ k.transpose(-2, -1)) * (d ** -0.5)
+    a = mm(q, k.transpose(-2, -1)) * (d ** -0.5)
     a = a.softmax(dim=-1)
-    o = (a @ v).transpose(1, 2).reshape(B, T, D)
-    return o @ p[pre + "attn.proj.weight"].t() + p[pre + "attn.proj.bias"]
+    o = mm(a, v).transpose(1, 2).reshape(B, T, D)
+    return mm(o, p[pre + "attn.proj.weight"].t()) + p[pre + "attn.proj.bias"]
 
 
 def block(p, i, x, heads):
     pre = f"blocks.{i}."
     x = x + mhsa(p, pre, layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], LN_EPS), heads)
     y = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], LN_EPS)
-    h = gelu_erf(y @ p[pre + "mlp.fc1.weight"].t() + p[pre + "mlp.fc1.bias"])
-    return x + h @ p[pre + "mlp.fc2.weight"].t() + p[pre + "mlp.fc2.bias"]
+    h = gelu_erf(mm(y, p[pre + "mlp.fc1.weight"].t()) + p[pre + "mlp.fc1.bias"])
+    return x + mm(h, p[pre + "mlp.fc2.weight"].t()) + p[pre + "mlp.fc2.bias"]
 
 
 def depth_of(p):
