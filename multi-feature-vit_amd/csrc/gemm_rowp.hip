@@ -58,6 +58,7 @@ constexpr int RP_LW = 6, RP_LA = 2;             // LDS-DMA instructions per wave
                                                 // counts the same number of operations)
 constexpr int RP_XROWS = 100;                   // LayerNorm-backward mode: tile rows whose x (1536 B each) fit the ring
 constexpr int RP_XDMA = (RP_XROWS * 96 + 511) / 512;   // 16-byte LDS-DMA instructions per thread for them (19: exactly the 152 KB ring)
+constexpr int RP_MINM_FWD = 1, RP_MINM_BWD = 1;   // smallest M per epilogue (tools/rowp_small_m.py)
 constexpr int RP_YP = 1536 + 16;                // staging pitch of a split output row (768 storage elements + pad)
 
 __device__ __forceinline__ const char* rp_uniform_ptr(const void* q) {
@@ -86,7 +87,9 @@ __device__ __forceinline__ void rp_dma4(unsigned voff, const char* sbase, unsign
                  : "memory");
 }
 
-template <int MODE>
+// MF: row fragments of 16 that carry rows (the launcher picks the smallest that covers its rows per tile: the ring always holds RP_TH rows - past
+// the tile they replicate its last row - but only MF fragments are multiplied, reduced and stored: at M = 3,152 a tile has 13 rows)
+template <int MODE, int MF>
 __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int npass) {
     constexpr int REPI = MODE;
     typedef sbf16 T;
@@ -135,30 +138,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         return *(const bf16x8*)(lds + (stage & 1) * RP_WSTAGE + (48 * wave + 16 * j) * 128 + off);
     };
 
-    // Forward epilogue mode: the accumulators START as the residual rows.  The 39 MB of residual rows are then fetched here, under the latency of
-    // the first operand stages, instead of in the epilogue, where nothing overlaps them (the epilogue is exposed HBM streaming: 116 MB per launch
-    // became 77).  Sum order: res + products + bias instead of products + bias + res - one f32 rounding apart.
-    f32x4v acc[RP_MF][3];
-#pragma unroll
-    for (int i = 0; i < RP_MF; ++i) {
-        int r0 = 16 * i + fr;
-        r0 = r0 < rows ? r0 : rows - 1;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if constexpr (REPI == REPI_RES_LN) {
-                // (the load result IS the accumulator: no arithmetic on it here - that would wait for each row's loads in turn; the bias joins in
-                // the epilogue)
-                const int n = 48 * wave + 4 * fq + 16 * j;
-                f32x4v rv = {0.f, 0.f, 0.f, 0.f};
-                if (p.res) rv = *(const f32x4v*)(p.res + (unsigned)(m0 + r0) * (unsigned)p.ldres + n);
-                acc[i][j] = rv;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-            }
-        }
-    }
-
     // prologue.  Inside a training step W is cold, and every CU walks through it in lockstep: each stage would be a first touch served at HBM
     // latency (measured inside the step: fc2 + LN 123 us against 98 us on a warm W).  So first the CUs of an XCD (blockIdx & 7: round-robin
     // dispatch - an assumption for speed only) touch one dword of every 128-byte line of W once, two lines per thread: the stages behind the
@@ -190,19 +169,56 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     for (int st = 1; st < RP_ASLOTS; ++st)
 #pragma unroll
         for (int i = 0; i < RP_LA; ++i) issue_a(st, st, i);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP_LW + (RP_ASLOTS - 1) * RP_LA) : "memory");     // the touches, W(0), A(0) have completed
+    // Forward epilogue mode: the accumulators START as the residual rows.  The 39 MB of residual rows are then fetched here, under the latency of
+    // the first operand stages, instead of in the epilogue, where nothing overlaps them (the epilogue is exposed HBM streaming: 116 MB per launch
+    // became 77).  Sum order: res + products + bias instead of products + bias + res - one f32 rounding apart.
+    f32x4v acc[MF][3];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) {
+        int r0 = 16 * i + fr;
+        r0 = r0 < rows ? r0 : rows - 1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if constexpr (REPI == REPI_RES_LN) {
+                // (the load result IS the accumulator: no arithmetic on it here - that would wait for each row's loads in turn; the bias joins in
+                // the epilogue)
+                const int n = 48 * wave + 4 * fq + 16 * j;
+                f32x4v rv = {0.f, 0.f, 0.f, 0.f};
+                if (p.res) rv = *(const f32x4v*)(p.res + (unsigned)(m0 + r0) * (unsigned)p.ldres + n);
+                acc[i][j] = rv;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+            }
+        }
+    }
+
+    if constexpr (REPI == REPI_RES_LN) {
+        // The residual loads are the YOUNGEST operations in flight: wait for everything here, once, and make the accumulators visibly
+        // defined.  (Issued in front of the LDS-DMA prologue, the compiler - which cannot count asm loads - placed its own
+        // s_waitcnt vmcnt(0) for them in front of the first MFMA of the LOOP: every second stage waited for the activation pieces
+        // just requested, three stages before their use - the lookahead of the A ring was gone.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(acc[i][j]));
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP_LW + (RP_ASLOTS - 1) * RP_LA) : "memory");     // the touches, W(0), A(0) have completed
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 wh[2][3], wl[2][3], ah[RP_MF], al[RP_MF];
+    bf16x8 wh[2][3], wl[2][3], ah[MF > 2 ? MF : 2], al[MF > 2 ? MF : 2];            // ah / al [0], [1]: unused (a01h / a01l hold those fragments)
+    bf16x8 a01h[2][2], a01l[2][2];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         wh[0][j] = frag_w(0, j, f_hi);
         wl[0][j] = frag_w(0, j, f_lo);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        ah[i] = frag_a(0, i, f_hi);
-        al[i] = frag_a(0, i, f_lo);
+    for (int i = 0; i < (MF > 1 ? 2 : 1); ++i) {
+        a01h[0][i] = frag_a(0, i, f_hi);
+        a01l[0][i] = frag_a(0, i, f_lo);
     }
 
     // one stage; `side(slot index 0 .. 62)` runs behind every MFMA
@@ -215,12 +231,46 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         if (wp >= npass) { wp = npass - 1; wk = nk - 1; }
         if (++ak == nk) ak = 0;
     };
-    auto stage_body = [&](int s, bf16x8 (&wH)[3], bf16x8 (&wL)[3], bf16x8 (&wHn)[3], bf16x8 (&wLn)[3]) __attribute__((always_inline)) {
+    // Schedule of one stage (9 MF MFMAs, a side job behind each).  Before the barrier, behind the MFMAs of row fragments 0 .. NB - 1: the reads
+    // of row fragments 2 .. MF - 1 of this stage (one every third MFMA).  The barrier stands behind row fragment NB - 1: every fragment of the
+    // stage is in registers by then (the slot is free) and stage s + 1 - issued a stage earlier - has landed.  Behind it, NJ jobs: this wave's 8
+    // LDS-DMA pieces of W(s + 2) / A(s + 4) into the slots just freed, the 6 W fragments and row fragments 0, 1 of stage s + 1.  MF = 7: barrier
+    // behind the fourth row fragment, jobs on 27 slots (the schedule the round-3 numbers were measured on); MF <= 4: 18 slots, one job each;
+    // MF = 1: 9 slots, two jobs each - such a tile is bound by its 48 KB W stage out of L2, not by the matrix pipe.
+    constexpr int NB = MF >= 7 ? 4 : MF == 6 ? 3 : MF >= 4 ? 2 : MF == 3 ? 1 : 0;
+    constexpr int NPRE = MF > 2 ? 2 * (MF - 2) : 0;                   // fragment reads in front of the barrier
+    constexpr int NAF = MF > 1 ? 4 : 2;                                // A fragment registers of stage s + 1 read behind it
+    constexpr int POST = 9 * (MF - NB);                                // MFMA slots behind the barrier
+    constexpr bool SPACED = POST >= 27;                                // one DMA every third slot (MF >= 5), else the jobs back to back
+    constexpr int NJ = RP_LW + RP_LA + 6 + NAF;
+    constexpr int JPS = SPACED ? 1 : (NJ + POST - 1) / POST;           // jobs per slot
+    static_assert(3 * NB * 3 >= NPRE, "fragment reads must fit in front of the barrier");
+    // (MF <= 4: row fragments 0, 1 of stage s + 1 are read while those of stage s still feed MFMAs - a second register set, like W's)
+    auto stage_body = [&](int s, bf16x8 (&wH)[3], bf16x8 (&wL)[3], bf16x8 (&wHn)[3], bf16x8 (&wLn)[3], bf16x8 (&aH)[2], bf16x8 (&aL)[2],
+                          bf16x8 (&aHn)[2], bf16x8 (&aLn)[2]) __attribute__((always_inline)) {
+        // job k of the back-to-back order: D0 W0 A0 D1 W1 A1 ... (D = LDS-DMA piece, W / A = fragment read of stage s + 1)
+        auto dma_job = [&](int k) __attribute__((always_inline)) {
+            if (k < RP_LW) issue_w(wp, wk, s & 1, k);
+            else issue_a(ak, s & (RP_ASLOTS - 1), k - RP_LW);
+        };
+        auto w_job = [&](int k) __attribute__((always_inline)) {
+            if (k < 3) wHn[k] = frag_w(s + 1, k, f_hi);
+            else wLn[k - 3] = frag_w(s + 1, k - 3, f_lo);
+        };
+        auto a_job = [&](int k) __attribute__((always_inline)) {
+            if constexpr (MF > 1) {
+                if (k < 2) aHn[k] = frag_a(s + 1, k, f_hi);
+                else aLn[k - 2] = frag_a(s + 1, k - 2, f_lo);
+            } else {
+                if (k == 0) aHn[0] = frag_a(s + 1, 0, f_hi);
+                else aLn[0] = frag_a(s + 1, 0, f_lo);
+            }
+        };
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
-            if (i == 4) {
-                // every fragment of stage s is in registers (requested during row fragments 0 - 3); W(s + 1) - and everything older - must
-                // have landed: the only younger operations of this wave are its two pieces of A(s + 3)
+        for (int i = 0; i < MF; ++i) {
+            if (i == NB) {
+                // every fragment of stage s is in registers; W(s + 1) - and everything older - must have landed: the only younger operations
+                // of this wave are its two pieces of A(s + 3)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP_LA) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -229,30 +279,36 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int j = t % 3, term = t / 3;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 1 ? wL[j] : wH[j], term == 0 ? al[i] : ah[i], acc[i][j], 0, 0, 0);
+                const bf16x8 av = i < 2 ? (term == 0 ? aL[i] : aH[i]) : (term == 0 ? al[i] : ah[i]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 1 ? wL[j] : wH[j], av, acc[i][j], 0, 0, 0);
                 const int idx = 9 * i + t;
-                if (idx < 36) {
-                    // row fragments 2 .. 6 of this stage: one read every third MFMA (10 reads in 30 slots)
-                    if (idx % 3 == 0 && idx / 3 < 10) {
+                if (idx < 9 * NB) {
+                    if (idx % 3 == 0 && idx / 3 < NPRE) {
                         const int k = idx / 3, fi = 2 + k / 2;
                         if (k % 2 == 0) ah[fi] = frag_a(s, fi, f_hi);
                         else al[fi] = frag_a(s, fi, f_lo);
                     }
+                } else if constexpr (SPACED) {
+                    const int u = idx - 9 * NB;                              // 0 .. 26
+                    if (u % 3 == 0 && u / 3 < RP_LW + RP_LA) dma_job(u / 3);
+                    else if (u % 3 == 1 && u / 3 < 6) w_job(u / 3);
+                    else if (u % 3 == 2 && u / 3 < NAF) a_job(u / 3);
                 } else {
-                    // behind the barrier: this wave's pieces of W(s + 2) and then of A(s + 4) into the slots just freed (8, every third slot),
-                    // the W fragments and row fragments 0, 1 of stage s + 1 (10 reads)
-                    const int u = idx - 36;                                  // 0 .. 26
-                    if (u % 3 == 0 && u / 3 < RP_LW + RP_LA) {
-                        if (u / 3 < RP_LW) issue_w(wp, wk, s & 1, u / 3);
-                        else issue_a(ak, s & (RP_ASLOTS - 1), u / 3 - RP_LW);
-                    } else if (u % 3 == 1 && u / 3 < 6) {
-                        const int k = u / 3;
-                        if (k < 3) wHn[k] = frag_w(s + 1, k, f_hi);
-                        else wLn[k - 3] = frag_w(s + 1, k - 3, f_lo);
-                    } else if (u % 3 == 2 && u / 3 < 4) {
-                        const int k = u / 3;
-                        if (k < 2) ah[k] = frag_a(s + 1, k, f_hi);
-                        else al[k - 2] = frag_a(s + 1, k - 2, f_lo);
+#pragma unroll
+                    for (int q = 0; q < JPS; ++q) {
+                        const int n = (idx - 9 * NB) * JPS + q;              // job number: triples (D, W, A) while all three kinds last
+                        // order: D0 W0 A0 .. D(NAF-1) W(NAF-1) A(NAF-1) | D W pairs up to W5 | the remaining D
+                        if (n < 3 * NAF) {
+                            if (n % 3 == 0) dma_job(n / 3);
+                            else if (n % 3 == 1) w_job(n / 3);
+                            else a_job(n / 3);
+                        } else if (n < 3 * NAF + 2 * (6 - NAF)) {
+                            const int m = n - 3 * NAF;
+                            if (m % 2 == 0) dma_job(NAF + m / 2);
+                            else w_job(NAF + m / 2);
+                        } else if (n < NJ) {
+                            dma_job(6 + (n - 3 * NAF - 2 * (6 - NAF)));
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -276,9 +332,10 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     };
 
     for (int g = 0; g < G; g += 2) {
-        stage_body(g, wh[0], wl[0], wh[1], wl[1]);
+        constexpr int AN = SPACED ? 0 : 1;                             // MF >= 5: one set (the fragments are dead by the time the next are read)
+        stage_body(g, wh[0], wl[0], wh[1], wl[1], a01h[0], a01l[0], a01h[AN], a01l[AN]);
         advance_streams();
-        stage_body(g + 1, wh[1], wl[1], wh[0], wl[0]);                 // (nk is even: checked by the launcher)
+        stage_body(g + 1, wh[1], wl[1], wh[0], wl[0], a01h[AN], a01l[AN], a01h[0], a01l[0]);   // (nk is even: checked by the launcher)
         advance_streams();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -293,9 +350,9 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     float* red = (float*)(lds + RP_RING);                              // [8 waves][RP_TH]
     float* red2 = red + 8 * RP_TH;
     // per-row totals over the 384 columns of `part[i]` (this lane's partial over its 12 values): all 512 threads call it
-    auto row_total = [&](float (&part)[RP_MF], float* buf) __attribute__((always_inline)) {
+    auto row_total = [&](float (&part)[MF], float* buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
+        for (int i = 0; i < MF; ++i) {
             float v = part[i];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
@@ -303,7 +360,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
+        for (int i = 0; i < MF; ++i) {
             float t = 0.f;
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) t += buf[w8 * RP_TH + 16 * i + fre];
@@ -311,9 +368,9 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         }
     };
     // the same for two partials at once (one barrier)
-    auto row_total2 = [&](float (&pa)[RP_MF], float (&pb)[RP_MF]) __attribute__((always_inline)) {
+    auto row_total2 = [&](float (&pa)[MF], float (&pb)[MF]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
+        for (int i = 0; i < MF; ++i) {
             float a = pa[i], b = pb[i];
             a += __shfl_xor(a, 16, 64);
             b += __shfl_xor(b, 16, 64);
@@ -326,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
+        for (int i = 0; i < MF; ++i) {
             float ta = 0.f, tb = 0.f;
 #pragma unroll
             for (int w8 = 0; w8 < 8; ++w8) {
@@ -342,7 +399,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         char* ybuf = lds;
         fresh_lane();
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
+        for (int i = 0; i < MF; ++i) {
             if (i < i0 || i >= i1) continue;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -372,7 +429,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
 
     if constexpr (REPI == REPI_RES_LN) {
         const float invN = 1.0f / (float)RP_N;
-        float part[RP_MF];
+        float part[MF];
         fresh_lane();
         // v = (residual + products) + bias: the residual rows were the accumulators' initial values
         f32x4v bj[3];
@@ -382,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
             if (p.bias) bj[j] = *(const f32x4v*)(p.bias + ncol0 + 16 * j);
         }
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
+        for (int i = 0; i < MF; ++i) {
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; ++j)
@@ -394,9 +451,9 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
             part[i] = s;
         }
         row_total(part, red);
-        float mu[RP_MF];
+        float mu[MF];
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
+        for (int i = 0; i < MF; ++i) {
             mu[i] = part[i] * invN;
             float s = 0.f;
 #pragma unroll
@@ -413,7 +470,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         fresh_lane();
         float* xo = (float*)p.out0;
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
+        for (int i = 0; i < MF; ++i) {
             const unsigned m = (unsigned)row_of(i);
             const float rs = rsqrtf(part[i] * invN + p.eps);
             if (wave == 0 && fqe == 0 && p.mean) {
@@ -432,8 +489,8 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         }
         if (!p.y_f32) {
             __syncthreads();                                           // (red / red2 live outside the ring; the ring itself is free)
-            store_split(p.out1, p.ldo1, 0, 4);
-            store_split(p.out1, p.ldo1, 4, RP_MF);
+            store_split(p.out1, p.ldo1, 0, MF < 4 ? MF : 4);
+            if constexpr (MF > 4) store_split(p.out1, p.ldo1, 4, MF);
         }
     }
 
@@ -453,7 +510,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         {
             const unsigned nchunk = (unsigned)rows * 96u;
 #pragma unroll 1
-            for (int n = 0; n < RP_XDMA; ++n) {
+            for (int n = 0; n < (int)((nchunk + 511u) / 512u); ++n) {                      // (<= RP_XDMA)
                 unsigned q = (unsigned)n * 512u + (unsigned)tid;
                 q = q < nchunk ? q : nchunk - 1;
                 const unsigned r = q / 96u, c = (q % 96u) ^ (r & 15u);
@@ -468,9 +525,9 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         f32x4v gm[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) gm[j] = *(const f32x4v*)(gamp + ncol0 + 16 * j);
-        float mu[RP_MF], rsd[RP_MF];
+        float mu[MF], rsd[MF];
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
+        for (int i = 0; i < MF; ++i) {
             const unsigned m = (unsigned)row_of(i);
             mu[i] = p.mean[m];
             rsd[i] = p.rstd[m];
@@ -508,7 +565,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
                     for (int r = 0; r < 4; ++r) atomicAdd(dst + ncol0 + 16 * j + r, cv[j][r]);
             }
         };
-        float s1[RP_MF], s2[RP_MF];
+        float s1[MF], s2[MF];
         // phase 1, instantiated per residual-gradient kind (0 none, 1 f32 rows, 2 the operand-type copy hi + lo): a run-time test per
         // element turned the phase into 400 branches and 100 spilled registers
         auto phase1 = [&](auto kind) __attribute__((always_inline)) {
@@ -541,7 +598,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
                 return __uint_as_float((r & 1) ? (h & 0xffff0000u) : (h << 16)) + __uint_as_float((r & 1) ? (l & 0xffff0000u) : (l << 16));
             };
             res_load(0);
-            res_load(1);
+            if constexpr (MF > 1) res_load(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                           // every wave's x pieces have landed
             float cg[3][4], cb[3][4];
@@ -550,8 +607,8 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
 #pragma unroll
                 for (int r = 0; r < 4; ++r) cg[j][r] = cb[j][r] = 0.f;
 #pragma unroll
-            for (int i = 0; i < RP_MF; ++i) {
-                if (i + 2 < RP_MF) res_load(i + 2);
+            for (int i = 0; i < MF; ++i) {
+                if (i + 2 < MF) res_load(i + 2);
                 const bool ok = 16 * i + fre < rows;
                 float a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -591,7 +648,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) cx[j][r] = 0.f;
 #pragma unroll
-        for (int i = 0; i < RP_MF; ++i) {
+        for (int i = 0; i < MF; ++i) {
             const bool ok = 16 * i + fre < rows;
             const float k1 = rsd[i] * s1[i] * invN, k2 = rsd[i] * s2[i] * invN;
 #pragma unroll
@@ -609,8 +666,8 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         col_out(cx, 2, p.cs2);
         if (p.out1) {
             __syncthreads();                                           // x is dead: the ring turns into the staging buffer of the split rows
-            store_split(p.out1, p.ldo1, 0, 4);
-            store_split(p.out1, p.ldo1, 4, RP_MF);
+            store_split(p.out1, p.ldo1, 0, MF < 4 ? MF : 4);
+            if constexpr (MF > 4) store_split(p.out1, p.ldo1, 4, MF);
         }
     }
 }
@@ -625,22 +682,36 @@ int rp_rows_per_tile(int M, int cap = RP_TH) {
 }
 template <int MODE> constexpr int rp_cap() { return MODE == REPI_LNBWD_RES ? RP_XROWS : RP_TH; }
 
+template <int MODE, int MF> int launch_rowp_mf(const GemmP& q, int grid, int rpt, hipStream_t st) {
+    static PerDeviceOnce attr;
+    if (attr.first()) {
+        (void)hipFuncSetAttribute((const void*)gemm_rowp_kernel<MODE, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
+    }
+    MFVIT_LAUNCH((gemm_rowp_kernel<MODE, MF>), dim3(grid), dim3(512), RP_LDS, st, q, rpt, q.N / RP_N);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
 template <int MODE> int launch_rowp(const GemmP& p, hipStream_t st) {
     const int rpt = rp_rows_per_tile(p.M, rp_cap<MODE>());
     const int grid = (p.M + rpt - 1) / rpt;
-    static PerDeviceOnce attr;
-    if (attr.first()) {
-        (void)hipFuncSetAttribute((const void*)gemm_rowp_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
-    }
     ProfScope ps(MODE == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
     GemmP q = p;
     q.rows_per_wg = 0;
 #ifdef MFVIT_ABLATE
     { const char* e = getenv("MFVIT_ROWP_NOEPI"); q.rows_per_wg = (e && atoi(e)) ? 78 : 0; }
 #endif
-    MFVIT_LAUNCH((gemm_rowp_kernel<MODE>), dim3(grid), dim3(512), RP_LDS, st, q, rpt, p.N / RP_N);
-    MFVIT_CHECK_LAUNCH();
-    return MFVIT_OK;
+    static int sw_mf = INT_MIN;                                          // MFVIT_ROWP_MF=7: every tile on the 7-fragment kernel (the round-3 behaviour)
+    const int mf = env_switch("MFVIT_ROWP_MF", 0, sw_mf) == 7 ? 7 : (rpt + 15) / 16;
+    switch (mf) {
+    case 1: return launch_rowp_mf<MODE, 1>(q, grid, rpt, st);
+    case 2: return launch_rowp_mf<MODE, 2>(q, grid, rpt, st);
+    case 3: return launch_rowp_mf<MODE, 3>(q, grid, rpt, st);
+    case 4: return launch_rowp_mf<MODE, 4>(q, grid, rpt, st);
+    case 5: return launch_rowp_mf<MODE, 5>(q, grid, rpt, st);
+    case 6: return launch_rowp_mf<MODE, 6>(q, grid, rpt, st);
+    default: return launch_rowp_mf<MODE, 7>(q, grid, rpt, st);
+    }
 }
 
 // MFVIT_ROWP: 0 off, 1 the forward epilogue only (+ bias + residual -> LayerNorm), 2 (default) the LayerNorm-backward epilogue as well.  Read
@@ -658,7 +729,10 @@ bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
     if (dtype != MFVIT_BF16X3 || rowp_mode() == 0) return false;
     if (repi != REPI_RES_LN && repi != REPI_LNBWD_RES) return false;
     if (repi == REPI_LNBWD_RES && rowp_mode() < 2) return false;
-    if (p.N != RP_N || p.K % 64 || p.K < 128 || p.M < 4096 || p.nb > 1) return false;   // (an even number of stages, at least 4)
+    static int sw_minm = INT_MIN;                                        // smallest M that takes this kernel (A/B: MFVIT_ROWP_MINM >= 0)
+    const int minm_env = env_switch("MFVIT_ROWP_MINM", -1, sw_minm);
+    const int minm = minm_env >= 0 ? minm_env : (repi == REPI_RES_LN ? RP_MINM_FWD : RP_MINM_BWD);
+    if (p.N != RP_N || p.K % 64 || p.K < 128 || p.M < minm || p.nb > 1) return false;   // (an even number of stages, at least 4)
     if (p.orow_in || p.res_mod || p.rows_per_wg) return false;                  // patch-embedding row remap stays with gemm_nt_row
     if (repi == REPI_LNBWD_RES) {
         if (!p.aux || !p.mean || !p.rstd || !p.gamma || p.ldaux % 4 || (size_t)p.aux % 16 || (size_t)p.gamma % 16) return false;

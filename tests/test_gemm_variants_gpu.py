@@ -17,6 +17,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 D, F = 384, 1536
 SHAPES = [(128 * 197, "full"), (128 * 197 - 57, "ragged"), (4096 + 40, "small")]
+# the tall-tile kernel is instantiated per number of 16-row fragments a tile carries (1 .. 7): one M for each, and tiles of a single row
+ROW_SHAPES = SHAPES + [(16 * 197, "B16: 1 fragment"), (32 * 197 - 3, "B32: 2"), (48 * 197, "B48: 3"), (64 * 197, "B64: 4"), (96 * 197, "B96: 5"),
+                       (112 * 197, "B112: 6"), (197, "one row per tile")]
 
 
 def sp(x):
@@ -37,12 +40,13 @@ def rn(g, *shape, sc=1.0):
     return torch.randn(*shape, device=DEV, generator=g) * sc
 
 
-@pytest.mark.parametrize("M,tag", SHAPES)
+@pytest.mark.parametrize("M,tag", ROW_SHAPES)
 @pytest.mark.parametrize("K", [D, F])
 @pytest.mark.parametrize("mode", ["0", "2"])
 def test_row_kernel_forward_residual_layernorm(monkeypatch, M, tag, K, mode):
     """x = a @ w.T + bias + res ; y = LayerNorm(x)  (proj / fc2 of timm's Block + the following norm): both row kernels, split and f32 y."""
     monkeypatch.setenv("MFVIT_ROWP", mode)
+    monkeypatch.setenv("MFVIT_ROWP_MINM", "1")                              # mode 2: the tall-tile kernel at every M, whatever the default gate
     g = _gen(11 + K)
     a, w = sp(rn(g, M, K)), sp(rn(g, D, K, sc=.05))
     b, res = rn(g, D), rn(g, M, D)
@@ -58,12 +62,13 @@ def test_row_kernel_forward_residual_layernorm(monkeypatch, M, tag, K, mode):
         assert max(errs.values()) < 3e-5, (tag, K, mode, y_f32, errs)
 
 
-@pytest.mark.parametrize("M,tag", SHAPES)
+@pytest.mark.parametrize("M,tag", ROW_SHAPES)
 @pytest.mark.parametrize("K", [3 * D, F])
 @pytest.mark.parametrize("mode", ["0", "2"])
 def test_row_kernel_dgrad_layernorm_backward(monkeypatch, M, tag, K, mode):
     """dx = LayerNorm-backward(dy @ wt.T; x) + dres, dgamma, dbeta, column sums of dx  (qkv / fc1 data gradients + norm1 / norm2 backward)."""
     monkeypatch.setenv("MFVIT_ROWP", mode)
+    monkeypatch.setenv("MFVIT_ROWP_MINM", "1")                              # mode 2: the tall-tile kernel at every M, whatever the default gate
     g = _gen(23 + K)
     dy, wt = sp(rn(g, M, K, sc=.1)), sp(rn(g, D, K, sc=.05))
     x = rn(g, M, D, sc=1.5) + .3
