@@ -1385,6 +1385,490 @@ __global__ __launch_bounds__(512) void attn_bwd_pp_kernel(const typename Vec4<T>
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward, SINGLE PASS (round 4): S, P, dP and dS of a (query tile, key tile) pair are computed ONCE.
+//
+// Both kernels above run two phases per (image, head): wave = query tile (dQ needs S^T, dS^T: keys in the accumulator ROWS, the contraction
+// index of the MFMA) and wave = key tile (dK, dV need S, dS: queries in the rows).  Every score tile is therefore computed twice - 42 MFMAs and
+// ~380 VALU instructions per tile pair where 30 and ~200 would do, in a kernel whose time is the SUM of its VALU and MFMA time.  Here:
+//   * waves 0 .. 6 own a KEY tile each (K, V fragments of the tile stay in registers for the whole pair) and walk through the query tiles
+//     TOGETHER, one step per query tile: S[q][key], dP, P, dS, then dV += dO^T P and dK += Q^T dS as in phase B above;
+//   * the hi / lo fragments of dS they have packed for the dK product are ALSO written - the same 16 bytes, split in two 8-byte halves -
+//     into a 4 KB tile of LDS laid out [key][query] in the swizzled image format: read back with ds_read_b64_tr_b16 they are dS^T fragments
+//     with the keys in the contraction index;
+//   * wave 7 (the helper) turns them into dQ: one step behind the others it reads the seven tiles of the step (two buffers, one barrier per
+//     step) and accumulates dQ^T[d][q] = sum over key tiles K_j^T dS_j^T in ONE accumulator - the K^T fragments of all seven key tiles live in
+//     its registers (112 of them) - and stores the finished dQ tile.  No atomics, no second pass.
+//   * the helper is also the producer: K / V images are dead once the fragments are in registers (barrier Z), so the next pair's K / V
+//     stream in during the steps; query tile t of Q / dO is dead behind the barrier of step t - the next pair's rows go straight over it
+//     (one copy of every image: 4 x 25.6 KB + 2 x 28 KB of dS^T tiles + row constants = 161.5 KB).
+//   * row constants (-lse/scale, -D = -rowsum(dO o O)): wave w computes those of query tile w between the two barriers at the head of a
+//     pair, from the dO image and O rows it requested from global memory a pair earlier (17 registers).
+// Padded keys: the last key tile's K / V fragments (and the helper's K^T elements) are zeroed past Tn in registers; padded queries carry
+// -lse/scale = -1e30 (p = 0); tile reads past an image's rows see finite 16-bit data of the next region.
+template <typename T> struct SpGeo {
+    static constexpr bool SP = is_split<T>::value;
+    static constexpr int RB = AttnT<T>::RB, CPR = RB / 16, RPP = 64 / CPR, NCW = 7;
+    static constexpr int SCR = 32 * RB;                                // one wave's dS^T tile: 32 key rows
+    static __host__ __device__ int timg(int Tn) { return (Tn + RPP - 1) / RPP * RPP; }
+    static __host__ __device__ int tpad(int Tn) { return (Tn + 31) & ~31; }
+    static __host__ __device__ int img(int Tn) { return timg(Tn) * RB; }
+    // [dO][Q][V][K][dS^T tiles x 2][row constants]: a tile read past an image's rows lands in the next image / in dS^T values (finite 16-bit data)
+    static __host__ __device__ int off_do(int) { return 0; }
+    static __host__ __device__ int off_q(int Tn) { return img(Tn); }
+    static __host__ __device__ int off_v(int Tn) { return 2 * img(Tn); }
+    static __host__ __device__ int off_k(int Tn) { return 3 * img(Tn); }
+    static __host__ __device__ int off_scr(int Tn, int b) { return 4 * img(Tn) + b * NCW * SCR; }
+    static __host__ __device__ int off_ld(int Tn) { return 4 * img(Tn) + 2 * NCW * SCR; }              // -lse/scale rows, then -D rows
+    static __host__ __device__ int lds_bytes(int Tn) { return off_ld(Tn) + 2 * tpad(Tn) * 4; }
+    static __device__ __forceinline__ int swz(int row) { return SP ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3); }
+};
+
+// NT: row tiles of a pair (= computing waves): 7 (T = 193 .. 224); other lengths stay with the two-phase kernels
+template <typename T, int NT>
+__global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename Vec4<T>::elem* __restrict__ out,
+                                                          const typename Vec4<T>::elem* __restrict__ dout, const float* __restrict__ lse,
+                                                          typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale, int npair) {
+    typedef AttnT<T> A;
+    typedef SpGeo<T> G;
+    typedef typename A::E E;
+    typedef typename A::frag_t frag_t;
+    constexpr int EP = A::EP, RB = G::RB, CPR = G::CPR, RPP = G::RPP, LO = A::SP ? 1 : 0, NCW = G::NCW, SCR = G::SCR;
+    constexpr int NM = A::SP ? 6 : 2;                                  // MFMAs of one 32 x 32 x 32 product
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int nt = NT;                                             // (checked by the launcher: (Tn + 31) / 32 == NT <= NCW)
+    const int Timg = G::timg(Tn), Tpad = G::tpad(Tn), np = Timg / RPP;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hh = lane >> 5, kr = lane & 31;
+    const long hs = (long)H * HD * EP, rs = 3 * hs, os = hs;
+    const int npl = (npair - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    for (int i = threadIdx.x * 16; i < G::lds_bytes(Tn); i += 512 * 16) *(uint4*)(lds + i) = make_uint4(0, 0, 0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ATTN_SB();
+    auto pair_bid = [&](int k) __attribute__((always_inline)) { return xcd_remap((int)blockIdx.x + k * (int)gridDim.x, npair); };
+    // piece pj (RPP rows, 1 KB) of an image by LDS-DMA: scalar base of the piece + a per-lane byte offset that only depends on the parity of pj
+    // (row = pj RPP + lrow: the swizzle looks at row bits 1 .. 3), lanes whose row is past Tn masked INSIDE the asm statement (no branch in the
+    // compiler's view: the steps stay one basic block)
+    int lrow = lane / CPR;
+    // (plain arithmetic on three values: a two-element array indexed by pj & 1 - and a select between two captured variables just the same -
+    // went to scratch memory, and every scratch load waits for ALL LDS-DMA in flight: the pipeline ran one piece at a time)
+    unsigned sw_x, vrs_e, vos_e;      // sw_x: what an odd piece flips in the offset (low bits: the strides are multiples of 128 B)
+    auto calc_dma = [&](int lane_) __attribute__((always_inline)) {
+        lrow = lane_ / CPR;
+        const int cpos = lane_ % CPR;
+        const unsigned sw_e = 16u * (unsigned)(cpos ^ G::swz(lrow));
+        sw_x = sw_e ^ (16u * (unsigned)(cpos ^ G::swz(RPP + lrow)));
+        vrs_e = (unsigned)lrow * (unsigned)(rs * 2) + sw_e;
+        vos_e = (unsigned)lrow * (unsigned)(os * 2) + sw_e;
+    };
+    calc_dma(lane);
+    auto voff_rs = [&](int pj) __attribute__((always_inline)) { return vrs_e ^ (sw_x & (0u - (unsigned)(pj & 1))); };
+    auto voff_os = [&](int pj) __attribute__((always_inline)) { return vos_e ^ (sw_x & (0u - (unsigned)(pj & 1))); };
+    auto dma_sv = [&](const char* piece_base_, unsigned voff, int lds_off, int pj) __attribute__((always_inline)) {
+        const unsigned long long pbv = (unsigned long long)piece_base_;    // (uniform by construction: pinned to scalar registers for the "s" operand)
+        const unsigned pb_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)pbv), pb_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(pbv >> 32));
+        const char* piece_base = (const char*)(((unsigned long long)pb_hi << 32) | pb_lo);   // (unsigned halves: the builtin returns int - OR-ing it in sign-extends)
+        unsigned long long keep_exec;
+        unsigned keep_m0;
+        asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32 vcc, %5, %6\n\ts_and_b64 exec, exec, vcc\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep_exec), "=&s"(keep_m0)
+                     : "v"(voff), "s"(piece_base), "s"(__builtin_amdgcn_readfirstlane((unsigned)lds_off + (unsigned)pj * 1024u)),
+                       "s"(__builtin_amdgcn_readfirstlane(Tn - pj * RPP)), "v"(lrow)
+                     : "memory", "vcc");
+    };
+    // entry i (0 .. 15) of step window w: i < 8: K / V piece 8 w + i (window 0: 16 of them); i >= 8: piece i - 8 of query tile w - 1 of Q (then dO).
+    // Everything is a select on scalars - indices past the end repeat the last piece (identical bytes into rows nobody reads any more).
+    constexpr int PPT = 32 / RPP;                                      // pieces per tile and image
+    auto dma_entry = [&](const E* kvsrc, const E* qsrc, const E* dosrc, int w, int i) __attribute__((always_inline)) {
+        const bool kv = i < 8 || w == 0;
+        int pi = w == 0 ? i : 16 + 8 * (w - 1) + i;                    // K / V piece (K pieces first)
+        pi = pi < 2 * np ? pi : 2 * np - 1;
+        const int second = pi >= np ? 1 : 0;
+        int e = i - 8;                                                 // Q / dO piece of tile w - 1
+        e = e < 2 * PPT ? e : 2 * PPT - 1;
+        const int isdo = e >= PPT ? 1 : 0;
+        int pq = (w - 1) * PPT + (e - isdo * PPT);
+        pq = pq < np ? pq : np - 1;
+        const int pj = kv ? pi - second * np : pq;
+        const char* src = kv ? (const char*)(kvsrc + (second ? 2 * hs : hs)) : (isdo ? (const char*)dosrc : (const char*)qsrc);
+        const long stride = (!kv && isdo) ? os : rs;
+        const int off = kv ? (second ? G::off_v(Tn) : G::off_k(Tn)) : (isdo ? G::off_do(Tn) : G::off_q(Tn));
+        const unsigned vsel = (!kv && isdo) ? 1u : 0u;
+        const unsigned vo = (vrs_e + vsel * (vos_e - vrs_e)) ^ (sw_x & (0u - (unsigned)(pj & 1)));
+        dma_sv(src + (long)pj * RPP * stride * 2, vo, off, pj);
+    };
+    const bool helper = wave == NCW;
+    char* const dOs = lds + G::off_do(Tn);
+    char* const Qs = lds + G::off_q(Tn);
+    char* const Vs = lds + G::off_v(Tn);
+    char* const Ks = lds + G::off_k(Tn);
+    float* const Ls = (float*)(lds + G::off_ld(Tn));
+    float* const Ds = Ls + Tpad;
+
+    // O rows / lse of the NEXT pair's query tile `wave` (requested a pair ahead): lane (row kr, half hh) holds the hi [and lo] chunks of d = 16 hh .. + 16
+    uint4 ofr[2][2];
+    float lsr = 0.f;
+    auto o_fetch = [&](int bid_) __attribute__((always_inline)) {
+        const int bb = bid_ / H, h_ = bid_ % H;
+        const int q = wave * 32 + kr, qc = q < Tn ? q : Tn - 1;
+        const E* op = out + ((long)bb * Tn + qc) * os + h_ * HD * EP;
+#pragma unroll
+        for (int part = 0; part <= LO; ++part)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ofr[part][i] = *(const uint4*)(op + 8 * ((A::SP ? 4 * part : 0) + 2 * hh + i));
+        lsr = lse[((long)bb * H + h_) * Tn + qc];
+    };
+    // row constants of query tile `wave` of the pair whose dO image has landed
+    auto consts = [&]() __attribute__((always_inline)) {
+        const int q = wave * 32 + kr, qc = q < Tn ? q : Tn - 1;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            union { uint4 u; frag_t f; } o0, o1, d0, d1;
+            o0.u = ofr[0][i];
+            d0.u = *(const uint4*)(dOs + qc * RB + 16 * ((2 * hh + i) ^ G::swz(qc)));
+            if constexpr (A::SP) {
+                o1.u = ofr[1][i];
+                d1.u = *(const uint4*)(dOs + qc * RB + 16 * ((4 + 2 * hh + i) ^ G::swz(qc)));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float ov = (float)o0.f[j], dv_ = (float)d0.f[j];
+                if constexpr (A::SP) { ov += (float)o1.f[j]; dv_ += (float)d1.f[j]; }
+                acc = fmaf(ov, dv_, acc);
+            }
+        }
+        acc += xhalf(acc);
+        if (hh == 0) {
+            Ls[q] = q < Tn ? -lsr / scale : -1e30f;                    // padded queries: p = exp2(-1e30 c) = 0
+            Ds[q] = q < Tn ? -acc : 0.f;
+        }
+    };
+
+    // per-lane offsets inside an image: row fragments [part][k-step], transposed reads [part][first / second 4-row block], dS^T writes [part][g].
+    // The key waves derive them AFRESH behind barrier Z of every pair, from a laundered lane id: carried across the head of the pair (the row
+    // constants' arithmetic) they were spilled, the reloads sat in front of the step loop, and their wait - vmcnt(0) at the top of every
+    // iteration - also waited for every LDS-DMA of the step before.
+    int roff[2][2], toff[2][2], woff[2][4];
+    auto calc_offsets = [&](int lane_) __attribute__((always_inline)) {
+        const int hh_ = lane_ >> 5, kr_ = lane_ & 31;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) roff[part][s] = kr_ * RB + 16 * (((A::SP ? 4 * part : 0) + 2 * s + hh_) ^ G::swz(kr_));
+        const int g1 = (lane_ >> 4) & 1, q4 = (lane_ & 15) >> 2, p4 = lane_ & 3;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int row = 4 * hh_ + q4 + 8 * rd;                 // (the swizzle of row tile * 32 + 16 s + row depends on these bits only)
+                const int cch = (A::SP ? 4 * part : 0) + 2 * g1 + (p4 >> 1);
+                toff[part][rd] = row * RB + 16 * (cch ^ G::swz(row)) + 8 * (p4 & 1);
+            }
+        // dS^T[key kr][queries 8 g + 4 hh .. + 3]: 8 bytes at byte 16 g + 8 hh of the row's hi (lo) part
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) woff[part][g] = kr_ * RB + 16 * (((A::SP ? 4 * part : 0) + g) ^ G::swz(kr_)) + 8 * hh_;
+    };
+    calc_offsets(lane);
+    const float c = scale * 1.4426950408889634f;
+    auto rd_row = [&](frag_t (&f)[2][2], const char* image, int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int part = 0; part <= LO; ++part) f[part][s] = *(const frag_t*)(image + tile * 32 * RB + roff[part][s]);
+    };
+    auto rd_tr = [&](frag_t (&f)[2], const char* image, int tile, int s) __attribute__((always_inline)) {   // [part], k-step s
+#pragma unroll
+        for (int part = 0; part <= LO; ++part) {
+            union { struct { s16x4 a, b; } s2; frag_t v; } u;
+            const char* p0 = image + (tile * 32 + 16 * s) * RB;
+            u.s2.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + toff[part][0]));
+            u.s2.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + toff[part][1]));
+            f[part] = u.v;
+        }
+    };
+    auto mm = [&](int i, const frag_t (&a)[2][2], const frag_t (&bh)[2], const frag_t (&bl)[2], f32x16& acc, const f32x16& init) __attribute__((always_inline)) {
+        if constexpr (A::SP) {
+            const int s = i / 3, term = i % 3;
+            acc = MmaTraits_mma(term == 0 ? a[1][s] : a[0][s], term == 1 ? bl[s] : bh[s], i == 0 ? init : acc);
+        } else {
+            acc = MmaTraits_mma(a[0][i], bh[i], i == 0 ? init : acc);
+        }
+    };
+    auto mt = [&](int i, const frag_t (&a)[2], const frag_t& bh, const frag_t& bl, f32x16& acc) __attribute__((always_inline)) {
+        if constexpr (A::SP) acc = MmaTraits_mma(i == 0 ? a[1] : a[0], i == 1 ? bl : bh, acc);
+        else acc = MmaTraits_mma(a[0], bh, acc);
+    };
+    auto zero_frag = [&](frag_t& f) __attribute__((always_inline)) {
+        union { uint4 u; frag_t v; } z;
+        z.u = make_uint4(0, 0, 0, 0);
+        f = z.v;
+    };
+
+    {   // prologue: pair 0 by everybody
+        const int bid = pair_bid(0);
+        const E* base = qkv + (long)(bid / H) * Tn * rs + (bid % H) * HD * EP;
+        const E* dob = dout + (long)(bid / H) * Tn * os + (bid % H) * HD * EP;
+        for (int pj = wave; pj < np; pj += 8) {
+            dma_sv((const char*)(base + hs) + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_k(Tn), pj);
+            dma_sv((const char*)(base + 2 * hs) + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_v(Tn), pj);
+            dma_sv((const char*)base + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_q(Tn), pj);
+            dma_sv((const char*)dob + (long)pj * RPP * os * 2, voff_os(pj), G::off_do(Tn), pj);
+        }
+        if (!helper) o_fetch(bid);
+        wait_vm<0>();
+    }
+
+    int rnd_no = -1;
+    (void)rnd_no;
+    // The three roles run SEPARATE persistent loops (same barrier sequence: X, Z and one per step): values of one role are not live in another's
+    // code (in one loop with role branches the helper's 112 K^T registers and the key waves' state were spilled around each other, and a scratch
+    // reload waits for every LDS-DMA in flight).
+    if (helper) {
+        for (int kp = 0; kp < npl; ++kp) {
+            const int bid = pair_bid(kp);
+            const int b = bid / H, h = bid % H;
+            E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
+            const bool more = kp + 1 < npl;
+            const int bidn = pair_bid(more ? kp + 1 : kp);
+            const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
+            const E* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ++rnd_no;
+            ATTN_STAMP(10);
+            __builtin_amdgcn_s_barrier();                                  // X: this pair's images are in place, the dS^T tiles are free
+            ATTN_SB();
+            ATTN_STAMP(0);
+        // ------------------------------------------------------------------------------------------- the helper: producer + dQ
+            frag_t ktr[NCW][2][2];                                     // K^T fragments [key tile][k-step][part]
+#pragma unroll
+            for (int j = 0; j < nt; ++j) {
+                rd_tr(ktr[j][0], Ks, j, 0);
+                rd_tr(ktr[j][1], Ks, j, 1);
+            }
+            // keys past Tn (last tile): zero (element e of k-step s = key row 16 s + 8 (e >> 2) + 4 hh + (e & 3))
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int part = 0; part <= LO; ++part)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if ((nt - 1) * 32 + 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3) >= Tn) ktr[nt - 1][s][part][e] = (E)0.0f;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                              // Z: K / V are dead
+            ATTN_SB();
+            ATTN_STAMP(1);
+            // the next pair's pieces: every wave issues entries `wave` and `wave + 8` of a step's window right behind the barrier that opens it
+            dma_entry(basen, basen, dobn, 0, NCW);
+            dma_entry(basen, basen, dobn, 0, NCW + 8);
+#pragma unroll 1
+            for (int u = 0; u < nt; ++u) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ATTN_STAMP(12 + u);
+                __builtin_amdgcn_s_barrier();                          // step u's dS^T tiles are complete; query tile u of Q / dO is dead
+                ATTN_SB();
+                ATTN_STAMP(2 + u);
+                if (u + 1 < nt) {
+                    dma_entry(basen, basen, dobn, u + 1, NCW);
+                    dma_entry(basen, basen, dobn, u + 1, NCW + 8);
+                } else {                                               // behind the last step: the last query tile's pieces (nobody else is left to issue them)
+                    for (int pj = (nt - 1) * PPT; pj < np; ++pj) {
+                        dma_sv((const char*)basen + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_q(Tn), pj);
+                        dma_sv((const char*)dobn + (long)pj * RPP * os * 2, voff_os(pj), G::off_do(Tn), pj);
+                    }
+                }
+                const char* sc = lds + G::off_scr(Tn, u & 1);
+                f32x16 dq;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+                frag_t bfr[2][2];                                      // dS^T fragments [k-step][part] of the key tile in hand
+#pragma unroll
+                for (int j = 0; j < nt; ++j) {
+                    rd_tr(bfr[0], sc + j * SCR, 0, 0);
+                    rd_tr(bfr[1], sc + j * SCR, 0, 1);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int i = 0; i < NM / 2; ++i) mt(i, ktr[j][s], bfr[s][0], bfr[s][LO], dq);
+                }
+                const int q = u * 32 + kr;
+                if (q < Tn) store_tile_T16<T>(dbase + (long)q * rs, dq, scale, lane);
+            }
+            wait_vm<0>();                                              // this wave's pieces of the next pair have landed (and its dQ stores have left)
+        }
+        return;
+    }
+    for (int kp = 0; kp < npl; ++kp) {
+        const int bid = pair_bid(kp);
+        const int b = bid / H, h = bid % H;
+        E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
+        const bool more = kp + 1 < npl;
+        const int bidn = pair_bid(more ? kp + 1 : kp);
+        const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
+        const E* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ++rnd_no;
+        ATTN_STAMP(10);
+        __builtin_amdgcn_s_barrier();                                  // X: this pair's images are in place, the dS^T tiles are free
+        ATTN_SB();
+        ATTN_STAMP(0);
+        // ----------------------------------------------------------------------------------------------- key tile `wave`
+        frag_t kfB[2][2], vfB[2][2];
+        rd_row(kfB, Ks, wave);
+        rd_row(vfB, Vs, wave);
+        if (wave * 32 + kr >= Tn) {                                    // padded keys: zero K / V (the fragment's column is this lane's key)
+#pragma unroll
+            for (int part = 0; part <= LO; ++part)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) { zero_frag(kfB[part][s]); zero_frag(vfB[part][s]); }
+        }
+        consts();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                  // Z: the row constants are in place
+        ATTN_SB();
+        ATTN_STAMP(1);
+        int lane_l = lane;                                             // (every lane-derived value of the steps comes from this laundered copy)
+        asm volatile("" : "+v"(lane_l));
+        calc_offsets(lane_l);
+        calc_dma(lane_l);
+        const int hh_c = lane_l >> 5;
+        if (wave >= 4) __builtin_amdgcn_s_sleep(1);                    // (two waves of a SIMD in lockstep behind a barrier cost up to 2 x: see attn_bwd_pp_kernel)
+        f32x16 dk, dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
+        frag_t qfr[2][2], dofr[2][2], dotr[2], qtr[2];
+        f32x16 smA, dpA, smB, dpB;
+        auto ld_consts = [&](f32x16& sm, f32x16& dp, int qt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int q0 = qt * 32 + 8 * g + 4 * hh_c;
+                const float4 L4 = *(const float4*)(Ls + q0);
+                const float4 D4 = *(const float4*)(Ds + q0);
+                sm[4 * g] = L4.x, sm[4 * g + 1] = L4.y, sm[4 * g + 2] = L4.z, sm[4 * g + 3] = L4.w;
+                dp[4 * g] = D4.x, dp[4 * g + 1] = D4.y, dp[4 * g + 2] = D4.z, dp[4 * g + 3] = D4.w;
+            }
+        };
+        rd_row(qfr, Qs, 0);
+        rd_row(dofr, dOs, 0);
+        ld_consts(smA, dpA, 0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) { mm(i, qfr, kfB[0], kfB[LO], smA, smA); mm(i, dofr, vfB[0], vfB[LO], dpA, dpA); }
+        ATTN_SB();
+        rd_row(qfr, Qs, 1);
+        rd_row(dofr, dOs, 1);
+        ATTN_SB();
+        char* const scw = lds + G::off_scr(Tn, 0) + wave * SCR;
+        auto step = [&](f32x16& sm, f32x16& dp, f32x16& nsm, f32x16& ndp, int qt) __attribute__((always_inline)) {
+            frag_t ph, pl, sh, sl;                                      // ONE set of packed P / dS fragments, reused by the two k-steps
+            char* const sw = scw + (qt & 1) * (NCW * SCR);
+            const int qn = qt + 1 < nt ? qt + 1 : nt - 1, qn2 = qt + 2 < nt ? qt + 2 : nt - 1;
+            ld_consts(nsm, ndp, qn);
+            rd_tr(dotr, dOs, qt, 0);
+            rd_tr(qtr, Qs, qt, 0);
+            ATTN_SB();
+            auto ev = [&](int r0, int r1) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = r0; r < r1; ++r) {
+                    sm[r] = __builtin_amdgcn_exp2f(sm[r] * c);
+                    dp[r] *= sm[r];
+                }
+            };
+            auto pkP = [&](int s) __attribute__((always_inline)) {
+                pack8<T>(sm, s, ph, pl);
+                if constexpr (!A::SP) pl = ph;
+            };
+            auto pkS = [&](int s) __attribute__((always_inline)) {      // dS fragments of k-step s; the same bytes go to the dS^T tile
+                pack8<T>(dp, s, sh, sl);
+                union { frag_t f; uint2 u[2]; } a;
+                a.f = sh;
+                *(uint2*)(sw + woff[0][2 * s]) = a.u[0];
+                *(uint2*)(sw + woff[0][2 * s + 1]) = a.u[1];
+                if constexpr (A::SP) {
+                    a.f = sl;
+                    *(uint2*)(sw + woff[1][2 * s]) = a.u[0];
+                    *(uint2*)(sw + woff[1][2 * s + 1]) = a.u[1];
+                } else {
+                    sl = sh;
+                }
+            };
+            if constexpr (A::SP) {
+                ev(0, 4); ATTN_SB();
+                mm(0, qfr, kfB[0], kfB[1], nsm, nsm); ev(4, 8); ATTN_SB();
+                mm(0, dofr, vfB[0], vfB[1], ndp, ndp); pkP(0); ATTN_SB();
+                mm(1, qfr, kfB[0], kfB[1], nsm, nsm); pkS(0); ATTN_SB();
+                mm(1, dofr, vfB[0], vfB[1], ndp, ndp); ev(8, 11); ATTN_SB();
+                mm(2, qfr, kfB[0], kfB[1], nsm, nsm); ev(11, 14); ATTN_SB();
+                mm(2, dofr, vfB[0], vfB[1], ndp, ndp); ev(14, 16); ATTN_SB();
+                mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
+                mt(1, dotr, ph, pl, dv); mt(1, qtr, sh, sl, dk); ATTN_SB();
+                mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB();
+                rd_tr(dotr, dOs, qt, 1);
+                rd_tr(qtr, Qs, qt, 1);
+                ATTN_SB();
+                mm(3, qfr, kfB[0], kfB[1], nsm, nsm); mm(3, dofr, vfB[0], vfB[1], ndp, ndp); pkP(1); ATTN_SB();
+                mm(4, qfr, kfB[0], kfB[1], nsm, nsm); mm(4, dofr, vfB[0], vfB[1], ndp, ndp); pkS(1); ATTN_SB();
+                mm(5, qfr, kfB[0], kfB[1], nsm, nsm); mm(5, dofr, vfB[0], vfB[1], ndp, ndp); ATTN_SB();
+                rd_row(qfr, Qs, qn2);
+                rd_row(dofr, dOs, qn2);
+                ATTN_SB();
+                mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
+                mt(1, dotr, ph, pl, dv); mt(1, qtr, sh, sl, dk); ATTN_SB();
+                mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB();
+            } else {
+                ev(0, 8); ATTN_SB();
+                mm(0, qfr, kfB[0], kfB[0], nsm, nsm); pkP(0); pkS(0); ATTN_SB();
+                mm(0, dofr, vfB[0], vfB[0], ndp, ndp); ev(8, 16); ATTN_SB();
+                mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
+                rd_tr(dotr, dOs, qt, 1);
+                rd_tr(qtr, Qs, qt, 1);
+                ATTN_SB();
+                mm(1, qfr, kfB[0], kfB[0], nsm, nsm); mm(1, dofr, vfB[0], vfB[0], ndp, ndp); pkP(1); pkS(1); ATTN_SB();
+                rd_row(qfr, Qs, qn2);
+                rd_row(dofr, dOs, qn2);
+                ATTN_SB();
+                mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the dS^T tile is written, every read of query tile qt has returned
+            ATTN_STAMP(12 + qt);
+            __builtin_amdgcn_s_barrier();
+            ATTN_SB();
+            ATTN_STAMP(2 + qt);
+            if (qt + 1 < nt) {                                          // the window this barrier opened (the last one is the helper's)
+                dma_entry(basen, basen, dobn, qt + 1, wave);
+                dma_entry(basen, basen, dobn, qt + 1, wave + 8);
+            }
+        };
+        static_assert(NT % 2 == 1, "the last step is peeled off the two-step loop");
+        // Nothing of the compiler's own may be in flight when the loop starts: a spill reload placed in front of the loop gets its wait - vmcnt(0),
+        // which also covers every LDS-DMA - at the value's first use INSIDE the loop, i.e. in every iteration.  So: a compiler-visible wait
+        // here (only scratch reloads can be pending), and window 0 of the next pair's pieces goes out behind it.
+        __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+        dma_entry(basen, basen, dobn, 0, wave);
+        dma_entry(basen, basen, dobn, 0, wave + 8);
+#pragma unroll 1
+        for (int qt = 0; qt + 1 < nt; qt += 2) {
+            step(smA, dpA, smB, dpB, qt);
+            step(smB, dpB, smA, dpA, qt + 1);
+        }
+        // the next pair's O rows / lse are requested HERE, in front of the last step: 17 registers that are not live in the loop (requested
+        // behind barrier Z they were, the loop spilled, and the reloads' waits - vmcnt(0) at the top of every iteration - also waited for
+        // every LDS-DMA of the step before)
+        if (more) o_fetch(bidn);
+        step(smA, dpA, smB, dpB, nt - 1);
+        wait_vm<0>();                                                  // this wave's pieces (the last ones a step old) and the O rows have landed
+        const int k = wave * 32 + kr;
+        if (k < Tn) {
+            store_tile_T16<T>(dbase + (long)k * rs + hs, dk, scale, lane);
+            store_tile_T16<T>(dbase + (long)k * rs + 2 * hs, dv, 1.0f, lane);
+        }
+        ATTN_STAMP(11);
+    }
+}
+
 // column sums of a [M][N] matrix of T (N logical columns, N % 8 == 0) into f32 out[N] (atomicAdd).  Used for d qkv.bias.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_t_kernel(const typename Vec4<T>::elem* __restrict__ x, long ld, float* __restrict__ out, int M, int N) {
@@ -1450,6 +1934,28 @@ template <typename T> int launch_bwd_t(const void* qkv, const void* out, const v
     if (attr.first()) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    {   // single-pass kernel (split bf16 by default; MFVIT_ATTN_BWD_SP=0 off, 2 = the plain 16-bit types too)
+        static int sws = INT_MIN;
+        const int cus3 = attn_cus();
+        const int nt = (Tn + 31) >> 5;
+        const int b3 = SpGeo<T>::lds_bytes(Tn);
+        const int want = env_switch("MFVIT_ATTN_BWD_SP", 0, sws);
+        if ((want == 2 || (want == 1 && is_split<T>::value)) && B * H >= 2 * cus3 && nt == 7 && b3 <= 160 * 1024) {
+            (void)hipFuncSetAttribute((const void*)attn_bwd_sp_kernel<T, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            {
+                ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
+                MFVIT_LAUNCH((attn_bwd_sp_kernel<T, 7>), dim3(cus3), dim3(512), b3, st, (const E*)qkv, (const E*)out, (const E*)dout, lse, (E*)dqkv, Tn, H,
+                             1.0f / sqrtf((float)HD), B * H);
+                MFVIT_CHECK_LAUNCH();
+            }
+            if (dbias) {
+                const int M = B * Tn, N = 3 * H * HD;
+                MFVIT_LAUNCH((colsum_t_kernel<T>), dim3((M + 63) / 64), dim3(256), 0, st, (const E*)dqkv, (long)N * AttnT<T>::EP, dbias, M, N);
+                MFVIT_CHECK_LAUNCH();
+            }
+            return MFVIT_OK;
+        }
     }
     {   // producer-wave kernel without register prefetch: enough pairs to fill every CU twice, 4 - 7 tiles per pair
         static int sw = INT_MIN;
