@@ -1507,18 +1507,27 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
     float* const Ls = (float*)(lds + G::off_ld(Tn));
     float* const Ds = Ls + Tpad;
 
-    // O rows / lse of the NEXT pair's query tile `wave` (requested a pair ahead): lane (row kr, half hh) holds the hi [and lo] chunks of d = 16 hh .. + 16
-    uint4 ofr[2][2];
-    float lsr = 0.f;
-    auto o_fetch = [&](int bid_) __attribute__((always_inline)) {
-        const int bb = bid_ / H, h_ = bid_ % H;
-        const int q = wave * 32 + kr, qc = q < Tn ? q : Tn - 1;
-        const E* op = out + ((long)bb * Tn + qc) * os + h_ * HD * EP;
+    // The O rows of a pair (needed once, for D = rowsum(dO o O)) come in by LDS-DMA like the other images - into the SECOND dS^T buffer, which is
+    // idle between the last step barrier of one pair and step 1 of the next (key waves 0 - 2 request them behind that barrier; the helper reads
+    // buffer 0 then).  In registers (16 per lane, requested a step or a tail ahead) the waves that issue the LDS-DMA windows spilled them the
+    // moment they were loaded - load, wait, spill, four HBM latencies per pair - whatever the placement.
+    char* const Os = lds + G::off_scr(Tn, 1);
+    // -lse / scale rows of a pair: by the helper (four rows per lane), behind the last step barrier of the pair before (nobody reads the rows any more)
+    float lsv[4];
+    auto lse_fetch = [&](int bid_) __attribute__((always_inline)) {
+        const float* lp = lse + ((long)(bid_ / H) * H + bid_ % H) * Tn;
 #pragma unroll
-        for (int part = 0; part <= LO; ++part)
+        for (int i = 0; i < 4; ++i) {
+            const int r = lane + 64 * i;
+            lsv[i] = lp[r < Tn ? r : Tn - 1];
+        }
+    };
+    auto lse_write = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) ofr[part][i] = *(const uint4*)(op + 8 * ((A::SP ? 4 * part : 0) + 2 * hh + i));
-        lsr = lse[((long)bb * H + h_) * Tn + qc];
+        for (int i = 0; i < 4; ++i) {
+            const int r = lane + 64 * i;
+            if (r < Tpad) Ls[r] = r < Tn ? -lsv[i] / scale : -1e30f;   // padded queries: p = exp2(-1e30 c) = 0
+        }
     };
     // row constants of query tile `wave` of the pair whose dO image has landed
     auto consts = [&]() __attribute__((always_inline)) {
@@ -1527,10 +1536,10 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             union { uint4 u; frag_t f; } o0, o1, d0, d1;
-            o0.u = ofr[0][i];
+            o0.u = *(const uint4*)(Os + qc * RB + 16 * ((2 * hh + i) ^ G::swz(qc)));
             d0.u = *(const uint4*)(dOs + qc * RB + 16 * ((2 * hh + i) ^ G::swz(qc)));
             if constexpr (A::SP) {
-                o1.u = ofr[1][i];
+                o1.u = *(const uint4*)(Os + qc * RB + 16 * ((4 + 2 * hh + i) ^ G::swz(qc)));
                 d1.u = *(const uint4*)(dOs + qc * RB + 16 * ((4 + 2 * hh + i) ^ G::swz(qc)));
             }
 #pragma unroll
@@ -1541,10 +1550,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             }
         }
         acc += xhalf(acc);
-        if (hh == 0) {
-            Ls[q] = q < Tn ? -lsr / scale : -1e30f;                    // padded queries: p = exp2(-1e30 c) = 0
-            Ds[q] = q < Tn ? -acc : 0.f;
-        }
+        if (hh == 0) Ds[q] = q < Tn ? -acc : 0.f;
     };
 
     // per-lane offsets inside an image: row fragments [part][k-step], transposed reads [part][first / second 4-row block], dS^T writes [part][g].
@@ -1618,9 +1624,11 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             dma_sv((const char*)(base + 2 * hs) + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_v(Tn), pj);
             dma_sv((const char*)base + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_q(Tn), pj);
             dma_sv((const char*)dob + (long)pj * RPP * os * 2, voff_os(pj), G::off_do(Tn), pj);
+            dma_sv((const char*)(out + (long)(bid / H) * Tn * os + (bid % H) * HD * EP) + (long)pj * RPP * os * 2, voff_os(pj), G::off_scr(Tn, 1), pj);
         }
-        if (!helper) o_fetch(bid);
+        if (helper) lse_fetch(bid);
         wait_vm<0>();
+        if (helper) lse_write();
     }
 
     int rnd_no = -1;
@@ -1662,9 +1670,11 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             __builtin_amdgcn_s_barrier();                              // Z: K / V are dead
             ATTN_SB();
             ATTN_STAMP(1);
-            // the next pair's pieces: every wave issues entries `wave` and `wave + 8` of a step's window right behind the barrier that opens it
-            dma_entry(basen, basen, dobn, 0, NCW);
-            dma_entry(basen, basen, dobn, 0, NCW + 8);
+            // window 0 of the next pair's pieces (16 K / V pieces): the helper has nothing else to do until the first step's dS^T tiles exist
+            for (int i = 0; i < 16; ++i) {
+                dma_entry(basen, basen, dobn, 0, i);
+                __builtin_amdgcn_s_sleep(1);
+            }
 #pragma unroll 1
             for (int u = 0; u < nt; ++u) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1672,201 +1682,226 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
                 __builtin_amdgcn_s_barrier();                          // step u's dS^T tiles are complete; query tile u of Q / dO is dead
                 ATTN_SB();
                 ATTN_STAMP(2 + u);
-                if (u + 1 < nt) {
-                    dma_entry(basen, basen, dobn, u + 1, NCW);
-                    dma_entry(basen, basen, dobn, u + 1, NCW + 8);
-                } else {                                               // behind the last step: the last query tile's pieces (nobody else is left to issue them)
-                    for (int pj = (nt - 1) * PPT; pj < np; ++pj) {
+                if (u + 1 == nt) {                                     // behind the last step: the last query tile's pieces (nobody else is left to issue them;
+                    for (int pj = (nt - 1) * PPT; pj < np; ++pj) {     // the windows of the steps are issued by key waves 0 - 2, which have the slack)
                         dma_sv((const char*)basen + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_q(Tn), pj);
                         dma_sv((const char*)dobn + (long)pj * RPP * os * 2, voff_os(pj), G::off_do(Tn), pj);
                     }
+                    if (more) lse_fetch(bidn);                         // (under the last dQ tile's MFMAs)
                 }
                 const char* sc = lds + G::off_scr(Tn, u & 1);
-                f32x16 dq;
+                f32x16 dq, dq1;                                        // two accumulators (k-step 0 / 1): a single chain of 42 dependent MFMAs issues at ~40 cycles each
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+                for (int r = 0; r < 16; ++r) dq[r] = dq1[r] = 0.f;
                 frag_t bfr[2][2];                                      // dS^T fragments [k-step][part] of the key tile in hand
 #pragma unroll
                 for (int j = 0; j < nt; ++j) {
                     rd_tr(bfr[0], sc + j * SCR, 0, 0);
                     rd_tr(bfr[1], sc + j * SCR, 0, 1);
 #pragma unroll
-                    for (int s = 0; s < 2; ++s)
-#pragma unroll
-                        for (int i = 0; i < NM / 2; ++i) mt(i, ktr[j][s], bfr[s][0], bfr[s][LO], dq);
+                    for (int i = 0; i < NM / 2; ++i) {
+                        mt(i, ktr[j][0], bfr[0][0], bfr[0][LO], dq);
+                        mt(i, ktr[j][1], bfr[1][0], bfr[1][LO], dq1);
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dq[r] += dq1[r];
                 const int q = u * 32 + kr;
                 if (q < Tn) store_tile_T16<T>(dbase + (long)q * rs, dq, scale, lane);
             }
             wait_vm<0>();                                              // this wave's pieces of the next pair have landed (and its dQ stores have left)
+            if (more) lse_write();
         }
         return;
     }
-    for (int kp = 0; kp < npl; ++kp) {
-        const int bid = pair_bid(kp);
-        const int b = bid / H, h = bid % H;
-        E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
-        const bool more = kp + 1 < npl;
-        const int bidn = pair_bid(more ? kp + 1 : kp);
-        const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
-        const E* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ++rnd_no;
-        ATTN_STAMP(10);
-        __builtin_amdgcn_s_barrier();                                  // X: this pair's images are in place, the dS^T tiles are free
-        ATTN_SB();
-        ATTN_STAMP(0);
-        // ----------------------------------------------------------------------------------------------- key tile `wave`
+    // Key waves 0 - 2 also issue the next pair's pieces (window w: 16 entries, 6 / 5 / 5 per wave): they are the first waves of SIMDs 0 - 2 and
+    // reach the step barrier ~1,000 cycles ahead of their SIMD partners (waves 4 - 6) - an LDS-DMA stalls only the wave that issues it.
+    auto key_role = [&](auto dma_tag) __attribute__((always_inline)) {
+        constexpr bool DMA = decltype(dma_tag)::value;
+        auto window = [&](const E* kvsrc, const E* qsrc, const E* dosrc, int w) __attribute__((always_inline)) {
+            if constexpr (DMA) {
+#pragma unroll
+                for (int e3 = 0; e3 < 6; ++e3) {
+                    const int i = wave + 3 * e3;                       // (wave 0: 0 3 6 9 12 15; wave 1: 1 4 .. 13 and 13 again; wave 2: 2 5 .. 14, 14)
+                    dma_entry(kvsrc, qsrc, dosrc, w, i < 16 ? i : i - 3);
+                }
+            }
+        };
+        // head of a pair: barrier X, this wave's K / V fragments, the row constants D of query tile `wave` (O rows requested a tail ago), barrier Z
         frag_t kfB[2][2], vfB[2][2];
-        rd_row(kfB, Ks, wave);
-        rd_row(vfB, Vs, wave);
-        if (wave * 32 + kr >= Tn) {                                    // padded keys: zero K / V (the fragment's column is this lane's key)
-#pragma unroll
-            for (int part = 0; part <= LO; ++part)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) { zero_frag(kfB[part][s]); zero_frag(vfB[part][s]); }
-        }
-        consts();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                  // Z: the row constants are in place
-        ATTN_SB();
-        ATTN_STAMP(1);
-        int lane_l = lane;                                             // (every lane-derived value of the steps comes from this laundered copy)
-        asm volatile("" : "+v"(lane_l));
-        calc_offsets(lane_l);
-        calc_dma(lane_l);
-        const int hh_c = lane_l >> 5;
-        if (wave >= 4) __builtin_amdgcn_s_sleep(1);                    // (two waves of a SIMD in lockstep behind a barrier cost up to 2 x: see attn_bwd_pp_kernel)
-        f32x16 dk, dv;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
-        frag_t qfr[2][2], dofr[2][2], dotr[2], qtr[2];
-        f32x16 smA, dpA, smB, dpB;
-        auto ld_consts = [&](f32x16& sm, f32x16& dp, int qt) __attribute__((always_inline)) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int q0 = qt * 32 + 8 * g + 4 * hh_c;
-                const float4 L4 = *(const float4*)(Ls + q0);
-                const float4 D4 = *(const float4*)(Ds + q0);
-                sm[4 * g] = L4.x, sm[4 * g + 1] = L4.y, sm[4 * g + 2] = L4.z, sm[4 * g + 3] = L4.w;
-                dp[4 * g] = D4.x, dp[4 * g + 1] = D4.y, dp[4 * g + 2] = D4.z, dp[4 * g + 3] = D4.w;
-            }
-        };
-        rd_row(qfr, Qs, 0);
-        rd_row(dofr, dOs, 0);
-        ld_consts(smA, dpA, 0);
-#pragma unroll
-        for (int i = 0; i < NM; ++i) { mm(i, qfr, kfB[0], kfB[LO], smA, smA); mm(i, dofr, vfB[0], vfB[LO], dpA, dpA); }
-        ATTN_SB();
-        rd_row(qfr, Qs, 1);
-        rd_row(dofr, dOs, 1);
-        ATTN_SB();
-        char* const scw = lds + G::off_scr(Tn, 0) + wave * SCR;
-        auto step = [&](f32x16& sm, f32x16& dp, f32x16& nsm, f32x16& ndp, int qt) __attribute__((always_inline)) {
-            frag_t ph, pl, sh, sl;                                      // ONE set of packed P / dS fragments, reused by the two k-steps
-            char* const sw = scw + (qt & 1) * (NCW * SCR);
-            const int qn = qt + 1 < nt ? qt + 1 : nt - 1, qn2 = qt + 2 < nt ? qt + 2 : nt - 1;
-            ld_consts(nsm, ndp, qn);
-            rd_tr(dotr, dOs, qt, 0);
-            rd_tr(qtr, Qs, qt, 0);
+        auto head = [&]() __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ++rnd_no;
+            ATTN_STAMP(10);
+            __builtin_amdgcn_s_barrier();                                  // X: this pair's images are in place, the dS^T tiles are free
             ATTN_SB();
-            auto ev = [&](int r0, int r1) __attribute__((always_inline)) {
-#pragma unroll
-                for (int r = r0; r < r1; ++r) {
-                    sm[r] = __builtin_amdgcn_exp2f(sm[r] * c);
-                    dp[r] *= sm[r];
+            ATTN_STAMP(0);
+            // ----------------------------------------------------------------------------------------------- key tile `wave`
+            rd_row(kfB, Ks, wave);
+            rd_row(vfB, Vs, wave);
+            if (wave * 32 + kr >= Tn) {                                    // padded keys: zero K / V (the fragment's column is this lane's key)
+    #pragma unroll
+                for (int part = 0; part <= LO; ++part)
+    #pragma unroll
+                    for (int s = 0; s < 2; ++s) { zero_frag(kfB[part][s]); zero_frag(vfB[part][s]); }
+            }
+            consts();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                  // Z: the row constants are in place
+            ATTN_SB();
+            ATTN_STAMP(1);
+        };
+        head();
+        for (int kp = 0; kp < npl; ++kp) {
+            const int bid = pair_bid(kp);
+            const int b = bid / H, h = bid % H;
+            E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
+            const bool more = kp + 1 < npl;
+            const int bidn = pair_bid(more ? kp + 1 : kp);
+            const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
+            const E* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
+            int lane_l = lane;                                             // (every lane-derived value of the steps comes from this laundered copy)
+            asm volatile("" : "+v"(lane_l));
+            calc_offsets(lane_l);
+            calc_dma(lane_l);
+            const int hh_c = lane_l >> 5;
+            if (wave >= 4) __builtin_amdgcn_s_sleep(1);                    // (two waves of a SIMD in lockstep behind a barrier cost up to 2 x: see attn_bwd_pp_kernel)
+            f32x16 dk, dv;
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
+            frag_t qfr[2][2], dofr[2][2], dotr[2], qtr[2];
+            f32x16 smA, dpA, smB, dpB;
+            auto ld_consts = [&](f32x16& sm, f32x16& dp, int qt) __attribute__((always_inline)) {
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int q0 = qt * 32 + 8 * g + 4 * hh_c;
+                    const float4 L4 = *(const float4*)(Ls + q0);
+                    const float4 D4 = *(const float4*)(Ds + q0);
+                    sm[4 * g] = L4.x, sm[4 * g + 1] = L4.y, sm[4 * g + 2] = L4.z, sm[4 * g + 3] = L4.w;
+                    dp[4 * g] = D4.x, dp[4 * g + 1] = D4.y, dp[4 * g + 2] = D4.z, dp[4 * g + 3] = D4.w;
                 }
             };
-            auto pkP = [&](int s) __attribute__((always_inline)) {
-                pack8<T>(sm, s, ph, pl);
-                if constexpr (!A::SP) pl = ph;
-            };
-            auto pkS = [&](int s) __attribute__((always_inline)) {      // dS fragments of k-step s; the same bytes go to the dS^T tile
-                pack8<T>(dp, s, sh, sl);
-                union { frag_t f; uint2 u[2]; } a;
-                a.f = sh;
-                *(uint2*)(sw + woff[0][2 * s]) = a.u[0];
-                *(uint2*)(sw + woff[0][2 * s + 1]) = a.u[1];
+            rd_row(qfr, Qs, 0);
+            rd_row(dofr, dOs, 0);
+            ld_consts(smA, dpA, 0);
+    #pragma unroll
+            for (int i = 0; i < NM; ++i) { mm(i, qfr, kfB[0], kfB[LO], smA, smA); mm(i, dofr, vfB[0], vfB[LO], dpA, dpA); }
+            ATTN_SB();
+            rd_row(qfr, Qs, 1);
+            rd_row(dofr, dOs, 1);
+            ATTN_SB();
+            char* const scw = lds + G::off_scr(Tn, 0) + wave * SCR;
+            // last_tag: the peeled last step has no next tile - no score MFMAs, row constants or row fragments for one (their 64 registers are
+            // what lets the next pair's O rows sit in registers across this step without a spill)
+            auto step = [&](f32x16& sm, f32x16& dp, f32x16& nsm, f32x16& ndp, int qt, auto last_tag) __attribute__((always_inline)) {
+                constexpr bool LAST = decltype(last_tag)::value;
+                frag_t ph, pl, sh, sl;                                      // ONE set of packed P / dS fragments, reused by the two k-steps
+                char* const sw = scw + (qt & 1) * (NCW * SCR);
+                const int qn = qt + 1 < nt ? qt + 1 : nt - 1, qn2 = qt + 2 < nt ? qt + 2 : nt - 1;
+                if constexpr (!LAST) ld_consts(nsm, ndp, qn);
+                rd_tr(dotr, dOs, qt, 0);
+                rd_tr(qtr, Qs, qt, 0);
+                ATTN_SB();
+                auto ev = [&](int r0, int r1) __attribute__((always_inline)) {
+    #pragma unroll
+                    for (int r = r0; r < r1; ++r) {
+                        sm[r] = __builtin_amdgcn_exp2f(sm[r] * c);
+                        dp[r] *= sm[r];
+                    }
+                };
+                auto pkP = [&](int s) __attribute__((always_inline)) {
+                    pack8<T>(sm, s, ph, pl);
+                    if constexpr (!A::SP) pl = ph;
+                };
+                auto pkS = [&](int s) __attribute__((always_inline)) {      // dS fragments of k-step s; the same bytes go to the dS^T tile
+                    pack8<T>(dp, s, sh, sl);
+                    union { frag_t f; uint2 u[2]; } a;
+                    a.f = sh;
+                    *(uint2*)(sw + woff[0][2 * s]) = a.u[0];
+                    *(uint2*)(sw + woff[0][2 * s + 1]) = a.u[1];
+                    if constexpr (A::SP) {
+                        a.f = sl;
+                        *(uint2*)(sw + woff[1][2 * s]) = a.u[0];
+                        *(uint2*)(sw + woff[1][2 * s + 1]) = a.u[1];
+                    } else {
+                        sl = sh;
+                    }
+                };
                 if constexpr (A::SP) {
-                    a.f = sl;
-                    *(uint2*)(sw + woff[1][2 * s]) = a.u[0];
-                    *(uint2*)(sw + woff[1][2 * s + 1]) = a.u[1];
+                    ev(0, 4); ATTN_SB();
+                    if constexpr (!LAST) mm(0, qfr, kfB[0], kfB[1], nsm, nsm); ev(4, 8); ATTN_SB();
+                    if constexpr (!LAST) mm(0, dofr, vfB[0], vfB[1], ndp, ndp); pkP(0); ATTN_SB();
+                    if constexpr (!LAST) mm(1, qfr, kfB[0], kfB[1], nsm, nsm); pkS(0); ATTN_SB();
+                    if constexpr (!LAST) mm(1, dofr, vfB[0], vfB[1], ndp, ndp); ev(8, 11); ATTN_SB();
+                    if constexpr (!LAST) mm(2, qfr, kfB[0], kfB[1], nsm, nsm); ev(11, 14); ATTN_SB();
+                    if constexpr (!LAST) mm(2, dofr, vfB[0], vfB[1], ndp, ndp); ev(14, 16); ATTN_SB();
+                    mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
+                    mt(1, dotr, ph, pl, dv); mt(1, qtr, sh, sl, dk); ATTN_SB();
+                    mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB();
+                    rd_tr(dotr, dOs, qt, 1);
+                    rd_tr(qtr, Qs, qt, 1);
+                    ATTN_SB();
+                    if constexpr (!LAST) mm(3, qfr, kfB[0], kfB[1], nsm, nsm); if constexpr (!LAST) mm(3, dofr, vfB[0], vfB[1], ndp, ndp); pkP(1); ATTN_SB();
+                    if constexpr (!LAST) mm(4, qfr, kfB[0], kfB[1], nsm, nsm); if constexpr (!LAST) mm(4, dofr, vfB[0], vfB[1], ndp, ndp); pkS(1); ATTN_SB();
+                    if constexpr (!LAST) mm(5, qfr, kfB[0], kfB[1], nsm, nsm); if constexpr (!LAST) mm(5, dofr, vfB[0], vfB[1], ndp, ndp); ATTN_SB();
+                    if constexpr (!LAST) {
+                        rd_row(qfr, Qs, qn2);
+                        rd_row(dofr, dOs, qn2);
+                    }
+                    ATTN_SB();
+                    mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
+                    mt(1, dotr, ph, pl, dv); mt(1, qtr, sh, sl, dk); ATTN_SB();
+                    mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB();
                 } else {
-                    sl = sh;
+                    ev(0, 8); ATTN_SB();
+                    if constexpr (!LAST) mm(0, qfr, kfB[0], kfB[0], nsm, nsm); pkP(0); pkS(0); ATTN_SB();
+                    if constexpr (!LAST) mm(0, dofr, vfB[0], vfB[0], ndp, ndp); ev(8, 16); ATTN_SB();
+                    mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
+                    rd_tr(dotr, dOs, qt, 1);
+                    rd_tr(qtr, Qs, qt, 1);
+                    ATTN_SB();
+                    if constexpr (!LAST) mm(1, qfr, kfB[0], kfB[0], nsm, nsm); if constexpr (!LAST) mm(1, dofr, vfB[0], vfB[0], ndp, ndp); pkP(1); pkS(1); ATTN_SB();
+                    if constexpr (!LAST) {
+                        rd_row(qfr, Qs, qn2);
+                        rd_row(dofr, dOs, qn2);
+                    }
+                    ATTN_SB();
+                    mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the dS^T tile is written, every read of query tile qt has returned
+                ATTN_STAMP(12 + qt);
+                __builtin_amdgcn_s_barrier();
+                ATTN_SB();
+                ATTN_STAMP(2 + qt);
+                if (qt + 1 < nt) window(basen, basen, dobn, qt + 1);    // the window this barrier opened (the last one is the helper's)
             };
-            if constexpr (A::SP) {
-                ev(0, 4); ATTN_SB();
-                mm(0, qfr, kfB[0], kfB[1], nsm, nsm); ev(4, 8); ATTN_SB();
-                mm(0, dofr, vfB[0], vfB[1], ndp, ndp); pkP(0); ATTN_SB();
-                mm(1, qfr, kfB[0], kfB[1], nsm, nsm); pkS(0); ATTN_SB();
-                mm(1, dofr, vfB[0], vfB[1], ndp, ndp); ev(8, 11); ATTN_SB();
-                mm(2, qfr, kfB[0], kfB[1], nsm, nsm); ev(11, 14); ATTN_SB();
-                mm(2, dofr, vfB[0], vfB[1], ndp, ndp); ev(14, 16); ATTN_SB();
-                mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
-                mt(1, dotr, ph, pl, dv); mt(1, qtr, sh, sl, dk); ATTN_SB();
-                mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB();
-                rd_tr(dotr, dOs, qt, 1);
-                rd_tr(qtr, Qs, qt, 1);
-                ATTN_SB();
-                mm(3, qfr, kfB[0], kfB[1], nsm, nsm); mm(3, dofr, vfB[0], vfB[1], ndp, ndp); pkP(1); ATTN_SB();
-                mm(4, qfr, kfB[0], kfB[1], nsm, nsm); mm(4, dofr, vfB[0], vfB[1], ndp, ndp); pkS(1); ATTN_SB();
-                mm(5, qfr, kfB[0], kfB[1], nsm, nsm); mm(5, dofr, vfB[0], vfB[1], ndp, ndp); ATTN_SB();
-                rd_row(qfr, Qs, qn2);
-                rd_row(dofr, dOs, qn2);
-                ATTN_SB();
-                mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
-                mt(1, dotr, ph, pl, dv); mt(1, qtr, sh, sl, dk); ATTN_SB();
-                mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB();
-            } else {
-                ev(0, 8); ATTN_SB();
-                mm(0, qfr, kfB[0], kfB[0], nsm, nsm); pkP(0); pkS(0); ATTN_SB();
-                mm(0, dofr, vfB[0], vfB[0], ndp, ndp); ev(8, 16); ATTN_SB();
-                mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
-                rd_tr(dotr, dOs, qt, 1);
-                rd_tr(qtr, Qs, qt, 1);
-                ATTN_SB();
-                mm(1, qfr, kfB[0], kfB[0], nsm, nsm); mm(1, dofr, vfB[0], vfB[0], ndp, ndp); pkP(1); pkS(1); ATTN_SB();
-                rd_row(qfr, Qs, qn2);
-                rd_row(dofr, dOs, qn2);
-                ATTN_SB();
-                mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
+            static_assert(NT % 2 == 1, "the last step is peeled off the two-step loop");
+            // Nothing of the compiler's own may be in flight when the loop starts: a spill reload placed in front of the loop gets its wait - vmcnt(0),
+            // which also covers every LDS-DMA - at the value's first use INSIDE the loop, i.e. in every iteration.  So: a compiler-visible wait
+            // here (only scratch reloads can be pending), and window 0 of the next pair's pieces goes out behind it.
+            __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+    #pragma unroll 1
+            for (int qt = 0; qt + 1 < nt; qt += 2) {
+                step(smA, dpA, smB, dpB, qt, std::false_type{});
+                step(smB, dpB, smA, dpA, qt + 1, std::false_type{});
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the dS^T tile is written, every read of query tile qt has returned
-            ATTN_STAMP(12 + qt);
-            __builtin_amdgcn_s_barrier();
-            ATTN_SB();
-            ATTN_STAMP(2 + qt);
-            if (qt + 1 < nt) {                                          // the window this barrier opened (the last one is the helper's)
-                dma_entry(basen, basen, dobn, qt + 1, wave);
-                dma_entry(basen, basen, dobn, qt + 1, wave + 8);
+            step(smA, dpA, smB, dpB, nt - 1, std::true_type{});
+            if constexpr (DMA) {                                           // the next pair's O rows into the idle dS^T buffer
+                const E* on = out + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
+                for (int pj = wave; pj < np; pj += 3) dma_sv((const char*)on + (long)pj * RPP * os * 2, voff_os(pj), G::off_scr(Tn, 1), pj);
             }
-        };
-        static_assert(NT % 2 == 1, "the last step is peeled off the two-step loop");
-        // Nothing of the compiler's own may be in flight when the loop starts: a spill reload placed in front of the loop gets its wait - vmcnt(0),
-        // which also covers every LDS-DMA - at the value's first use INSIDE the loop, i.e. in every iteration.  So: a compiler-visible wait
-        // here (only scratch reloads can be pending), and window 0 of the next pair's pieces goes out behind it.
-        __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
-        dma_entry(basen, basen, dobn, 0, wave);
-        dma_entry(basen, basen, dobn, 0, wave + 8);
-#pragma unroll 1
-        for (int qt = 0; qt + 1 < nt; qt += 2) {
-            step(smA, dpA, smB, dpB, qt);
-            step(smB, dpB, smA, dpA, qt + 1);
+            const int k = wave * 32 + kr;
+            if (k < Tn) {
+                store_tile_T16<T>(dbase + (long)k * rs + hs, dk, scale, lane);
+                store_tile_T16<T>(dbase + (long)k * rs + 2 * hs, dv, 1.0f, lane);
+            }
+            ATTN_STAMP(11);
+            wait_vm<0>();                                                  // this wave's pieces have landed (the stores above have left)
+            if (more) head();                                          // (the pair loop is rotated: the O rows requested above die inside this iteration)
         }
-        // the next pair's O rows / lse are requested HERE, in front of the last step: 17 registers that are not live in the loop (requested
-        // behind barrier Z they were, the loop spilled, and the reloads' waits - vmcnt(0) at the top of every iteration - also waited for
-        // every LDS-DMA of the step before)
-        if (more) o_fetch(bidn);
-        step(smA, dpA, smB, dpB, nt - 1);
-        wait_vm<0>();                                                  // this wave's pieces (the last ones a step old) and the O rows have landed
-        const int k = wave * 32 + kr;
-        if (k < Tn) {
-            store_tile_T16<T>(dbase + (long)k * rs + hs, dk, scale, lane);
-            store_tile_T16<T>(dbase + (long)k * rs + 2 * hs, dv, 1.0f, lane);
-        }
-        ATTN_STAMP(11);
-    }
+    };
+    if (wave < 3) key_role(std::true_type{});
+    else key_role(std::false_type{});
 }
 
 // column sums of a [M][N] matrix of T (N logical columns, N % 8 == 0) into f32 out[N] (atomicAdd).  Used for d qkv.bias.
