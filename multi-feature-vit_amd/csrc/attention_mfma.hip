@@ -1970,13 +1970,13 @@ template <typename T> int launch_bwd_t(const void* qkv, const void* out, const v
         (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    {   // single-pass kernel (split bf16 by default; MFVIT_ATTN_BWD_SP=0 off, 2 = the plain 16-bit types too)
+    {   // single-pass kernel: seven row tiles (T = 193 .. 224), enough pairs to give every CU two.  Default for all three 16-bit types
+        // (bench shape: split bf16 115 vs 155 us, bf16 / fp16 62.5 vs 71 us: profiles/r04_kernel_experiments.txt); MFVIT_ATTN_BWD_SP=0: off
         static int sws = INT_MIN;
         const int cus3 = attn_cus();
         const int nt = (Tn + 31) >> 5;
         const int b3 = SpGeo<T>::lds_bytes(Tn);
-        const int want = env_switch("MFVIT_ATTN_BWD_SP", 0, sws);
-        if ((want == 2 || (want == 1 && is_split<T>::value)) && B * H >= 2 * cus3 && nt == 7 && b3 <= 160 * 1024) {
+        if (env_switch("MFVIT_ATTN_BWD_SP", 1, sws) != 0 && B * H >= 2 * cus3 && nt == 7 && b3 <= 160 * 1024) {
             (void)hipFuncSetAttribute((const void*)attn_bwd_sp_kernel<T, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             {
                 ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);

@@ -216,12 +216,16 @@ def test_attention_fwd_bwd(mode, B, T, H):
 
 
 @pytest.mark.parametrize("mode", ATT_MODES, ids=[m.name for m in ATT_MODES])
-def test_attention_persistent_kernels_behind_their_switches(monkeypatch, mode):
-    """The persistent producer-wave attention kernels that are NOT the default for a precision (csrc/attention_mfma.hip: the forward for the
-    plain 16-bit types, MFVIT_ATTN_FWD_RING=2; the backward without register prefetch, MFVIT_ATTN_BWD_PP=1) against float64 at B * H = 540."""
+@pytest.mark.parametrize("bwd", ["two-phase", "producer-wave"])
+def test_attention_persistent_kernels_behind_their_switches(monkeypatch, mode, bwd):
+    """The persistent attention kernels that are NOT the default for a precision (csrc/attention_mfma.hip) against float64 at B * H = 540:
+    the producer-wave forward for the plain 16-bit types (MFVIT_ATTN_FWD_RING=2) and the two two-phase backward kernels - with register
+    prefetch (MFVIT_ATTN_BWD_SP=0) and with a producer wave (+ MFVIT_ATTN_BWD_PP=1); the default backward at this shape is the single-pass
+    kernel (test_attention_fwd_bwd[45-197-12], test_attention_single_pass_backward_tile_edges)."""
     from mfvit import ops
     monkeypatch.setenv("MFVIT_ATTN_FWD_RING", "2")        # (tests/conftest.py sets MFVIT_AB_LIVE=1: switches are read at every launch)
-    monkeypatch.setenv("MFVIT_ATTN_BWD_PP", "1")
+    monkeypatch.setenv("MFVIT_ATTN_BWD_SP", "0")
+    monkeypatch.setenv("MFVIT_ATTN_BWD_PP", "1" if bwd == "producer-wave" else "0")
     B, T, H, D = 45, 197, 12, 384
     qkv, dout = rnd((B, T, 3 * D), 27), rnd((B, T, D), 28)
     qd = mode.rounded(qkv).requires_grad_(True)
@@ -231,9 +235,30 @@ def test_attention_persistent_kernels_behind_their_switches(monkeypatch, mode):
     o_ref.backward(mode.rounded(dout))
     dqkv, dbias = ops.attention_bwd(mode.pack(qkv), out, mode.pack(dout), lse, H, split=mode.split)
     e_d, e_b = rel_err(mode.unpack(dqkv), qd.grad), rel_err(dbias, qd.grad.sum((0, 1)))
-    log(f"attention persistent kernels[{mode.name},B={B}] out {e_o:.2e} lse {e_l:.2e} dqkv {e_d:.2e} dbias {e_b:.2e}")
+    log(f"attention persistent kernels[{mode.name},B={B},{bwd}] out {e_o:.2e} lse {e_l:.2e} dqkv {e_d:.2e} dbias {e_b:.2e}")
     t = 2e-4 if mode.split else (4e-3 if mode.name == "fp16" else 2e-2)
     assert e_o < mode.tol and e_l < 1e-5 and e_d < t and e_b < t
+
+
+@pytest.mark.parametrize("mode", ATT_MODES, ids=[m.name for m in ATT_MODES])
+@pytest.mark.parametrize("T", [193, 208, 209, 224])
+def test_attention_single_pass_backward_tile_edges(mode, T):
+    """The single-pass backward (attn_bwd_sp_kernel: seven row tiles, B * H >= 2 x #CUs) at the edges of its last tile: one valid row in
+    it (193), exactly its first / just into its second 16-row half (208 / 209), no padding at all (224); 43 x 12 = 516 pairs, so
+    workgroups own two or three pairs (first, middle and last pair of a persistent loop).  dq / dk / dv separately against float64."""
+    from mfvit import ops
+    B, H, D = 43, 12, 384
+    qkv, dout = rnd((B, T, 3 * D), 31 + T), rnd((B, T, D), 32 + T)
+    qd = mode.rounded(qkv).requires_grad_(True)
+    o_ref, _ = _attn_ref(qd, H)
+    out, lse = ops.attention_fwd(mode.pack(qkv), H, split=mode.split)
+    o_ref.backward(mode.rounded(dout))
+    dqkv, dbias = ops.attention_bwd(mode.pack(qkv), out, mode.pack(dout), lse, H, split=mode.split)
+    g, r = mode.unpack(dqkv).view(B, T, 3, D), qd.grad.view(B, T, 3, D)
+    es = [rel_err(g[:, :, i], r[:, :, i]) for i in range(3)]
+    log(f"attention single-pass backward[{mode.name},T={T}] dq {es[0]:.2e} dk {es[1]:.2e} dv {es[2]:.2e} dbias {rel_err(dbias, qd.grad.sum((0, 1))):.2e}")
+    t = 2e-4 if mode.split else (4e-3 if mode.name == "fp16" else 2e-2)
+    assert max(es) < t and torch.isfinite(dqkv.float()).all()
 
 
 def test_layernorm_rows_split_and_f16():
