@@ -525,13 +525,17 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
         f32x4v gm[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) gm[j] = *(const f32x4v*)(gamp + ncol0 + 16 * j);
-        float mu[MF], rsd[MF];
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const unsigned m = (unsigned)row_of(i);
-            mu[i] = p.mean[m];
-            rsd[i] = p.rstd[m];
+        // Row statistics of the tile (mean, rstd of the saved LayerNorm input) into the scratch area, read per row fragment from LDS in both
+        // phases.  (Held in 14 registers per lane they were spilled together with the residual-gradient pointer, and every reload - a scratch
+        // load - waits for ALL vector-memory operations in flight: the residual-gradient prefetch of the next fragments ran one fragment at a time.)
+        float* stat = (float*)(lds + RP_RING + 2 * 8 * RP_TH * 4);      // behind red / red2: [2][RP_TH] (896 B of the 1024 left; the prologue's dummy line is dead)
+        if (tid < RP_TH) {
+            const unsigned m = (unsigned)(m0 + (tid < rows ? tid : rows - 1));
+            stat[tid] = p.mean[m];
+            stat[RP_TH + tid] = p.rstd[m];
         }
+        auto mu_of = [&](int i) __attribute__((always_inline)) { return stat[16 * i + fre]; };            // (rows past the tile: the last valid row's, like x)
+        auto rsd_of = [&](int i) __attribute__((always_inline)) { return stat[RP_TH + 16 * i + fre]; };
         // residual gradient of row fragment i -> rq[i % 3] (f32 rows, or the operand-type copy: hi + lo)
         int xlaunder = 0;                                              // (opaque zero, refreshed before the second phase: its reads of x must not
                                                                        // be merged with the first phase's - that kept 84 values of h alive, in scratch)
@@ -611,17 +615,18 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
                 if (i + 2 < MF) res_load(i + 2);
                 const bool ok = 16 * i + fre < rows;
                 float a1 = 0.f, a2 = 0.f;
+                const float mu_i = mu_of(i), rsd_i = rsd_of(i);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const f32x4v xv = x_lds(i, j);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float h = (xv[r] - mu[i]) * rsd[i], dy = acc[i][j][r], g = dy * gm[j][r];
+                        const float h = (xv[r] - mu_i) * rsd_i, dy = acc[i][j][r], g = dy * gm[j][r];
                         a1 += g;
                         a2 += g * h;
                         cg[j][r] += ok ? dy * h : 0.f;
                         cb[j][r] += ok ? dy : 0.f;
-                        acc[i][j][r] = rsd[i] * g + res_val(rq[i % 3][j], r);
+                        acc[i][j][r] = rsd_i * g + res_val(rq[i % 3][j], r);
                     }
                     // pinned here: left alone, the compiler sinks these updates behind the reduction (next to their uses) and carries h of
                     // every element there - through scratch
@@ -650,13 +655,14 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const bool ok = 16 * i + fre < rows;
-            const float k1 = rsd[i] * s1[i] * invN, k2 = rsd[i] * s2[i] * invN;
+            const float mu_i = mu_of(i), rsd_i = rsd_of(i);
+            const float k1 = rsd_i * s1[i] * invN, k2 = rsd_i * s2[i] * invN;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const f32x4v xv = x_lds(i, j);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float dx = acc[i][j][r] - (k1 + (xv[r] - mu[i]) * rsd[i] * k2);
+                    const float dx = acc[i][j][r] - (k1 + (xv[r] - mu_i) * rsd_i * k2);
                     acc[i][j][r] = dx;
                     cx[j][r] += ok ? dx : 0.f;
                 }
