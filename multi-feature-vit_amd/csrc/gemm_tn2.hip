@@ -76,7 +76,9 @@ template <typename T> __device__ __forceinline__ typename Vec8<T>::type t2_frag(
 }
 
 // T = bf16 | f16 | sbf16 (split bf16, see T2Geo)
-template <typename T, bool CS, bool W8, bool IL>
+// RM: the rows of A are REMAPPED (GemmP::orow_*: the patch-embedding weight gradient reads the token rows 1 .. np of every image of a [B][np + 1][D]
+// gradient tensor); instantiated for the default split-bf16 form only
+template <typename T, bool CS, bool W8, bool IL, bool RM = false>
 __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
     typedef T2Geo<T> G;
     constexpr int NWV = W8 ? 8 : 4;                          // waves
@@ -125,6 +127,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
         for (int i = 0; i < NI; ++i) {
             int m = mrow + NWV * RPI * i;
             m = m < p.M ? m : p.M - 1;                        // never read past the tensor (clamped rows are zeroed below)
+            if constexpr (RM) m = out_row(p, m);
             t2_glds16(A + (long)m * lda_ + n0 + lch * 8, sa + i * NWV * 1024);
         }
 #pragma unroll
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
         int m = mbeg + stc * KR + lrow + NWV * RPI * i;
         m = m < p.M ? m : p.M - 1;
         const unsigned dst = lbase + (unsigned)slot * T2_STAGE + (d >= NI ? T2_TILE : 0) + i * NWV * 1024;
-        if (d < NI) t2_glds16(A + (long)m * lda_ + n0 + lch * 8, dst);
+        if (d < NI) t2_glds16(A + (long)(RM ? out_row(p, m) : m) * lda_ + n0 + lch * 8, dst);
         else t2_glds16(X + (long)m * ldw_ + k0 + lch * 8, dst);
     };
 
@@ -401,7 +404,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
 
 bool gemm_tn_glds_supported(int dtype, const GemmP& p) {
     static const int on = [] { const char* e = getenv("MFVIT_TN_GLDS"); return e ? atoi(e) : 1; }();
-    if (!on || (dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || p.nb > 1 || p.orow_in) return false;
+    if (!on || (dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || p.nb > 1) return false;
+    if (p.orow_in) {                                            // remapped A rows: the default split-bf16 form without bias sums only
+        static int sw8r = INT_MIN, swilr = INT_MIN;
+        if (dtype != MFVIT_BF16X3 || p.cs0 || p.res_mod || env_switch("MFVIT_TN2_W8", 1, sw8r) == 0 || env_switch("MFVIT_TN2_IL", 1, swilr) == 0) return false;
+    }
     if (p.N % 128 || p.K % 128 || p.M < 4096) return false;     // 128 x 128 LOGICAL tiles in every mode
     if (p.lda % 8 || p.ldw % 8) return false;
     return true;
@@ -458,7 +465,17 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
         if (w8) go2(cs, std::true_type{});
         else go2(cs, std::false_type{});
     };
-    if (p.cs0) go1(std::true_type{});
+    if (p.orow_in) {
+        if constexpr (is_split<T>::value) {
+            static PerDeviceOnce attr_rm;
+            if (attr_rm.first())
+                (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<T, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            p.cpart = nullptr;
+            MFVIT_LAUNCH((gemm_tn_glds_kernel<T, false, true, true, true>), dim3(tiles * p.splits), dim3(512), bytes, st, p);
+        } else {
+            return MFVIT_EINVAL;
+        }
+    } else if (p.cs0) go1(std::true_type{});
     else go1(std::false_type{});
     MFVIT_CHECK_LAUNCH();
     if (p.cpart) return tn_partial_reduce(p.cpart, p.splits, p.N, p.K, (float*)p.out0, p.ldo0, st);
