@@ -1413,7 +1413,8 @@ template <typename T> struct SpGeo {
     static __host__ __device__ int timg(int Tn) { return (Tn + RPP - 1) / RPP * RPP; }
     static __host__ __device__ int tpad(int Tn) { return (Tn + 31) & ~31; }
     static __host__ __device__ int img(int Tn) { return timg(Tn) * RB; }
-    // [dO][Q][V][K][dS^T tiles x 2][row constants]: a tile read past an image's rows lands in the next image / in dS^T values (finite 16-bit data)
+    // [dO][Q][O][K][dS^T tiles x 2][row constants] (off_v: the O rows - V itself never enters LDS): a tile read past an image's rows lands in the
+    // next image / in dS^T values (finite 16-bit data)
     static __host__ __device__ int off_do(int) { return 0; }
     static __host__ __device__ int off_q(int Tn) { return img(Tn); }
     static __host__ __device__ int off_v(int Tn) { return 2 * img(Tn); }
@@ -1478,12 +1479,12 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
                        "s"(__builtin_amdgcn_readfirstlane(Tn - pj * RPP)), "v"(lrow)
                      : "memory", "vcc");
     };
-    // entry i (0 .. 15) of step window w: i < 8: K / V piece 8 w + i (window 0: 16 of them); i >= 8: piece i - 8 of query tile w - 1 of Q (then dO).
+    // entry i (0 .. 15) of step window w: i < 8: piece 8 w + i of the K-then-O stream (window 0: 16 of them); i >= 8: piece i - 8 of query tile w - 1 of Q (then dO).
     // Everything is a select on scalars - indices past the end repeat the last piece (identical bytes into rows nobody reads any more).
     constexpr int PPT = 32 / RPP;                                      // pieces per tile and image
-    auto dma_entry = [&](const E* kvsrc, const E* qsrc, const E* dosrc, int w, int i) __attribute__((always_inline)) {
+    auto dma_entry = [&](const E* ksrc, const E* osrc, const E* qsrc, const E* dosrc, int w, int i) __attribute__((always_inline)) {
         const bool kv = i < 8 || w == 0;
-        int pi = w == 0 ? i : 16 + 8 * (w - 1) + i;                    // K / V piece (K pieces first)
+        int pi = w == 0 ? i : 16 + 8 * (w - 1) + i;                    // piece of the K (first) / O stream
         pi = pi < 2 * np ? pi : 2 * np - 1;
         const int second = pi >= np ? 1 : 0;
         int e = i - 8;                                                 // Q / dO piece of tile w - 1
@@ -1492,26 +1493,40 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
         int pq = (w - 1) * PPT + (e - isdo * PPT);
         pq = pq < np ? pq : np - 1;
         const int pj = kv ? pi - second * np : pq;
-        const char* src = kv ? (const char*)(kvsrc + (second ? 2 * hs : hs)) : (isdo ? (const char*)dosrc : (const char*)qsrc);
-        const long stride = (!kv && isdo) ? os : rs;
+        const bool o_str = (kv && second) || (!kv && isdo);            // O and dO rows are os apart, K and Q rows rs
+        const char* src = kv ? (second ? (const char*)osrc : (const char*)ksrc) : (isdo ? (const char*)dosrc : (const char*)qsrc);
+        const long stride = o_str ? os : rs;
         const int off = kv ? (second ? G::off_v(Tn) : G::off_k(Tn)) : (isdo ? G::off_do(Tn) : G::off_q(Tn));
-        const unsigned vsel = (!kv && isdo) ? 1u : 0u;
+        const unsigned vsel = o_str ? 1u : 0u;
         const unsigned vo = (vrs_e + vsel * (vos_e - vrs_e)) ^ (sw_x & (0u - (unsigned)(pj & 1)));
         dma_sv(src + (long)pj * RPP * stride * 2, vo, off, pj);
     };
     const bool helper = wave == NCW;
     char* const dOs = lds + G::off_do(Tn);
     char* const Qs = lds + G::off_q(Tn);
-    char* const Vs = lds + G::off_v(Tn);
     char* const Ks = lds + G::off_k(Tn);
     float* const Ls = (float*)(lds + G::off_ld(Tn));
     float* const Ds = Ls + Tpad;
 
-    // The O rows of a pair (needed once, for D = rowsum(dO o O)) come in by LDS-DMA like the other images - into the SECOND dS^T buffer, which is
-    // idle between the last step barrier of one pair and step 1 of the next (key waves 0 - 2 request them behind that barrier; the helper reads
-    // buffer 0 then).  In registers (16 per lane, requested a step or a tail ahead) the waves that issue the LDS-DMA windows spilled them the
-    // moment they were loaded - load, wait, spill, four HBM latencies per pair - whatever the placement.
-    char* const Os = lds + G::off_scr(Tn, 1);
+    // V never enters LDS: a key wave needs only ITS key tile of V, as B fragments whose 16 bytes per lane are 16 contiguous bytes of a V row -
+    // it loads them straight from global memory into the fragment registers at the start of the last step (their last use of the pair is
+    // behind them by then).  The image that would hold V holds the O rows instead (needed once, in the head of a pair, for D = rowsum(dO o O)):
+    // they stream in with the K pieces during the steps.  (Round-4 history: O in 16 registers per lane was spilled in the waves that issue
+    // LDS-DMA - load, wait, spill, four HBM latencies per pair; O through the idle dS^T buffer could only be requested behind the last step
+    // barrier - most of one HBM latency exposed per pair.)
+    char* const Os = lds + G::off_v(Tn);
+    auto v_fetch = [&](frag_t (&vf)[2][2], const E* vsrc) __attribute__((always_inline)) {   // V rows of key tile `wave` (vsrc: the pair's V base)
+        const int key = wave * 32 + kr, kc = key < Tn ? key : Tn - 1;
+        const E* vp = vsrc + (long)kc * rs;
+#pragma unroll
+        for (int part = 0; part <= LO; ++part)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                union { uint4 u; frag_t f; } t;
+                t.u = *(const uint4*)(vp + 8 * ((A::SP ? 4 * part : 0) + 2 * s2 + hh));
+                vf[part][s2] = t.f;
+            }
+    };
     // -lse / scale rows of a pair: by the helper (four rows per lane), behind the last step barrier of the pair before (nobody reads the rows any more)
     float lsv[4];
     auto lse_fetch = [&](int bid_) __attribute__((always_inline)) {
@@ -1621,10 +1636,9 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
         const E* dob = dout + (long)(bid / H) * Tn * os + (bid % H) * HD * EP;
         for (int pj = wave; pj < np; pj += 8) {
             dma_sv((const char*)(base + hs) + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_k(Tn), pj);
-            dma_sv((const char*)(base + 2 * hs) + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_v(Tn), pj);
             dma_sv((const char*)base + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_q(Tn), pj);
             dma_sv((const char*)dob + (long)pj * RPP * os * 2, voff_os(pj), G::off_do(Tn), pj);
-            dma_sv((const char*)(out + (long)(bid / H) * Tn * os + (bid % H) * HD * EP) + (long)pj * RPP * os * 2, voff_os(pj), G::off_scr(Tn, 1), pj);
+            dma_sv((const char*)(out + (long)(bid / H) * Tn * os + (bid % H) * HD * EP) + (long)pj * RPP * os * 2, voff_os(pj), G::off_v(Tn), pj);
         }
         if (helper) lse_fetch(bid);
         wait_vm<0>();
@@ -1645,6 +1659,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             const int bidn = pair_bid(more ? kp + 1 : kp);
             const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
             const E* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
+            const E* obn = out + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             ++rnd_no;
             ATTN_STAMP(10);
@@ -1670,9 +1685,13 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             __builtin_amdgcn_s_barrier();                              // Z: K / V are dead
             ATTN_SB();
             ATTN_STAMP(1);
-            // window 0 of the next pair's pieces (16 K / V pieces): the helper has nothing else to do until the first step's dS^T tiles exist
+            // The last query tile's Q / dO pieces of THIS pair were requested behind the last step barrier of the pair before; nobody waited for
+            // them in front of barrier X (most of an HBM latency per pair): they are waited for HERE, and the first step barrier hands them on -
+            // their first readers are behind it (the row constants of the last query tile, the row fragments prefetched in step nt - 3).
+            wait_vm<0>();
+            // window 0 of the next pair's pieces (16 K pieces): the helper has nothing else to do until the first step's dS^T tiles exist
             for (int i = 0; i < 16; ++i) {
-                dma_entry(basen, basen, dobn, 0, i);
+                dma_entry(basen + hs, obn, basen, dobn, 0, i);
                 __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll 1
@@ -1687,8 +1706,11 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
                         dma_sv((const char*)basen + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_q(Tn), pj);
                         dma_sv((const char*)dobn + (long)pj * RPP * os * 2, voff_os(pj), G::off_do(Tn), pj);
                     }
-                    if (more) lse_fetch(bidn);                         // (under the last dQ tile's MFMAs)
                 }
+                // -lse / scale rows of the next pair: requested two steps from the end, written one step from the end (the last reader of this
+                // pair's rows - the row constants of the last query tile - is in front of barrier nt - 2)
+                if (more && u + 3 == nt) lse_fetch(bidn);
+                if (more && u + 2 == nt) lse_write();
                 const char* sc = lds + G::off_scr(Tn, u & 1);
                 f32x16 dq, dq1;                                        // two accumulators (k-step 0 / 1): a single chain of 42 dependent MFMAs issues at ~40 cycles each
 #pragma unroll
@@ -1709,8 +1731,6 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
                 const int q = u * 32 + kr;
                 if (q < Tn) store_tile_T16<T>(dbase + (long)q * rs, dq, scale, lane);
             }
-            wait_vm<0>();                                              // this wave's pieces of the next pair have landed (and its dQ stores have left)
-            if (more) lse_write();
         }
         return;
     }
@@ -1718,12 +1738,12 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
     // reach the step barrier ~1,000 cycles ahead of their SIMD partners (waves 4 - 6) - an LDS-DMA stalls only the wave that issues it.
     auto key_role = [&](auto dma_tag) __attribute__((always_inline)) {
         constexpr bool DMA = decltype(dma_tag)::value;
-        auto window = [&](const E* kvsrc, const E* qsrc, const E* dosrc, int w) __attribute__((always_inline)) {
+        auto window = [&](const E* ksrc, const E* osrc, const E* qsrc, const E* dosrc, int w) __attribute__((always_inline)) {
             if constexpr (DMA) {
 #pragma unroll
                 for (int e3 = 0; e3 < 6; ++e3) {
                     const int i = wave + 3 * e3;                       // (wave 0: 0 3 6 9 12 15; wave 1: 1 4 .. 13 and 13 again; wave 2: 2 5 .. 14, 14)
-                    dma_entry(kvsrc, qsrc, dosrc, w, i < 16 ? i : i - 3);
+                    dma_entry(ksrc, osrc, qsrc, dosrc, w, i < 16 ? i : i - 3);
                 }
             }
         };
@@ -1737,20 +1757,23 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             ATTN_SB();
             ATTN_STAMP(0);
             // ----------------------------------------------------------------------------------------------- key tile `wave`
-            rd_row(kfB, Ks, wave);
-            rd_row(vfB, Vs, wave);
+            rd_row(kfB, Ks, wave);                                         // (vfB: requested from global memory a step / a prologue ago)
             if (wave * 32 + kr >= Tn) {                                    // padded keys: zero K / V (the fragment's column is this lane's key)
     #pragma unroll
                 for (int part = 0; part <= LO; ++part)
     #pragma unroll
                     for (int s = 0; s < 2; ++s) { zero_frag(kfB[part][s]); zero_frag(vfB[part][s]); }
             }
-            consts();
+            if (wave + 1 < nt) consts();                                   // (the last query tile's: behind the first step barrier, see the helper)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                  // Z: the row constants are in place
             ATTN_SB();
             ATTN_STAMP(1);
         };
+        {
+            const int bid0 = pair_bid(0);
+            v_fetch(vfB, qkv + (long)(bid0 / H) * Tn * rs + (bid0 % H) * HD * EP + 2 * hs);
+        }
         head();
         for (int kp = 0; kp < npl; ++kp) {
             const int bid = pair_bid(kp);
@@ -1760,6 +1783,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             const int bidn = pair_bid(more ? kp + 1 : kp);
             const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
             const E* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
+            const E* obn = out + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
             int lane_l = lane;                                             // (every lane-derived value of the steps comes from this laundered copy)
             asm volatile("" : "+v"(lane_l));
             calc_offsets(lane_l);
@@ -1873,23 +1897,26 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
                 __builtin_amdgcn_s_barrier();
                 ATTN_SB();
                 ATTN_STAMP(2 + qt);
-                if (qt + 1 < nt) window(basen, basen, dobn, qt + 1);    // the window this barrier opened (the last one is the helper's)
+                if (qt + 1 < nt) window(basen + hs, obn, basen, dobn, qt + 1);    // the window this barrier opened (the last one is the helper's)
             };
-            static_assert(NT % 2 == 1, "the last step is peeled off the two-step loop");
+            static_assert(NT % 2 == 1 && NT >= 5, "steps 0, NT - 2 and NT - 1 are peeled off the two-step loop");
             // Nothing of the compiler's own may be in flight when the loop starts: a spill reload placed in front of the loop gets its wait - vmcnt(0),
             // which also covers every LDS-DMA - at the value's first use INSIDE the loop, i.e. in every iteration.  So: a compiler-visible wait
             // here (only scratch reloads can be pending), and window 0 of the next pair's pieces goes out behind it.
             __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
-    #pragma unroll 1
-            for (int qt = 0; qt + 1 < nt; qt += 2) {
-                step(smA, dpA, smB, dpB, qt, std::false_type{});
-                step(smB, dpB, smA, dpA, qt + 1, std::false_type{});
+                step(smA, dpA, smB, dpB, 0, std::false_type{});
+            if (wave + 1 == nt) {                                          // the last query tile's Q / dO rows are guaranteed from here on
+                consts();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (read four step barriers from here)
             }
+#pragma unroll 1
+            for (int qt = 1; qt + 3 < nt; qt += 2) {
+                step(smB, dpB, smA, dpA, qt, std::false_type{});
+                step(smA, dpA, smB, dpB, qt + 1, std::false_type{});
+            }
+            step(smB, dpB, smA, dpA, nt - 2, std::false_type{});
+            v_fetch(vfB, basen + 2 * hs);                                  // the next pair's V fragments (this pair's last dP MFMAs are behind us)
             step(smA, dpA, smB, dpB, nt - 1, std::true_type{});
-            if constexpr (DMA) {                                           // the next pair's O rows into the idle dS^T buffer
-                const E* on = out + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
-                for (int pj = wave; pj < np; pj += 3) dma_sv((const char*)on + (long)pj * RPP * os * 2, voff_os(pj), G::off_scr(Tn, 1), pj);
-            }
             const int k = wave * 32 + kr;
             if (k < Tn) {
                 store_tile_T16<T>(dbase + (long)k * rs + hs, dk, scale, lane);
