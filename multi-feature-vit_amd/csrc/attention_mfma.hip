@@ -1651,6 +1651,11 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
     // code (in one loop with role branches the helper's 112 K^T registers and the key waves' state were spilled around each other, and a scratch
     // reload waits for every LDS-DMA in flight).
     if (helper) {
+        // The helper is the longest wave of every step and shares its SIMD with key wave 3, which reaches the step barriers ~2,000 cycles early:
+        // issue priority to the helper (MFVIT_SP_PRIO: A/B macro).
+#ifndef MFVIT_SP_NOPRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
         for (int kp = 0; kp < npl; ++kp) {
             const int bid = pair_bid(kp);
             const int b = bid / H, h = bid % H;
@@ -1690,7 +1695,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             // their first readers are behind it (the row constants of the last query tile, the row fragments prefetched in step nt - 3).
             wait_vm<0>();
             // window 0 of the next pair's pieces (16 K pieces): the helper has nothing else to do until the first step's dS^T tiles exist
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 10; ++i) {                             // (entries 10 .. 15: key waves 0 - 2 in front of their first step)
                 dma_entry(basen + hs, obn, basen, dobn, 0, i);
                 __builtin_amdgcn_s_sleep(1);
             }
@@ -1904,6 +1909,10 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             // which also covers every LDS-DMA - at the value's first use INSIDE the loop, i.e. in every iteration.  So: a compiler-visible wait
             // here (only scratch reloads can be pending), and window 0 of the next pair's pieces goes out behind it.
             __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0)
+            if constexpr (DMA) {                                           // the last six entries of window 0 (the helper issues ten: more would make it late for the first step barrier)
+                dma_entry(basen + hs, obn, basen, dobn, 0, 10 + wave);
+                dma_entry(basen + hs, obn, basen, dobn, 0, 13 + wave);
+            }
                 step(smA, dpA, smB, dpB, 0, std::false_type{});
             if (wave + 1 == nt) {                                          // the last query tile's Q / dO rows are guaranteed from here on
                 consts();
