@@ -1472,7 +1472,11 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
         const char* piece_base = (const char*)(((unsigned long long)pb_hi << 32) | pb_lo);   // (unsigned halves: the builtin returns int - OR-ing it in sign-extends)
         unsigned long long keep_exec;
         unsigned keep_m0;
-        asm volatile("s_mov_b64 %0, exec\n\tv_cmp_gt_i32 vcc, %5, %6\n\ts_and_b64 exec, exec, vcc\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+        // (v_cmpx: the compare ANDs into exec itself and writes vcc - no scalar ALU instruction, so SCC is left alone.  The first version used
+        // s_and_b64 exec, exec, vcc WITHOUT an "scc" clobber: a compare the compiler held in SCC across the statement was lost - it only showed when
+        // an unrelated uniform branch made the compiler do so; WITH the clobber the scalar selects of the window arithmetic turned into vector
+        // code, 100 spilled registers and vmcnt(0) waits in the step loop: 108 -> 178 us)
+        asm volatile("s_mov_b64 %0, exec\n\tv_cmpx_gt_i32 vcc, %5, %6\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %1\n\ts_mov_b64 exec, %0"
                      : "=&s"(keep_exec), "=&s"(keep_m0)
                      : "v"(voff), "s"(piece_base), "s"(__builtin_amdgcn_readfirstlane((unsigned)lds_off + (unsigned)pj * 1024u)),
