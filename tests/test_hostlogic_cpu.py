@@ -259,3 +259,28 @@ def test_shipped_kernels_with_asm_loads_pass_the_hazard_scan():
     if not present:
         pytest.skip("no device assembly under build/ (library not built here)")
     ge.check_asm_load_hazards(objdir, regenerate=False)
+
+
+def test_inline_asm_statements_declare_what_they_write(tmp_path):
+    """tools/check_inline_asm.py: an asm statement that writes SCC / vcc must clobber it, m0 / exec must be restored inside the statement.
+    (Round 4: `s_and_b64 exec, exec, vcc` without an "scc" clobber corrupted a compare the compiler held in SCC - only once an unrelated
+    branch made it do so.)  The shipped sources pass; the statement of the bug and a vcc variant are flagged."""
+    import glob
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "check_inline_asm.py")
+    srcs = sorted(glob.glob(os.path.join(root, "multi-feature-vit_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "multi-feature-vit_amd", "csrc", "*.cuh")))
+    assert srcs
+    r = subprocess.run([sys.executable, tool] + srcs, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    bad = tmp_path / "bad.hip"
+    bad.write_text('void f() {\n'
+                   '  asm volatile("s_mov_b64 %0, exec\\n\\tv_cmp_gt_i32 vcc, %1, %2\\n\\ts_and_b64 exec, exec, vcc\\n\\ts_mov_b64 exec, %0" : "=&s"(k) : "s"(a), "v"(b) : "memory", "vcc");\n'
+                   '  asm volatile("v_cmp_gt_i32 vcc, %0, %1" :: "s"(a), "v"(b) : "memory");\n'
+                   '  asm volatile("s_mov_b32 m0, %0\\n\\tglobal_load_lds_dwordx4 %1, off" :: "s"(a), "v"(b) : "memory");\n'
+                   '}\n')
+    r = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1
+    assert "writes SCC" in r.stdout and "writes vcc" in r.stdout and "writes m0" in r.stdout, r.stdout
+
