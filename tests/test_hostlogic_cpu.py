@@ -284,3 +284,25 @@ def test_inline_asm_statements_declare_what_they_write(tmp_path):
     assert r.returncode == 1
     assert "writes SCC" in r.stdout and "writes vcc" in r.stdout and "writes m0" in r.stdout, r.stdout
 
+
+def test_loop_drain_scanner_flags_vmcnt0_and_spills_inside_mfma_loops(tmp_path):
+    """tools/scan_loop_waits.py (run by build() over the hot LDS-DMA kernels): a `vmcnt(0)` or a scratch access inside an innermost MFMA loop is
+    a finding - hipcc cannot count asm loads, its own waits drain the whole queue; a counted wait and a drain outside the loop are not."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "scan_loop_waits.py")
+    mf = "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]\n" * 12
+
+    def kernel(name, body):
+        return f"{name}:\n\ts_waitcnt vmcnt(0)\n.LBB0_1:\n{mf}{body}\ts_cbranch_scc1 .LBB0_1\n\ts_waitcnt vmcnt(0)\n\ts_endpgm\n"
+    good, bad1, bad2 = tmp_path / "good.s", tmp_path / "bad1.s", tmp_path / "bad2.s"
+    good.write_text(kernel("_Z4hotAv", "\ts_waitcnt vmcnt(4)\n"))
+    bad1.write_text(kernel("_Z4hotBv", "\ts_waitcnt vmcnt(0)\n"))
+    bad2.write_text(kernel("_Z4hotCv", "\tscratch_load_dword v1, off, off offset:8\n"))
+    run = lambda f, rx="hot": subprocess.run([sys.executable, tool, "--fail", rx, str(f)], capture_output=True, text=True)
+    assert run(good).returncode == 0
+    assert run(bad1).returncode == 1 and "vmcnt(0)" in run(bad1).stdout
+    assert run(bad2).returncode == 1 and "scratch_load" in run(bad2).stdout
+    assert run(bad1, "other_kernel").returncode == 0                  # (only kernels that match the name filter)
+

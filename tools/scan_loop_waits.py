@@ -1,23 +1,48 @@
-"""List compiler- or hand-placed `s_waitcnt vmcnt(0)` INSIDE loops of the device assembly of a .hip file (a full drain of the vector-memory
-queue in a main loop defeats any prefetch distance: the compiler places one when a register it believes in flight - it cannot count asm
-loads - is used inside the loop).  usage: scan_loop_waits.py file.s [...]"""
+"""Full drains of the vector-memory queue - `s_waitcnt vmcnt(0)` - and scratch (spill) accesses INSIDE the innermost MFMA loops of the device
+assembly.  hipcc cannot count loads issued from inline asm, so wherever IT needs a vector-memory result inside such a loop (a global load it
+issued, a spill reload) it waits for the whole queue - every LDS-DMA in flight included - and the prefetch distance of the loop is gone
+(DESIGN.md 5, round 4).
+usage: scan_loop_waits.py file.s [...]                         list every finding
+       scan_loop_waits.py --fail <kernel-name regex> file.s    exit code 1 if a matching kernel has one (used by __graft_entry__.build())"""
 import re, sys
-for path in sys.argv[1:]:
-    name, labels, lines = None, {}, open(path).read().split("\n")
-    # pass 1: label line numbers
+
+
+def scan(path, name_rx=None, min_mfma=12):
+    lines = open(path).read().split("\n")
+    labels = {}
     for i, l in enumerate(lines):
         m = re.match(r"^(\.LBB\d+_\d+):", l)
-        if m: labels[m.group(1)] = i
-    loops = []          # (start, end) line ranges of backward branches
+        if m:
+            labels[m.group(1)] = i
+    loops = []
     for i, l in enumerate(lines):
         m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l) or re.search(r"s_branch\s+(\.LBB\d+_\d+)", l)
-        if m and m.group(1) in labels and labels[m.group(1)] < i: loops.append((labels[m.group(1)], i))
-    for i, l in enumerate(lines):
-        m = re.match(r"^(_Z\w+):", l)
-        if m: name = m.group(1)
-        if re.search(r"s_waitcnt.*vmcnt\(0\)", l):
-            inside = [(a, b) for a, b in loops if a <= i <= b]
-            if inside:
-                a, b = min(inside, key=lambda r: r[1] - r[0])
-                mf = sum("v_mfma" in x for x in lines[a:b])
-                print(f"{path}: {name[:90]} line {i + 1}: loop of {b - a} lines, {mf} MFMAs: {l.strip()}")
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            loops.append((labels[m.group(1)], i))
+    inner = [(a, b) for a, b in loops if not any((c, d) != (a, b) and a <= c and d <= b for c, d in loops)]
+    starts = sorted((i, re.match(r"^(_Z\w+):", l).group(1)) for i, l in enumerate(lines) if re.match(r"^(_Z\w+):", l))
+    found = []
+    for a, b in inner:
+        mf = sum("v_mfma" in x for x in lines[a:b])
+        if mf < min_mfma:
+            continue
+        name = [n for i, n in starts if i <= a][-1] if starts and starts[0][0] <= a else "?"
+        if name_rx and not re.search(name_rx, name):
+            continue
+        for i in range(a, b):
+            if re.search(r"s_waitcnt.*vmcnt\(0\)", lines[i]) or "scratch_" in lines[i]:
+                found.append((name, i + 1, mf, lines[i].strip()))
+    return found
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    rx = None
+    if args and args[0] == "--fail":
+        rx, args = args[1], args[2:]
+    rc = 0
+    for p in args:
+        for name, line, mf, text in scan(p, rx):
+            print(f"{p}:{line}: {name[:100]}: innermost loop with {mf} MFMAs: {text}")
+            rc = 1 if rx else 0
+    sys.exit(rc)
