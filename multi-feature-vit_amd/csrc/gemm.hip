@@ -1231,7 +1231,7 @@ int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
     return MFVIT_EINVAL;
 }
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
-    if (gemm_nt_rowp_supported(dtype, repi, p)) return gemm_nt_rowp(repi, p, st);
+    if (gemm_nt_rowp_supported(dtype, repi, p)) return gemm_nt_rowp(dtype, repi, p, st);
     if (repi == REPI_RES_LN) return row_by_dtype<REPI_RES_LN>(dtype, p, st);
     if (repi == REPI_LNBWD_RES) {
         const int rc = row_by_dtype<REPI_LNBWD_RES>(dtype, p, st);

@@ -74,6 +74,9 @@ __device__ __forceinline__ void rp_dma16(unsigned voff, const char* sbase, unsig
                  : "memory");
 }
 
+__device__ __forceinline__ f32x4v rp_mfma(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4v rp_mfma(f16x8 a, f16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
 // MODE: the two row-complete epilogues (REPI_RES_LN = 0, REPI_LNBWD_RES = 1; N = 384: one pass, npass = 1).  (Round 3 also ran the plain
 // linears on this kernel as `npass` passes of 384 columns, MFVIT_ROWT=1: qkv 107 - 119 us against 80 of the 128 x 128 tile kernel, fc1 + GELU
 // 144 - 152 against 135 - the 8-byte-per-lane partial-line stores of this accumulator layout cost 20 - 45 us per launch; removed in round 4,
@@ -89,16 +92,24 @@ __device__ __forceinline__ void rp_dma4(unsigned voff, const char* sbase, unsign
 
 // MF: row fragments of 16 that carry rows (the launcher picks the smallest that covers its rows per tile: the ring always holds RP_TH rows - past
 // the tile they replicate its last row - but only MF fragments are multiplied, reduced and stored: at M = 3,152 a tile has 13 rows)
-template <int MODE, int MF>
+// T: sbf16 (split bf16: a 128-byte row = ONE 32-wide k group as [hi x 32 | lo x 32], three MFMAs per product) or a plain 16-bit type (bf16 / f16,
+// round 4: a 128-byte row = 64 k values = TWO k steps, one MFMA each).  The fragment addressing is the same in both - chunk q of a row is the hi part /
+// k step 0, chunk 4 + q the lo part / k step 1 - only the term table of the MFMAs and the output formats differ.
+template <int MODE, int MF, typename T>
 __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int npass) {
     constexpr int REPI = MODE;
-    typedef sbf16 T;
+    constexpr bool SPLIT = is_split<T>::value;
+    constexpr int KG = SPLIT ? 32 : 64;                                // logical k values per 128-byte row
+    constexpr int TERMS = SPLIT ? 3 : 2;                               // MFMAs per (row fragment, column fragment) and stage
+    constexpr int PER = 3 * TERMS;                                     // MFMAs per row fragment and stage
+    typedef typename Vec8<T>::type frag_t;
+    typedef typename Vec4<T>::elem E16;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * rpt;
     const int rows = p.M - m0 < rpt ? p.M - m0 : rpt;                 // valid rows of this tile (1 .. RP_TH)
-    const int nk = p.K / 32;
+    const int nk = p.K / KG;
     const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
 
     // ---- LDS-DMA: a row = 8 chunks of 16 B, positions XOR (R >> 1) & 7 (R = row inside its slot); a piece = 8 rows = one 1 KB instruction:
@@ -132,10 +143,10 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     const int fr = lane & 15, fq = lane >> 4, fsw = (fr >> 1) & 7;
     const int f_hi = fr * 128 + 16 * (fq ^ fsw), f_lo = fr * 128 + 16 * ((4 + fq) ^ fsw);
     auto frag_a = [&](int stage, int i, int off) __attribute__((always_inline)) {
-        return *(const bf16x8*)(lds + RP_WRING + (stage & (RP_ASLOTS - 1)) * RP_ASTAGE + (16 * i) * 128 + off);
+        return *(const frag_t*)(lds + RP_WRING + (stage & (RP_ASLOTS - 1)) * RP_ASTAGE + (16 * i) * 128 + off);
     };
     auto frag_w = [&](int stage, int j, int off) __attribute__((always_inline)) {
-        return *(const bf16x8*)(lds + (stage & 1) * RP_WSTAGE + (48 * wave + 16 * j) * 128 + off);
+        return *(const frag_t*)(lds + (stage & 1) * RP_WSTAGE + (48 * wave + 16 * j) * 128 + off);
     };
 
     // prologue.  Inside a training step W is cold, and every CU walks through it in lockstep: each stage would be a first touch served at HBM
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     // flight - caught by tools/check_vmem_hazards.py - the compiler does not know an asm load is outstanding).
     const int G = npass * nk;                                          // stages of the whole tile
     {
-        const unsigned lpr = (unsigned)(p.K / 32);                             // 128-byte lines per W row
+        const unsigned lpr = (unsigned)(p.K / KG);                             // 128-byte lines per W row
         const unsigned lines = (unsigned)p.N * lpr;                            // all passes
         const unsigned t0 = (unsigned)(blockIdx.x >> 3) * 512u + (unsigned)tid;
         const unsigned nthr = ((gridDim.x + 7u) >> 3) * 512u;
@@ -208,8 +219,8 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    bf16x8 wh[2][3], wl[2][3], ah[MF > 2 ? MF : 2], al[MF > 2 ? MF : 2];            // ah / al [0], [1]: unused (a01h / a01l hold those fragments)
-    bf16x8 a01h[2][2], a01l[2][2];
+    frag_t wh[2][3], wl[2][3], ah[MF > 2 ? MF : 2], al[MF > 2 ? MF : 2];            // ah / al [0], [1]: unused (a01h / a01l hold those fragments)
+    frag_t a01h[2][2], a01l[2][2];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         wh[0][j] = frag_w(0, j, f_hi);
@@ -237,17 +248,17 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     // LDS-DMA pieces of W(s + 2) / A(s + 4) into the slots just freed, the 6 W fragments and row fragments 0, 1 of stage s + 1.  MF = 7: barrier
     // behind the fourth row fragment, jobs on 27 slots (the schedule the round-3 numbers were measured on); MF <= 4: 18 slots, one job each;
     // MF = 1: 9 slots, two jobs each - such a tile is bound by its 48 KB W stage out of L2, not by the matrix pipe.
-    constexpr int NB = MF >= 7 ? 4 : MF == 6 ? 3 : MF >= 4 ? 2 : MF == 3 ? 1 : 0;
+    constexpr int NB = SPLIT ? (MF >= 7 ? 4 : MF == 6 ? 3 : MF >= 4 ? 2 : MF == 3 ? 1 : 0) : (MF > 2 ? MF - 2 : 0);   // (plain: 6 MFMAs per fragment, two reads per fragment)
     constexpr int NPRE = MF > 2 ? 2 * (MF - 2) : 0;                   // fragment reads in front of the barrier
     constexpr int NAF = MF > 1 ? 4 : 2;                                // A fragment registers of stage s + 1 read behind it
-    constexpr int POST = 9 * (MF - NB);                                // MFMA slots behind the barrier
+    constexpr int POST = PER * (MF - NB);                                // MFMA slots behind the barrier
     constexpr bool SPACED = POST >= 27;                                // one DMA every third slot (MF >= 5), else the jobs back to back
     constexpr int NJ = RP_LW + RP_LA + 6 + NAF;
     constexpr int JPS = SPACED ? 1 : (NJ + POST - 1) / POST;           // jobs per slot
-    static_assert(3 * NB * 3 >= NPRE, "fragment reads must fit in front of the barrier");
+    static_assert(PER * NB / 3 >= NPRE, "fragment reads must fit in front of the barrier");
     // (MF <= 4: row fragments 0, 1 of stage s + 1 are read while those of stage s still feed MFMAs - a second register set, like W's)
-    auto stage_body = [&](int s, bf16x8 (&wH)[3], bf16x8 (&wL)[3], bf16x8 (&wHn)[3], bf16x8 (&wLn)[3], bf16x8 (&aH)[2], bf16x8 (&aL)[2],
-                          bf16x8 (&aHn)[2], bf16x8 (&aLn)[2]) __attribute__((always_inline)) {
+    auto stage_body = [&](int s, frag_t (&wH)[3], frag_t (&wL)[3], frag_t (&wHn)[3], frag_t (&wLn)[3], frag_t (&aH)[2], frag_t (&aL)[2],
+                          frag_t (&aHn)[2], frag_t (&aLn)[2]) __attribute__((always_inline)) {
         // job k of the back-to-back order: D0 W0 A0 D1 W1 A1 ... (D = LDS-DMA piece, W / A = fragment read of stage s + 1)
         auto dma_job = [&](int k) __attribute__((always_inline)) {
             if (k < RP_LW) issue_w(wp, wk, s & 1, k);
@@ -277,26 +288,28 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
+            for (int t = 0; t < PER; ++t) {
                 const int j = t % 3, term = t / 3;
-                const bf16x8 av = i < 2 ? (term == 0 ? aL[i] : aH[i]) : (term == 0 ? al[i] : ah[i]);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 1 ? wL[j] : wH[j], av, acc[i][j], 0, 0, 0);
-                const int idx = 9 * i + t;
-                if (idx < 9 * NB) {
+                // split: a_lo w_hi + a_hi w_lo + a_hi w_hi; plain: k step 0 (the "hi" registers), then k step 1
+                const bool a_lo = SPLIT ? term == 0 : term == 1, w_lo = term == 1;
+                const frag_t av = i < 2 ? (a_lo ? aL[i] : aH[i]) : (a_lo ? al[i] : ah[i]);
+                acc[i][j] = rp_mfma(w_lo ? wL[j] : wH[j], av, acc[i][j]);
+                const int idx = PER * i + t;
+                if (idx < PER * NB) {
                     if (idx % 3 == 0 && idx / 3 < NPRE) {
                         const int k = idx / 3, fi = 2 + k / 2;
                         if (k % 2 == 0) ah[fi] = frag_a(s, fi, f_hi);
                         else al[fi] = frag_a(s, fi, f_lo);
                     }
                 } else if constexpr (SPACED) {
-                    const int u = idx - 9 * NB;                              // 0 .. 26
+                    const int u = idx - PER * NB;                              // 0 .. 26
                     if (u % 3 == 0 && u / 3 < RP_LW + RP_LA) dma_job(u / 3);
                     else if (u % 3 == 1 && u / 3 < 6) w_job(u / 3);
                     else if (u % 3 == 2 && u / 3 < NAF) a_job(u / 3);
                 } else {
 #pragma unroll
                     for (int q = 0; q < JPS; ++q) {
-                        const int n = (idx - 9 * NB) * JPS + q;              // job number: triples (D, W, A) while all three kinds last
+                        const int n = (idx - PER * NB) * JPS + q;              // job number: triples (D, W, A) while all three kinds last
                         // order: D0 W0 A0 .. D(NAF-1) W(NAF-1) A(NAF-1) | D W pairs up to W5 | the remaining D
                         if (n < 3 * NAF) {
                             if (n % 3 == 0) dma_job(n / 3);
@@ -394,7 +407,8 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
             pb[i] = tb;
         }
     };
-    // split output tile rows [16 i0, 16 i1) of this workgroup -> out (storage ld `ldo`), through LDS (ring region) as whole lines
+    // output tile rows [16 i0, 16 i1) of this workgroup in the operand type -> out (storage ld `ldo`), through LDS (ring region) as whole lines
+    constexpr int YB = RP_N * 2 * (SPLIT ? 2 : 1), YP = YB + 16, YCH = YB / 16;      // bytes of an output row, staging pitch, 16-byte chunks per row
     auto store_split = [&](void* out, long ldo, int i0, int i1) __attribute__((always_inline)) {
         char* ybuf = lds;
         fresh_lane();
@@ -404,22 +418,31 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int n = ncol0 + 16 * j;                          // 4 consecutive logical columns n .. n + 3 (inside one 32-group)
-                bf16 h0, h1, h2, h3, l0, l1, l2, l3;
-                cvt_pair<bf16, true>(acc[i][j][0], acc[i][j][1], h0, h1, l0, l1);
-                cvt_pair<bf16, true>(acc[i][j][2], acc[i][j][3], h2, h3, l2, l3);
-                bf16x4 hv, lv;
-                hv[0] = h0; hv[1] = h1; hv[2] = h2; hv[3] = h3;
-                lv[0] = l0; lv[1] = l1; lv[2] = l2; lv[3] = l3;
-                char* rowp = ybuf + (16 * (i - i0) + fre) * RP_YP + 128 * (n >> 5) + 2 * (n & 31);
-                *(stg_b4*)rowp = hv;
-                *(stg_b4*)(rowp + 64) = lv;
+                typedef typename Vec4<T>::type V4;
+                typedef V4 __attribute__((may_alias)) stg4;
+                if constexpr (SPLIT) {
+                    bf16 h0, h1, h2, h3, l0, l1, l2, l3;
+                    cvt_pair<bf16, true>(acc[i][j][0], acc[i][j][1], h0, h1, l0, l1);
+                    cvt_pair<bf16, true>(acc[i][j][2], acc[i][j][3], h2, h3, l2, l3);
+                    V4 hv, lv;
+                    hv[0] = h0; hv[1] = h1; hv[2] = h2; hv[3] = h3;
+                    lv[0] = l0; lv[1] = l1; lv[2] = l2; lv[3] = l3;
+                    char* rowp = ybuf + (16 * (i - i0) + fre) * YP + 128 * (n >> 5) + 2 * (n & 31);
+                    *(stg4*)rowp = hv;
+                    *(stg4*)(rowp + 64) = lv;
+                } else {
+                    V4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = from_f32<E16>(acc[i][j][r]);
+                    *(stg4*)(ybuf + (16 * (i - i0) + fre) * YP + 2 * n) = v;
+                }
             }
         }
         __syncthreads();
         const int nrow = 16 * (i1 - i0);
-        for (int q = tid; q < nrow * 96; q += 512) {
-            const int row = q / 96, ch = q % 96;
-            const u32x4 v = *(const u32x4 __attribute__((may_alias))*)(ybuf + row * RP_YP + 16 * ch);
+        for (int q = tid; q < nrow * YCH; q += 512) {
+            const int row = q / YCH, ch = q % YCH;
+            const u32x4 v = *(const u32x4 __attribute__((may_alias))*)(ybuf + row * YP + 16 * ch);
             int r = 16 * i0 + row;
             r = r < rows ? r : rows - 1;
             __builtin_nontemporal_store(v, (u32x4*)((char*)out + (long)(m0 + r) * ldo * 2 + 16 * ch));
@@ -688,17 +711,17 @@ int rp_rows_per_tile(int M, int cap = RP_TH) {
 }
 template <int MODE> constexpr int rp_cap() { return MODE == REPI_LNBWD_RES ? RP_XROWS : RP_TH; }
 
-template <int MODE, int MF> int launch_rowp_mf(const GemmP& q, int grid, int rpt, hipStream_t st) {
+template <int MODE, int MF, typename T> int launch_rowp_mf(const GemmP& q, int grid, int rpt, hipStream_t st) {
     static PerDeviceOnce attr;
     if (attr.first()) {
-        (void)hipFuncSetAttribute((const void*)gemm_rowp_kernel<MODE, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_rowp_kernel<MODE, MF, T>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
     }
-    MFVIT_LAUNCH((gemm_rowp_kernel<MODE, MF>), dim3(grid), dim3(512), RP_LDS, st, q, rpt, q.N / RP_N);
+    MFVIT_LAUNCH((gemm_rowp_kernel<MODE, MF, T>), dim3(grid), dim3(512), RP_LDS, st, q, rpt, q.N / RP_N);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
 
-template <int MODE> int launch_rowp(const GemmP& p, hipStream_t st) {
+template <int MODE, typename T> int launch_rowp(const GemmP& p, hipStream_t st) {
     const int rpt = rp_rows_per_tile(p.M, rp_cap<MODE>());
     const int grid = (p.M + rpt - 1) / rpt;
     ProfScope ps(MODE == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
@@ -710,13 +733,13 @@ template <int MODE> int launch_rowp(const GemmP& p, hipStream_t st) {
     static int sw_mf = INT_MIN;                                          // MFVIT_ROWP_MF=7: every tile on the 7-fragment kernel (the round-3 behaviour)
     const int mf = env_switch("MFVIT_ROWP_MF", 0, sw_mf) == 7 ? 7 : (rpt + 15) / 16;
     switch (mf) {
-    case 1: return launch_rowp_mf<MODE, 1>(q, grid, rpt, st);
-    case 2: return launch_rowp_mf<MODE, 2>(q, grid, rpt, st);
-    case 3: return launch_rowp_mf<MODE, 3>(q, grid, rpt, st);
-    case 4: return launch_rowp_mf<MODE, 4>(q, grid, rpt, st);
-    case 5: return launch_rowp_mf<MODE, 5>(q, grid, rpt, st);
-    case 6: return launch_rowp_mf<MODE, 6>(q, grid, rpt, st);
-    default: return launch_rowp_mf<MODE, 7>(q, grid, rpt, st);
+    case 1: return launch_rowp_mf<MODE, 1, T>(q, grid, rpt, st);
+    case 2: return launch_rowp_mf<MODE, 2, T>(q, grid, rpt, st);
+    case 3: return launch_rowp_mf<MODE, 3, T>(q, grid, rpt, st);
+    case 4: return launch_rowp_mf<MODE, 4, T>(q, grid, rpt, st);
+    case 5: return launch_rowp_mf<MODE, 5, T>(q, grid, rpt, st);
+    case 6: return launch_rowp_mf<MODE, 6, T>(q, grid, rpt, st);
+    default: return launch_rowp_mf<MODE, 7, T>(q, grid, rpt, st);
     }
 }
 
@@ -732,13 +755,18 @@ int rowp_mode() {
 }  // namespace
 
 bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
-    if (dtype != MFVIT_BF16X3 || rowp_mode() == 0) return false;
+    if ((dtype != MFVIT_BF16X3 && dtype != MFVIT_BF16 && dtype != MFVIT_F16) || rowp_mode() == 0) return false;
+    const bool split = dtype == MFVIT_BF16X3;
+    static int sw_plain = INT_MIN;                                       // MFVIT_ROWP_PLAIN=0: the plain 16-bit types stay on gemm_nt_row (A/B)
+    if (!split && env_switch("MFVIT_ROWP_PLAIN", 1, sw_plain) == 0) return false;
     if (repi != REPI_RES_LN && repi != REPI_LNBWD_RES) return false;
     if (repi == REPI_LNBWD_RES && rowp_mode() < 2) return false;
     static int sw_minm = INT_MIN;                                        // smallest M that takes this kernel (A/B: MFVIT_ROWP_MINM >= 0)
     const int minm_env = env_switch("MFVIT_ROWP_MINM", -1, sw_minm);
     const int minm = minm_env >= 0 ? minm_env : (repi == REPI_RES_LN ? RP_MINM_FWD : RP_MINM_BWD);
-    if (p.N != RP_N || p.K % 64 || p.K < 128 || p.M < minm || p.nb > 1) return false;   // (an even number of stages, at least 4)
+    // an even number of stages (128-byte k groups: 32 logical columns split, 64 plain), at least 4
+    if (p.N != RP_N || p.K % (split ? 64 : 128) || p.K < (split ? 128 : 256) || p.M < minm || p.nb > 1) return false;
+    if (!split && p.res_t) return false;                                 // (the operand-type residual-gradient copy is a split-bf16 path)
     if (p.orow_in || p.res_mod || p.rows_per_wg) return false;                  // patch-embedding row remap stays with gemm_nt_row
     if (repi == REPI_LNBWD_RES) {
         if (!p.aux || !p.mean || !p.rstd || !p.gamma || p.ldaux % 4 || (size_t)p.aux % 16 || (size_t)p.gamma % 16) return false;
@@ -758,10 +786,17 @@ bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
     return true;
 }
 
-int gemm_nt_rowp(int repi, const GemmP& p, hipStream_t st) {
-    if (repi == REPI_RES_LN) return launch_rowp<REPI_RES_LN>(p, st);
+template <int MODE> static int launch_rowp_t(int dtype, const GemmP& p, hipStream_t st) {
+    if (dtype == MFVIT_BF16X3) return launch_rowp<MODE, sbf16>(p, st);
+    if (dtype == MFVIT_BF16) return launch_rowp<MODE, bf16>(p, st);
+    if (dtype == MFVIT_F16) return launch_rowp<MODE, f16>(p, st);
+    return MFVIT_EINVAL;
+}
+
+int gemm_nt_rowp(int dtype, int repi, const GemmP& p, hipStream_t st) {
+    if (repi == REPI_RES_LN) return launch_rowp_t<REPI_RES_LN>(dtype, p, st);
     if (repi == REPI_LNBWD_RES) {
-        const int rc = launch_rowp<REPI_LNBWD_RES>(p, st);
+        const int rc = launch_rowp_t<REPI_LNBWD_RES>(dtype, p, st);
         if (rc != MFVIT_OK || !p.cpart) return rc;
         const int rpt = rp_rows_per_tile(p.M, RP_XROWS);
         return colpart_reduce(p.cpart, (p.M + rpt - 1) / rpt, RP_N, 3, p.cs0, p.cs1, p.cs2, st);   // [tile][3][384] partials -> dgamma, dbeta, dcol

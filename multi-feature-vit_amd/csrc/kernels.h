@@ -10,7 +10,7 @@ enum { REPI_RES_LN = 0, REPI_LNBWD_RES = 1 };
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st);
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st);
 bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p);   // gemm_rowp.hip: one tall row-complete tile per CU (split bf16)
-int gemm_nt_rowp(int repi, const GemmP& p, hipStream_t st);
+int gemm_nt_rowp(int dtype, int repi, const GemmP& p, hipStream_t st);
 int input_transform(const unsigned char* src, const long long* desc, const int* tables, int n, int S, int crop, const float* mean,
                     const float* stdv, float* out, hipStream_t st);   // input.hip
 int eval_counts(const float* scores, long ld, const int64_t* labels, int n, int C, unsigned long long* conf, unsigned long long* u2,

@@ -149,3 +149,43 @@ def test_weight_gradient_with_partial_scratch(M):
                 ref = a.double().T @ b.double()
             out = ops.linear_wgrad(a, b, scratch=scratch, split=kind == "split")
             assert bool(torch.isfinite(out).all()) and rel(out, ref) < 2e-5, (M, name, kind, rel(out, ref))
+
+
+@pytest.mark.parametrize("M,tag", [(128 * 197, "full"), (128 * 197 - 57, "ragged"), (16 * 197, "B16: 1 fragment"), (48 * 197, "B48: 3"), (197, "one row per tile")])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_row_kernels_plain_16_bit_types(monkeypatch, M, tag, dt, mode):
+    """The tall-tile row kernels in the plain 16-bit types (round 4: gemm_rowp instantiated for bf16 / f16 - a 128-byte row is two k steps of one MFMA
+    each instead of one split k group of three) against float64 on the rounded operands, forward (K = 384, 1536) and LayerNorm backward (K = 1152, 1536);
+    mode 0 = gemm_nt_row, the kernel they replace.  Tolerances: the output's own rounding (2^-9 bf16, 2^-12 fp16) for the operand-type tensors, 3e-5 / 2e-4
+    for the f32 outputs and the column sums."""
+    monkeypatch.setenv("MFVIT_ROWP", mode)
+    monkeypatch.setenv("MFVIT_ROWP_MINM", "1")
+    tol_t = 6e-3 if dt == torch.bfloat16 else 8e-4
+    g = _gen(71)
+    for K in (D, F):
+        a, w = rn(g, M, K).to(dt), rn(g, D, K, sc=.05).to(dt)
+        b, res = rn(g, D), rn(g, M, D)
+        gam, bet = torch.rand(D, device=DEV, generator=g) + .5, rn(g, D)
+        x64 = a.double() @ w.double().T + b.double() + res.double()
+        mu = x64.mean(1, keepdim=True)
+        var = ((x64 - mu) ** 2).mean(1, keepdim=True)
+        y64 = (x64 - mu) / torch.sqrt(var + 1e-6) * gam.double() + bet.double()
+        for y_f32 in (False, True):
+            x, y, mean, rstd = ops.linear_res_ln_fwd(a, w, b, res, gam, bet, 1e-6, y_f32=y_f32)
+            errs = dict(x=rel(x, x64), mean=rel(mean, mu.squeeze(1)), rstd=rel(rstd, 1 / torch.sqrt(var + 1e-6).squeeze(1)))
+            assert max(errs.values()) < 3e-5 and rel(y, y64) < (3e-5 if y_f32 else tol_t), (tag, K, mode, y_f32, errs, rel(y, y64))
+    for K in (3 * D, F):
+        dy, wt = rn(g, M, K, sc=.1).to(dt), rn(g, D, K, sc=.05).to(dt)
+        x = rn(g, M, D, sc=1.5) + .3
+        mean = x.mean(1)
+        rstd = 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-6)
+        gam, dres = torch.rand(D, device=DEV, generator=g) + .5, rn(g, M, D, sc=.1)
+        d64 = dy.double() @ wt.double().T
+        h = (x.double() - mean.double()[:, None]) * rstd.double()[:, None]
+        gg = d64 * gam.double()
+        dx64 = rstd.double()[:, None] * (gg - gg.mean(1, keepdim=True) - h * (gg * h).mean(1, keepdim=True)) + dres.double()
+        dx, dxt, dgm, dbt, dcl = ops.linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, gam, dres)
+        errs = dict(dx=rel(dx, dx64), dgamma=rel(dgm, (d64 * h).sum(0)), dbeta=rel(dbt, d64.sum(0)), dcol=rel(dcl, dx64.sum(0)))
+        assert errs["dx"] < 3e-5 and rel(dxt, dx64) < tol_t and max(errs["dgamma"], errs["dbeta"], errs["dcol"]) < 2e-4, (tag, K, mode, errs)
+
