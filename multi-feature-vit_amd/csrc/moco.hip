@@ -27,6 +27,94 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
     mean[c] = mu;
     m2[c] = q;
 }
+// The same with the ROWS spread over the workgroup as well (round 4): 256 threads = 16 row groups x 16 column quads, one workgroup per 64
+// columns - with a thread per column and a serial loop over the rows the two passes were 2 n dependent loads per thread on 16 workgroups
+// (48 us for n = 128, C = 4096; the backward sums 107 us).  Partial sums meet in LDS; still two passes (mean first, then the squared
+// deviations: no cancellation).  Needs C % 4 == 0 (vector loads of four elements).
+template <typename T> struct Quad { T v[4]; };
+template <typename T> __device__ __forceinline__ void load_quad(const T* p, float (&f)[4]) {
+    const Quad<T> q = *(const Quad<T>*)p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = to_f32(q.v[j]);
+}
+__device__ __forceinline__ void quad_reduce(float (&v)[4], float* red, int rg, int cg) {       // sums over the 16 row groups, result in every thread
+    __syncthreads();                                                                           // (red may still be read from a previous reduction)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rg * 64 + 4 * cg + j] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g * 64 + 4 * cg + j];
+        v[j] = t;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_tiled_kernel(const T* __restrict__ x, int n, int C, float* __restrict__ mean, float* __restrict__ m2) {
+    __shared__ float red[16 * 64];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + 4 * cg;
+    const bool ok = c < C;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok)
+        for (int r = rg; r < n; r += 16) {
+            float f[4];
+            load_quad(x + (long)r * C + c, f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += f[j];
+        }
+    quad_reduce(s, red, rg, cg);
+    float mu[4], q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mu[j] = s[j] / (float)n;
+    if (ok)
+        for (int r = rg; r < n; r += 16) {
+            float f[4];
+            load_quad(x + (long)r * C + c, f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = f[j] - mu[j]; q[j] = fmaf(d, d, q[j]); }
+        }
+    quad_reduce(q, red, rg, cg);
+    if (ok && rg == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mean[c + j] = mu[j]; m2[c + j] = q[j]; }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_sums_tiled_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
+                                                                const float* __restrict__ mean, const float* __restrict__ invstd, int relu, int n, int C,
+                                                                float* __restrict__ s1, float* __restrict__ s2) {
+    __shared__ float red[16 * 64];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + 4 * cg;
+    const bool ok = c < C;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        float mu[4], is[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { mu[j] = mean[c + j]; is[j] = invstd[c + j]; }
+        for (int r = rg; r < n; r += 16) {
+            const long i = (long)r * C + c;
+            float g[4], xv[4], yv[4] = {1.f, 1.f, 1.f, 1.f};
+            load_quad(dy + i, g);
+            load_quad(x + i, xv);
+            if (relu) load_quad(y + i, yv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gg = (relu && !(yv[j] > 0.f)) ? 0.f : g[j];
+                a[j] += gg;
+                b[j] = fmaf(gg, (xv[j] - mu[j]) * is[j], b[j]);
+            }
+        }
+    }
+    quad_reduce(a, red, rg, cg);
+    quad_reduce(b, red, rg, cg);
+    if (ok && rg == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[c + j] = a[j]; s2[c + j] = b[j]; }
+    }
+}
 // Chan's parallel combine of W rank-local (mean, M2, count) triples -> global mean, invstd; running-stat update.
 __global__ __launch_bounds__(256) void bn_combine_kernel(const float* __restrict__ means, const float* __restrict__ m2s,
                                                          const float* __restrict__ counts, int W, int C, float eps, float momentum,
@@ -192,6 +280,15 @@ extern "C" {
 int mfvit_bn_stats(int dtype, const void* x, int n, int C, float* mean, float* m2, mfvit_stream_t stream) {
     if (!x || !mean || !m2 || n <= 0 || C <= 0) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0 && (size_t)x % 16 == 0) {                            // rows spread over the workgroup: one workgroup per 64 columns
+        const dim3 grid((C + 63) / 64);
+        if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_stats_tiled_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, n, C, mean, m2);
+        else if (dtype == MFVIT_F16) MFVIT_LAUNCH(bn_stats_tiled_kernel<f16>, grid, dim3(256), 0, st, (const f16*)x, n, C, mean, m2);
+        else if (dtype == MFVIT_F32) MFVIT_LAUNCH(bn_stats_tiled_kernel<float>, grid, dim3(256), 0, st, (const float*)x, n, C, mean, m2);
+        else return MFVIT_EINVAL;
+        MFVIT_CHECK_LAUNCH();
+        return MFVIT_OK;
+    }
     if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_stats_kernel<bf16>, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16*)x, n, C, mean, m2);
     else if (dtype == MFVIT_F16) MFVIT_LAUNCH(bn_stats_kernel<f16>, dim3((C + 255) / 256), dim3(256), 0, st, (const f16*)x, n, C, mean, m2);
     else if (dtype == MFVIT_F32) MFVIT_LAUNCH(bn_stats_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)x, n, C, mean, m2);
@@ -224,6 +321,15 @@ int mfvit_bn_bwd_sums(int dtype, const void* dy, const void* x, const void* y, c
                       int C, float* s1, float* s2, mfvit_stream_t stream) {
     if (!dy || !x || !mean || !invstd || !s1 || !s2 || (relu && !y)) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0 && (size_t)dy % 16 == 0 && (size_t)x % 16 == 0 && (!relu || (size_t)y % 16 == 0)) {
+        const dim3 grid((C + 63) / 64);
+        if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_bwd_sums_tiled_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, relu, n, C, s1, s2);
+        else if (dtype == MFVIT_F16) MFVIT_LAUNCH(bn_bwd_sums_tiled_kernel<f16>, grid, dim3(256), 0, st, (const f16*)dy, (const f16*)x, (const f16*)y, mean, invstd, relu, n, C, s1, s2);
+        else if (dtype == MFVIT_F32) MFVIT_LAUNCH(bn_bwd_sums_tiled_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, relu, n, C, s1, s2);
+        else return MFVIT_EINVAL;
+        MFVIT_CHECK_LAUNCH();
+        return MFVIT_OK;
+    }
     if (dtype == MFVIT_BF16) MFVIT_LAUNCH(bn_bwd_sums_kernel<bf16>, dim3((C + 255) / 256), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, (const bf16*)y, mean, invstd, relu, n, C, s1, s2);
     else if (dtype == MFVIT_F16) MFVIT_LAUNCH(bn_bwd_sums_kernel<f16>, dim3((C + 255) / 256), dim3(256), 0, st, (const f16*)dy, (const f16*)x, (const f16*)y, mean, invstd, relu, n, C, s1, s2);
     else if (dtype == MFVIT_F32) MFVIT_LAUNCH(bn_bwd_sums_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)dy, (const float*)x, (const float*)y, mean, invstd, relu, n, C, s1, s2);
