@@ -6,10 +6,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "multi-feature-vit_amd"))
 import torch
 import bench
-sys.argv = ["bench.py", "--no-extras", "--no-cpu-baseline"]
+sys.argv = ["bench.py", "--no-extras", "--no-cpu-baseline"] + sys.argv[1:]
 args = bench.parse()
 dev = torch.device("cuda:0")
-run = bench.CaRun(args, dev, 0, args.precision, args.mode)
+run = bench.MocoRun(args, dev, 0, args.precision) if args.workload == "moco" else bench.CaRun(args, dev, 0, args.precision, args.mode)
 for _ in range(3):
     run.step()
 torch.cuda.synchronize()
