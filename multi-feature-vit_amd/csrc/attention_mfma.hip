@@ -949,45 +949,6 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Backward, PERSISTENT with a producer wave and NO register prefetch (round 4).
-//
-// The kernel above carries the next pair through the compute phases in 72 registers per thread (254 of 256 in use): nothing is left to
-// request a fragment ahead of its use, so every MFMA group sits behind an LDS read it has just issued, and the score MFMAs, the exp2 / split
-// arithmetic and the gradient MFMAs of a tile run one after the other.  Here the data of the next pair never touches a register:
-//   * waves 0 .. 6 compute (wave = query tile in phase A, key tile in phase B; T = 197: 7 tiles), wave 7 is the PRODUCER (LDS-DMA);
-//   * LDS holds K, V of the current pair (one copy) and TWO buffers of (Q, dO, -lse/scale, -D).  K / V are dead once every wave has taken its
-//     key tile's fragments for phase B, so the producer streams the NEXT pair's K / V into the same images during phase B; the next pair's
-//     Q / dO go into the other buffer during phase A and B (phase A needs them only as the wave's own row fragments), and the producer
-//     computes that pair's D = rowsum(dO o O) and -lse/scale rows straight from global memory meanwhile.  Two barriers per pair.
-//   * both phases are software-pipelined per tile like the forward: the score MFMAs of tile t + 1 (S and dP, accumulators STARTING as
-//     -lse/scale and -D: the row constants live in two register blocks that are the C operand of the first MFMA, no v_mov per element)
-//     are spread over the exp2 / multiply / hi-lo split work of tile t; row fragments of tile t + 2 are requested right behind the MFMAs
-//     that consumed tile t + 1's, transposed fragments a product ahead.
-//   * images are unpadded (LDS-DMA), 16-byte chunks XOR-swizzled by f(row) = bit 1 of the row -> chunk bit 2, bits 2..3 -> chunk bits 0..1:
-//     b128 row reads AND ds_read_b64_tr_b16 transposed reads of the same image are bank-conflict free (the padded images above: transposed
-//     reads 2-way, 3.1 M conflict cycles per launch).
-//   * rows past Tn of an image are never written (LDS-DMA lanes masked) and stay zero; tile reads past an image's 200 rows see finite bytes
-//     of the next image - harmless: padded QUERIES carry -lse/scale = -1e30 (p = 0), padded KEYS multiply zero K rows in phase A (the K image
-//     comes last, a zeroed pad behind it) and end in columns that are not stored in phase B.
-//   * gradients leave as 16-byte stores (v_permlane32_swap pairs the half-waves' 8-byte pieces): half the store instructions.
-template <typename T> struct BwdGeo {
-    static constexpr bool SP = is_split<T>::value;
-    static constexpr int RB = AttnT<T>::RB, CPR = RB / 16, RPP = 64 / CPR, NCW = 7;
-    static __host__ __device__ int timg(int Tn) { return (Tn + RPP - 1) / RPP * RPP; }
-    static __host__ __device__ int tpad(int Tn) { return (Tn + 31) & ~31; }
-    static __host__ __device__ int img(int Tn) { return timg(Tn) * RB; }
-    static __host__ __device__ int pad(int Tn) { return (tpad(Tn) - timg(Tn)) * RB; }               // zeroed rows behind the K image (its last tile runs into them)
-    // image order: [dO_0][Q_0][dO_1][Q_1][V][K][zero pad][row constants] - the last tile of every image runs 24 rows into the NEXT image,
-    // which must hold finite 16-bit values (never the f32 row constants: their low halves read as bf16 can be NaN patterns)
-    static __host__ __device__ int off_qd(int Tn, int b) { return b * 2 * img(Tn); }                  // dO image, then Q image
-    static __host__ __device__ int off_v(int Tn) { return 4 * img(Tn); }
-    static __host__ __device__ int off_k(int Tn) { return 5 * img(Tn); }
-    static __host__ __device__ int off_ld(int Tn, int b) { return 6 * img(Tn) + pad(Tn) + b * 2 * (tpad(Tn) + 32) * 4; }   // -lse/scale rows, then -D rows
-    static __host__ __device__ int lds_bytes(int Tn) { return off_ld(Tn, 2); }
-    static __device__ __forceinline__ int swz(int row) { return SP ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3); }
-};
-
 // X^T[d][col] accumulator tile (col on the lane) -> rows of a [.., HD] tensor of T as 16-byte stores: the half-waves exchange their 8-byte
 // pieces (v_permlane32_swap) so that every lane owns 16 contiguous bytes of its row
 template <typename T> __device__ __forceinline__ void store_tile_T16(typename Vec4<T>::elem* row_ptr, const f32x16& acc, float mul, int lane) {
@@ -1018,377 +979,10 @@ template <typename T> __device__ __forceinline__ void store_tile_T16(typename Ve
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(512) void attn_bwd_pp_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename Vec4<T>::elem* __restrict__ out,
-                                                          const typename Vec4<T>::elem* __restrict__ dout, const float* __restrict__ lse,
-                                                          typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale, int npair) {
-    typedef AttnT<T> A;
-    typedef BwdGeo<T> G;
-    typedef typename A::E E;
-    typedef typename A::frag_t frag_t;
-    constexpr int EP = A::EP, RB = G::RB, CPR = G::CPR, RPP = G::RPP, LO = A::SP ? 1 : 0, NCW = G::NCW;
-    constexpr int NM = A::SP ? 6 : 2;                                  // MFMAs of one 32 x 32 x 32 product
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int nt = (Tn + 31) >> 5;
-    const int Timg = G::timg(Tn), img = G::img(Tn), Tpad = G::tpad(Tn);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long hs = (long)H * HD * EP, rs = 3 * hs, os = hs;
-    const int npl = (npair - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    for (int i = threadIdx.x * 16; i < G::lds_bytes(Tn); i += 512 * 16) *(uint4*)(lds + i) = make_uint4(0, 0, 0, 0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    ATTN_SB();
-    auto pair_bid = [&](int k) __attribute__((always_inline)) { return xcd_remap((int)blockIdx.x + k * (int)gridDim.x, npair); };
-    // one image: rows below Tn only (the others stay zero), piece by piece; `step` / `first`: this wave's share of the pieces
-    auto dma_image = [&](const E* src, long row_stride, int lds_off, int first, int step, bool pace) __attribute__((always_inline)) {
-        for (int pj = first; pj < Timg / RPP; pj += step) {
-            const int row = pj * RPP + lane / CPR, cpos = lane % CPR;
-            if (row < Tn) glds16(src + (long)row * row_stride + 8 * (cpos ^ G::swz(row)), (unsigned)lds_off + (unsigned)pj * 1024u);
-            if (pace) __builtin_amdgcn_s_sleep(1);
-        }
-    };
-    const bool producer = wave == NCW;
-    const bool act = wave < nt;
-    {   // prologue: pair 0 by everybody
-        const int bid = pair_bid(0);
-        const E* base = qkv + (long)(bid / H) * Tn * rs + (bid % H) * HD * EP;
-        const E* dob = dout + (long)(bid / H) * Tn * os + (bid % H) * HD * EP;
-        dma_image(base + hs, rs, G::off_k(Tn), wave, 8, false);
-        dma_image(base + 2 * hs, rs, G::off_v(Tn), wave, 8, false);
-        dma_image(base, rs, G::off_qd(Tn, 0) + img, wave, 8, false);
-        dma_image(dob, os, G::off_qd(Tn, 0), wave, 8, false);
-        wait_vm<0>();
-    }
-    // Row constants of a pair into constant buffer cbuf: -lse / scale and -D = -rowsum(dO o O), by ONE wave (the producer; the prologue: wave 0)
-    // AFTER that pair's dO image has landed: O comes from global memory - all of a lane's rows (up to 4) requested at once, 128 registers -
-    // dO from the (swizzled) LDS image.
-    auto row_consts = [&](int bid_, int qdbuf, int cbuf) __attribute__((always_inline)) {
-        const int bb = bid_ / H, hh = bid_ % H;
-        constexpr int NR = 4, NC = CPR;                                // rows per lane (Tpad + 32 <= 256), 16-byte chunks per row
-        uint4 ob[NR][NC];
-        float lv[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int r = lane + 64 * i;
-            const int rc = r < Tn ? r : Tn - 1;
-            const E* op = out + ((long)bb * Tn + rc) * os + hh * HD * EP;
-#pragma unroll
-            for (int cc = 0; cc < NC; ++cc) ob[i][cc] = *(const uint4*)(op + 8 * cc);
-            lv[i] = lse[((long)bb * H + hh) * Tn + rc];
-        }
-        const char* dimg = lds + G::off_qd(Tn, qdbuf);
-        float* Lp = (float*)(lds + G::off_ld(Tn, cbuf));
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int r = lane + 64 * i;
-            const int rc = r < Tn ? r : Tn - 1;
-            float acc = 0.f;
-#pragma unroll
-            for (int cc = 0; cc < (A::SP ? NC / 2 : NC); ++cc) {      // 8 logical d per chunk (split: hi chunk cc, lo chunk cc + 4)
-                union { uint4 u; frag_t f; } o0, o1, d0, d1;
-                o0.u = ob[i][cc];
-                d0.u = *(const uint4*)(dimg + rc * RB + 16 * (cc ^ G::swz(rc)));
-                if constexpr (A::SP) {
-                    o1.u = ob[i][cc + NC / 2];
-                    d1.u = *(const uint4*)(dimg + rc * RB + 16 * ((cc + NC / 2) ^ G::swz(rc)));
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float ov = (float)o0.f[j], dv_ = (float)d0.f[j];
-                    if constexpr (A::SP) { ov += (float)o1.f[j]; dv_ += (float)d1.f[j]; }
-                    acc = fmaf(ov, dv_, acc);
-                }
-            }
-            if (r < Tpad + 32) {
-                Lp[r] = r < Tn ? -lv[i] / scale : -1e30f;              // padded queries: p = exp2(-1e30 c) = 0
-                Lp[Tpad + 32 + r] = r < Tn ? -acc : 0.f;
-            }
-        }
-    };
-    __builtin_amdgcn_s_barrier();                                      // (pair 0's dO image is complete)
-    ATTN_SB();
-    if (wave == 0) row_consts(pair_bid(0), 0, 0);
-    // per-lane offsets inside an image: row fragments [part][k-step], transposed reads [part][first / second 4-row block]
-    int roff[2][2], toff[2][2];
-    {
-        const int r = lane & 31, hh = lane >> 5;
-#pragma unroll
-        for (int part = 0; part < 2; ++part)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) roff[part][s] = r * RB + 16 * (((A::SP ? 4 * part : 0) + 2 * s + hh) ^ G::swz(r));
-        const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
-#pragma unroll
-        for (int part = 0; part < 2; ++part)
-#pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-                const int row = 4 * hh + q4 + 8 * rd;                  // (the swizzle of row tile * 32 + 16 s + row depends on these bits only)
-                const int cch = (A::SP ? 4 * part : 0) + 2 * g1 + (p4 >> 1);
-                toff[part][rd] = row * RB + 16 * (cch ^ G::swz(row)) + 8 * (p4 & 1);
-            }
-    }
-    const float c = scale * 1.4426950408889634f;
-    auto rd_row = [&](frag_t (&f)[2][2], const char* image, int tile) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int part = 0; part <= LO; ++part) f[part][s] = *(const frag_t*)(image + tile * 32 * RB + roff[part][s]);
-    };
-    auto rd_tr = [&](frag_t (&f)[2], const char* image, int tile, int s) __attribute__((always_inline)) {   // [part], k-step s
-#pragma unroll
-        for (int part = 0; part <= LO; ++part) {
-            union { struct { s16x4 a, b; } s2; frag_t v; } u;
-            const char* p0 = image + (tile * 32 + 16 * s) * RB;
-            u.s2.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + toff[part][0]));
-            u.s2.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + toff[part][1]));
-            f[part] = u.v;
-        }
-    };
-    // MFMA i of a product A (x) B -> acc with A = a[part][k-step], B = (bh, bl)[k-step]; i = 0 takes `init` as C (split: lo*hi, hi*lo, hi*hi per k-step)
-    auto mm = [&](int i, const frag_t (&a)[2][2], const frag_t (&bh)[2], const frag_t (&bl)[2], f32x16& acc, const f32x16& init) __attribute__((always_inline)) {
-        if constexpr (A::SP) {
-            const int s = i / 3, term = i % 3;
-            acc = MmaTraits_mma(term == 0 ? a[1][s] : a[0][s], term == 1 ? bl[s] : bh[s], i == 0 ? init : acc);
-        } else {
-            acc = MmaTraits_mma(a[0][i], bh[i], i == 0 ? init : acc);
-        }
-    };
-    // MFMA i (0 .. NM / 2 - 1) of k-step s of a product whose A fragments are a[part] of THAT k-step
-    auto mt = [&](int i, const frag_t (&a)[2], const frag_t& bh, const frag_t& bl, f32x16& acc) __attribute__((always_inline)) {
-        if constexpr (A::SP) acc = MmaTraits_mma(i == 0 ? a[1] : a[0], i == 1 ? bl : bh, acc);
-        else acc = MmaTraits_mma(a[0], bh, acc);
-    };
-    int rnd_no = -1;
-    (void)rnd_no;
-    for (int kp = 0; kp < npl; ++kp) {
-        const int bid = pair_bid(kp);
-        const int b = bid / H, h = bid % H;
-        const int cb = kp & 1;                                         // this pair's Q / dO / row-constant buffer
-        const char* Vs = lds + G::off_v(Tn);
-        const char* Ks = lds + G::off_k(Tn);
-        const char* dOs = lds + G::off_qd(Tn, cb);
-        const char* Qs = dOs + img;
-        const float* Ls = (const float*)(lds + G::off_ld(Tn, cb));
-        const float* Ds = Ls + Tpad + 32;
-        E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
-        const bool more = kp + 1 < npl;
-        const int bidn = pair_bid(more ? kp + 1 : kp);
-        const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
-        const E* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
-        ++rnd_no;
-        ATTN_STAMP(10);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                  // X: this pair's images and row constants are in place
-        ATTN_SB();
-        ATTN_STAMP(0);
-        if (producer) {
-            if (more) {                                                // next pair's Q and dO into the other buffer
-                dma_image(basen, rs, G::off_qd(Tn, cb ^ 1) + img, 0, 1, true);
-                dma_image(dobn, os, G::off_qd(Tn, cb ^ 1), 0, 1, true);
-            }
-            ATTN_STAMP(1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                              // Z: K / V are dead
-            ATTN_SB();
-            ATTN_STAMP(3);
-            if (more) {                                                // ... its K and V over the dead images
-                dma_image(basen + hs, rs, G::off_k(Tn), 0, 1, true);
-                dma_image(basen + 2 * hs, rs, G::off_v(Tn), 0, 1, true);
-            }
-            wait_vm<0>();                                              // (this wave issued every piece: the next pair's images are complete)
-            if (more) row_consts(bidn, cb ^ 1, cb ^ 1);
-            ATTN_STAMP(4);
-            continue;
-        }
-        frag_t kfB[2][2], vfB[2][2];                                   // this wave's key-tile fragments for phase B
-        if (wave >= 4) __builtin_amdgcn_s_sleep(1);                  // (see the note on lockstep below)
-        if (act) {
-            // ---------------- phase A: dQ of query tile `wave`; S^T[key][q], dP^T[key][q] (query on the lane)
-            frag_t qf[2][2], dof[2][2];
-            rd_row(qf, Qs, wave);
-            rd_row(dof, dOs, wave);
-            const float Lq = Ls[wave * 32 + (lane & 31)], Dq = Ds[wave * 32 + (lane & 31)];
-            auto fill = [&](f32x16& x, float v) __attribute__((always_inline)) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = v;
-            };
-            f32x16 dq;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-            frag_t kfr[2][2], vfr[2][2], ktr[2][2];                    // row fragments of the tile being scored; K^T fragments [k-step][part] of the tile being reduced
-            f32x16 stA, dpA, stB, dpB;
-            rd_row(kfr, Ks, 0);
-            rd_row(vfr, Vs, 0);
-            fill(stA, Lq);
-            fill(dpA, Dq);
-#pragma unroll
-            for (int i = 0; i < NM; ++i) { mm(i, kfr, qf[0], qf[LO], stA, stA); mm(i, vfr, dof[0], dof[LO], dpA, dpA); }
-            ATTN_SB();
-            rd_tr(ktr[0], Ks, 0, 0);
-            rd_tr(ktr[1], Ks, 0, 1);
-            rd_row(kfr, Ks, 1);
-            rd_row(vfr, Vs, 1);
-            ATTN_SB();
-            auto stepA = [&](f32x16& st, f32x16& dp, f32x16& nst, f32x16& ndp, int kt) __attribute__((always_inline)) {
-                frag_t sh[2], sl[2];
-                auto ev = [&](int r0, int r1) __attribute__((always_inline)) {   // dS^T / scale = p (dP - D)
-#pragma unroll
-                    for (int r = r0; r < r1; ++r) st[r] = __builtin_amdgcn_exp2f(st[r] * c) * dp[r];
-                };
-                auto pk = [&](int s) __attribute__((always_inline)) {
-                    pack8<T>(st, s, sh[s], sl[s]);
-                    if constexpr (!A::SP) sl[s] = sh[s];
-                };
-                fill(nst, Lq);
-                fill(ndp, Dq);
-                ATTN_SB();
-                if constexpr (A::SP) {
-                    mm(0, kfr, qf[0], qf[1], nst, nst); ev(0, 3); ATTN_SB();
-                    mm(0, vfr, dof[0], dof[1], ndp, ndp); ev(3, 6); ATTN_SB();
-                    mm(1, kfr, qf[0], qf[1], nst, nst); ev(6, 8); ATTN_SB();
-                    mm(1, vfr, dof[0], dof[1], ndp, ndp); pk(0); ATTN_SB();
-                    mm(2, kfr, qf[0], qf[1], nst, nst); ev(8, 11); ATTN_SB();
-                    mm(2, vfr, dof[0], dof[1], ndp, ndp); ev(11, 14); ATTN_SB();
-                    mm(3, kfr, qf[0], qf[1], nst, nst); ev(14, 16); ATTN_SB();
-                    mm(3, vfr, dof[0], dof[1], ndp, ndp); pk(1); ATTN_SB();
-                    mm(4, kfr, qf[0], qf[1], nst, nst); mm(4, vfr, dof[0], dof[1], ndp, ndp); ATTN_SB();
-                    mm(5, kfr, qf[0], qf[1], nst, nst); mm(5, vfr, dof[0], dof[1], ndp, ndp); ATTN_SB();
-                    rd_row(kfr, Ks, kt + 2 < nt ? kt + 2 : nt - 1);     // (past the end: the last tile again, never used)
-                    rd_row(vfr, Vs, kt + 2 < nt ? kt + 2 : nt - 1);
-                    ATTN_SB();
-                    mt(0, ktr[0], sh[0], sl[0], dq); mt(1, ktr[0], sh[0], sl[0], dq); mt(2, ktr[0], sh[0], sl[0], dq); ATTN_SB();
-                    mt(0, ktr[1], sh[1], sl[1], dq); mt(1, ktr[1], sh[1], sl[1], dq); mt(2, ktr[1], sh[1], sl[1], dq); ATTN_SB();
-                } else {
-                    mm(0, kfr, qf[0], qf[0], nst, nst); ev(0, 8); ATTN_SB();
-                    mm(0, vfr, dof[0], dof[0], ndp, ndp); ev(8, 16); ATTN_SB();
-                    mm(1, kfr, qf[0], qf[0], nst, nst); pk(0); ATTN_SB();
-                    mm(1, vfr, dof[0], dof[0], ndp, ndp); pk(1); ATTN_SB();
-                    rd_row(kfr, Ks, kt + 2 < nt ? kt + 2 : nt - 1);
-                    rd_row(vfr, Vs, kt + 2 < nt ? kt + 2 : nt - 1);
-                    ATTN_SB();
-                    mt(0, ktr[0], sh[0], sl[0], dq); mt(0, ktr[1], sh[1], sl[1], dq); ATTN_SB();
-                }
-                rd_tr(ktr[0], Ks, kt + 1 < nt ? kt + 1 : nt - 1, 0);
-                rd_tr(ktr[1], Ks, kt + 1 < nt ? kt + 1 : nt - 1, 1);
-                ATTN_SB();
-            };
-            for (int kt = 0; kt < nt; kt += 2) {
-                stepA(stA, dpA, stB, dpB, kt);
-                if (kt + 1 < nt) stepA(stB, dpB, stA, dpA, kt + 1);
-            }
-            const int q = wave * 32 + (lane & 31);
-            if (q < Tn) store_tile_T16<T>(dbase + (long)q * rs, dq, scale, lane);
-            rd_row(kfB, Ks, wave);
-            rd_row(vfB, Vs, wave);
-        }
-        ATTN_STAMP(1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's reads of K / V are complete (fragments for phase B included)
-        __builtin_amdgcn_s_barrier();                                  // Z
-        ATTN_SB();
-        ATTN_STAMP(3);
-        if (wave >= 4) __builtin_amdgcn_s_sleep(1);
-        if (act) {
-            // ---------------- phase B: dK, dV of key tile `wave`; S[q][key], dP[q][key] (key on the lane, query in the registers)
-            f32x16 dk, dv;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
-            frag_t qfr[2][2], dofr[2][2], dotr[2], qtr[2];
-            f32x16 smA, dpA, smB, dpB;
-            auto ld_consts = [&](f32x16& sm, f32x16& dp, int qt) __attribute__((always_inline)) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int q0 = qt * 32 + 8 * g + 4 * (lane >> 5);
-                    const float4 L4 = *(const float4*)(Ls + q0);
-                    const float4 D4 = *(const float4*)(Ds + q0);
-                    sm[4 * g] = L4.x, sm[4 * g + 1] = L4.y, sm[4 * g + 2] = L4.z, sm[4 * g + 3] = L4.w;
-                    dp[4 * g] = D4.x, dp[4 * g + 1] = D4.y, dp[4 * g + 2] = D4.z, dp[4 * g + 3] = D4.w;
-                }
-            };
-            rd_row(qfr, Qs, 0);
-            rd_row(dofr, dOs, 0);
-            ld_consts(smA, dpA, 0);
-#pragma unroll
-            for (int i = 0; i < NM; ++i) { mm(i, qfr, kfB[0], kfB[LO], smA, smA); mm(i, dofr, vfB[0], vfB[LO], dpA, dpA); }
-            ATTN_SB();
-            rd_row(qfr, Qs, 1);
-            rd_row(dofr, dOs, 1);
-            ATTN_SB();
-            auto stepB = [&](f32x16& sm, f32x16& dp, f32x16& nsm, f32x16& ndp, int qt) __attribute__((always_inline)) {
-                frag_t ph, pl, sh, sl;                                  // ONE set of packed P / dS fragments, reused by the two k-steps
-                ld_consts(nsm, ndp, qt + 1);                            // (row constants of the next tile: the accumulators start from them)
-                rd_tr(dotr, dOs, qt, 0);
-                rd_tr(qtr, Qs, qt, 0);
-                ATTN_SB();
-                auto ev = [&](int r0, int r1) __attribute__((always_inline)) {
-#pragma unroll
-                    for (int r = r0; r < r1; ++r) {
-                        sm[r] = __builtin_amdgcn_exp2f(sm[r] * c);
-                        dp[r] *= sm[r];
-                    }
-                };
-                auto pkP = [&](int s) __attribute__((always_inline)) {
-                    pack8<T>(sm, s, ph, pl);
-                    if constexpr (!A::SP) pl = ph;
-                };
-                auto pkS = [&](int s) __attribute__((always_inline)) {
-                    pack8<T>(dp, s, sh, sl);
-                    if constexpr (!A::SP) sl = sh;
-                };
-                if constexpr (A::SP) {
-                    ev(0, 4); ATTN_SB();
-                    mm(0, qfr, kfB[0], kfB[1], nsm, nsm); ev(4, 8); ATTN_SB();
-                    mm(0, dofr, vfB[0], vfB[1], ndp, ndp); pkP(0); ATTN_SB();
-                    mm(1, qfr, kfB[0], kfB[1], nsm, nsm); pkS(0); ATTN_SB();
-                    mm(1, dofr, vfB[0], vfB[1], ndp, ndp); ev(8, 11); ATTN_SB();
-                    mm(2, qfr, kfB[0], kfB[1], nsm, nsm); ev(11, 14); ATTN_SB();
-                    mm(2, dofr, vfB[0], vfB[1], ndp, ndp); ev(14, 16); ATTN_SB();
-                    mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
-                    mt(1, dotr, ph, pl, dv); mt(1, qtr, sh, sl, dk); ATTN_SB();
-                    mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB();
-                    rd_tr(dotr, dOs, qt, 1);
-                    rd_tr(qtr, Qs, qt, 1);
-                    ATTN_SB();
-                    mm(3, qfr, kfB[0], kfB[1], nsm, nsm); mm(3, dofr, vfB[0], vfB[1], ndp, ndp); pkP(1); ATTN_SB();
-                    mm(4, qfr, kfB[0], kfB[1], nsm, nsm); mm(4, dofr, vfB[0], vfB[1], ndp, ndp); pkS(1); ATTN_SB();
-                    mm(5, qfr, kfB[0], kfB[1], nsm, nsm); mm(5, dofr, vfB[0], vfB[1], ndp, ndp); ATTN_SB();
-                    rd_row(qfr, Qs, qt + 2 < nt ? qt + 2 : nt - 1);
-                    rd_row(dofr, dOs, qt + 2 < nt ? qt + 2 : nt - 1);
-                    ATTN_SB();
-                    mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
-                    mt(1, dotr, ph, pl, dv); mt(1, qtr, sh, sl, dk); ATTN_SB();
-                    mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB();
-                } else {
-                    ev(0, 8); ATTN_SB();
-                    mm(0, qfr, kfB[0], kfB[0], nsm, nsm); pkP(0); pkS(0); ATTN_SB();
-                    mm(0, dofr, vfB[0], vfB[0], ndp, ndp); ev(8, 16); ATTN_SB();
-                    mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
-                    rd_tr(dotr, dOs, qt, 1);
-                    rd_tr(qtr, Qs, qt, 1);
-                    ATTN_SB();
-                    mm(1, qfr, kfB[0], kfB[0], nsm, nsm); mm(1, dofr, vfB[0], vfB[0], ndp, ndp); pkP(1); pkS(1); ATTN_SB();
-                    rd_row(qfr, Qs, qt + 2 < nt ? qt + 2 : nt - 1);
-                    rd_row(dofr, dOs, qt + 2 < nt ? qt + 2 : nt - 1);
-                    ATTN_SB();
-                    mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
-                }
-            };
-            for (int qt = 0; qt < nt; qt += 2) {
-                stepB(smA, dpA, smB, dpB, qt);
-                if (qt + 1 < nt) stepB(smB, dpB, smA, dpA, qt + 1);
-            }
-            const int k = wave * 32 + (lane & 31);
-            if (k < Tn) {
-                store_tile_T16<T>(dbase + (long)k * rs + hs, dk, scale, lane);
-                store_tile_T16<T>(dbase + (long)k * rs + 2 * hs, dv, 1.0f, lane);
-            }
-        }
-        ATTN_STAMP(4);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Backward, SINGLE PASS (round 4): S, P, dP and dS of a (query tile, key tile) pair are computed ONCE.
 //
-// Both kernels above run two phases per (image, head): wave = query tile (dQ needs S^T, dS^T: keys in the accumulator ROWS, the contraction
+// The two-phase kernel above runs two phases per (image, head): wave = query tile (dQ needs S^T, dS^T: keys in the accumulator ROWS, the contraction
 // index of the MFMA) and wave = key tile (dK, dV need S, dS: queries in the rows).  Every score tile is therefore computed twice - 42 MFMAs and
 // ~380 VALU instructions per tile pair where 30 and ~200 would do, in a kernel whose time is the SUM of its VALU and MFMA time.  Here:
 //   * waves 0 .. 6 own a KEY tile each (K, V fragments of the tile stay in registers for the whole pair) and walk through the query tiles
@@ -1397,15 +991,26 @@ __global__ __launch_bounds__(512) void attn_bwd_pp_kernel(const typename Vec4<T>
 //     into a 4 KB tile of LDS laid out [key][query] in the swizzled image format: read back with ds_read_b64_tr_b16 they are dS^T fragments
 //     with the keys in the contraction index;
 //   * wave 7 (the helper) turns them into dQ: one step behind the others it reads the seven tiles of the step (two buffers, one barrier per
-//     step) and accumulates dQ^T[d][q] = sum over key tiles K_j^T dS_j^T in ONE accumulator - the K^T fragments of all seven key tiles live in
-//     its registers (112 of them) - and stores the finished dQ tile.  No atomics, no second pass.
-//   * the helper is also the producer: K / V images are dead once the fragments are in registers (barrier Z), so the next pair's K / V
-//     stream in during the steps; query tile t of Q / dO is dead behind the barrier of step t - the next pair's rows go straight over it
-//     (one copy of every image: 4 x 25.6 KB + 2 x 28 KB of dS^T tiles + row constants = 161.5 KB).
+//     step) and accumulates dQ^T[d][q] = sum over key tiles K_j^T dS_j^T in two accumulators (even / odd key tiles: no dependent MFMA pairs) -
+//     the K^T fragments of all seven key tiles live in its registers (112 of them) - and stores the finished dQ tile.  No atomics, no second
+//     pass.  It runs with issue priority (s_setprio 3): it is the longest wave of every step and shares its SIMD with key wave 3.
+//   * one copy of every image (4 x 25.6 KB + 2 x 28 KB of dS^T tiles + row constants = 161.5 KB) and NO V image: a key wave needs only its own
+//     key tile of V, as fragments whose 16 bytes per lane are contiguous in a V row - four global loads per lane in front of the last step,
+//     into the registers of the fragments that died a step earlier.  The K image is dead once the fragments are in registers (barrier Z),
+//     query tile t of Q / dO behind the barrier of step t: the next pair's K pieces, its O rows (where V would be; needed for D only) and the
+//     Q / dO rows of tile t - 1 stream in during step t as a WINDOW of 16 LDS-DMA pieces issued by key waves 0 - 2 (the first waves of their
+//     SIMDs reach the step barrier ~1,000 cycles ahead of their partners; an LDS-DMA stalls the wave that issues it).  The last tile's pieces
+//     are issued by the helper behind the last step barrier and waited for behind barrier Z of the next pair.
+//   * images are unpadded (LDS-DMA), 16-byte chunks XOR-swizzled by f(row) = bit 1 of the row -> chunk bit 2, bits 2..3 -> chunk bits 0..1
+//     (SpGeo::swz): b128 row reads AND ds_read_b64_tr_b16 transposed reads of the same image are bank-conflict free.
 //   * row constants (-lse/scale, -D = -rowsum(dO o O)): wave w computes those of query tile w between the two barriers at the head of a
-//     pair, from the dO image and O rows it requested from global memory a pair earlier (17 registers).
+//     pair from the dO and O images (wave nt - 1: behind step 0, its rows arrive last); -lse/scale rows are written by the helper.
+//   * the key waves and the helper run SEPARATE persistent loops (role split at the top): lane-derived offsets are re-derived per pair from
+//     a laundered lane id - a spill reload is a compiler-placed vmcnt(0), i.e. a wait for every LDS-DMA in flight.
+//   * gradients leave as 16-byte stores (v_permlane32_swap pairs the half-waves' 8-byte pieces).
 // Padded keys: the last key tile's K / V fragments (and the helper's K^T elements) are zeroed past Tn in registers; padded queries carry
-// -lse/scale = -1e30 (p = 0); tile reads past an image's rows see finite 16-bit data of the next region.
+// -lse/scale = -1e30 (p = 0); rows past Tn of an image are never written (LDS-DMA lanes masked by v_cmpx inside the asm statement) and stay
+// zero; tile reads past an image's rows see finite 16-bit data of the next region.
 template <typename T> struct SpGeo {
     static constexpr bool SP = is_split<T>::value;
     static constexpr int RB = AttnT<T>::RB, CPR = RB / 16, RPP = 64 / CPR, NCW = 7;
@@ -1798,7 +1403,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             calc_offsets(lane_l);
             calc_dma(lane_l);
             const int hh_c = lane_l >> 5;
-            if (wave >= 4) __builtin_amdgcn_s_sleep(1);                    // (two waves of a SIMD in lockstep behind a barrier cost up to 2 x: see attn_bwd_pp_kernel)
+            if (wave >= 4) __builtin_amdgcn_s_sleep(1);                    // (two waves of a SIMD in lockstep behind a barrier cost up to 2 x)
             f32x16 dk, dv;
     #pragma unroll
             for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.f;
@@ -2021,28 +1626,6 @@ template <typename T> int launch_bwd_t(const void* qkv, const void* out, const v
             {
                 ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
                 MFVIT_LAUNCH((attn_bwd_sp_kernel<T, 7>), dim3(cus3), dim3(512), b3, st, (const E*)qkv, (const E*)out, (const E*)dout, lse, (E*)dqkv, Tn, H,
-                             1.0f / sqrtf((float)HD), B * H);
-                MFVIT_CHECK_LAUNCH();
-            }
-            if (dbias) {
-                const int M = B * Tn, N = 3 * H * HD;
-                MFVIT_LAUNCH((colsum_t_kernel<T>), dim3((M + 63) / 64), dim3(256), 0, st, (const E*)dqkv, (long)N * AttnT<T>::EP, dbias, M, N);
-                MFVIT_CHECK_LAUNCH();
-            }
-            return MFVIT_OK;
-        }
-    }
-    {   // producer-wave kernel without register prefetch: enough pairs to fill every CU twice, 4 - 7 tiles per pair
-        static int sw = INT_MIN;
-        const int cus2 = attn_cus();
-        const int nt = (Tn + 31) >> 5;
-        const int b2 = BwdGeo<T>::lds_bytes(Tn);
-        // OPT-IN (MFVIT_ATTN_BWD_PP=1): measured 160 us against 150 - 155 us of the register-prefetch kernel below at the bench shape
-        if (env_switch("MFVIT_ATTN_BWD_PP", 0, sw) && B * H >= 2 * cus2 && nt >= 4 && nt <= BwdGeo<T>::NCW && b2 <= 160 * 1024) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_pp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            {
-                ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
-                MFVIT_LAUNCH((attn_bwd_pp_kernel<T>), dim3(cus2), dim3(512), b2, st, (const E*)qkv, (const E*)out, (const E*)dout, lse, (E*)dqkv, Tn, H,
                              1.0f / sqrtf((float)HD), B * H);
                 MFVIT_CHECK_LAUNCH();
             }

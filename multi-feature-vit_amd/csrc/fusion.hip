@@ -92,8 +92,11 @@ __global__ __launch_bounds__(64) void x_cls_ln_kernel(const float* __restrict__ 
 }
 
 // Streaming pass over the T rows [own cls ; other stream's patches] of one (sample, direction):
-//   stats, scores against kq_h, softmax over t, u_h = sum_t a_h[t] z_t.   LDS: sc[3][T] | st[2][T] | red[4][18*64]
-__global__ __launch_bounds__(256) void x_stream_fwd_kernel(const float* __restrict__ fc, const float* __restrict__ fe,
+//   stats, scores against kq_h, softmax over t, u_h = sum_t a_h[t] z_t.   LDS: sc[3][T] | st[2][T] | red[XW][18*64]
+// XW waves per workgroup, a wave per row: ONE workgroup per CU (256 (sample, direction) pairs at the bench shape), so the rows in flight per
+// CU are the waves of that workgroup - with four (round 1 - 3) the pass ran at 1.7 TB/s.
+template <int XW>
+__global__ __launch_bounds__(XW * 64) void x_stream_fwd_kernel(const float* __restrict__ fc, const float* __restrict__ fe,
                                                            const float* __restrict__ params, FusLayout L, float eps, float scale, int B,
                                                            int T, const float* __restrict__ kq, float* __restrict__ u,
                                                            float* __restrict__ a_out, float* __restrict__ st_out) {
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void x_stream_fwd_kernel(const float* __restri
 #pragma unroll
         for (int h = 0; h < NH; ++h) kqv[h][i] = kq[(((long)dir * B + b) * NH + h) * D + lane + 64 * i];
     }
-    for (int t = w; t < T; t += 4) {
+    for (int t = w; t < T; t += XW) {
         const float* row = t == 0 ? own : oth + (long)t * D;
         float v[NPL], s = 0.f;
 #pragma unroll
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void x_stream_fwd_kernel(const float* __restri
             sc[w * T + t] = p;
             a_out[(((long)dir * B + b) * NH + w) * T + t] = p;
         }
-    } else {
+    } else if (w == NH) {
         for (int t = lane; t < T; t += 64) {
             st_out[(((long)dir * B + b) * 2) * T + t] = st[t];
             st_out[(((long)dir * B + b) * 2 + 1) * T + t] = st[T + t];
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(256) void x_stream_fwd_kernel(const float* __restri
     for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int i = 0; i < NPL; ++i) acc[h][i] = 0.f;
-    for (int t = w; t < T; t += 4) {
+    for (int t = w; t < T; t += XW) {
         const float* row = t == 0 ? own : oth + (long)t * D;
         const float mu = st[t], rs = st[T + t];
         const float a0 = sc[t], a1 = sc[T + t], a2 = sc[2 * T + t];
@@ -174,8 +177,12 @@ __global__ __launch_bounds__(256) void x_stream_fwd_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < NPL; ++i) red[(w * NH + h) * D + lane + 64 * i] = acc[h][i];
     __syncthreads();
-    for (int q = threadIdx.x; q < NH * D; q += 256)
-        u[((long)dir * B + b) * NH * D + q] = red[q] + red[NH * D + q] + red[2 * NH * D + q] + red[3 * NH * D + q];
+    for (int q = threadIdx.x; q < NH * D; q += XW * 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < XW; ++w2) v += red[w2 * NH * D + q];
+        u[((long)dir * B + b) * NH * D + q] = v;
+    }
 }
 
 // cal = cls + outp ; c = LN_post(cal) ; fus_cls = cls + c ; ds = head(fus_cls) ; fused = ds_cxr + ds_enh ;
@@ -305,8 +312,9 @@ __global__ __launch_bounds__(128) void x_finish_bwd_kernel(const float* __restri
     for (int i = 0; i < NPL; ++i) dqp[((long)dir * B + b) * D + lane + 64 * i] = dq[i];
 }
 
-// Backward of the streaming pass.  LDS: sa[3][T] (a) | sd[3][T] (da -> ds) | st[2][T] | red[4][30*64]
-__global__ __launch_bounds__(256) void x_stream_bwd_kernel(const float* __restrict__ fc, const float* __restrict__ fe,
+// Backward of the streaming pass.  LDS: sa[3][T] (a) | sd[3][T] (da -> ds) | st[2][T] | red[XW][30*64]
+template <int XW>
+__global__ __launch_bounds__(XW * 64) void x_stream_bwd_kernel(const float* __restrict__ fc, const float* __restrict__ fe,
                                                            const float* __restrict__ params, FusLayout L, float scale, int B, int T,
                                                            const float* __restrict__ kq, const float* __restrict__ a_in,
                                                            const float* __restrict__ st_in, const float* __restrict__ du,
@@ -332,10 +340,10 @@ __global__ __launch_bounds__(256) void x_stream_bwd_kernel(const float* __restri
             duv[h][i] = du[(((long)dir * B + b) * NH + h) * D + lane + 64 * i];
         }
     }
-    for (int q = threadIdx.x; q < NH * T; q += 256) sa[q] = a_in[((long)dir * B + b) * NH * T + q];
-    for (int q = threadIdx.x; q < 2 * T; q += 256) st[q] = st_in[((long)dir * B + b) * 2 * T + q];
+    for (int q = threadIdx.x; q < NH * T; q += XW * 64) sa[q] = a_in[((long)dir * B + b) * NH * T + q];
+    for (int q = threadIdx.x; q < 2 * T; q += XW * 64) st[q] = st_in[((long)dir * B + b) * 2 * T + q];
     __syncthreads();
-    for (int t = w; t < T; t += 4) {
+    for (int t = w; t < T; t += XW) {
         const float* row = t == 0 ? own : oth + (long)t * D;
         const float mu = st[t], rs = st[T + t];
         float d0 = 0.f, d1 = 0.f, d2 = 0.f;
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(256) void x_stream_bwd_kernel(const float* __restri
 #pragma unroll
         for (int h = 0; h < NH; ++h) akq[h][i] = 0.f;
     }
-    for (int t = w; t < T; t += 4) {
+    for (int t = w; t < T; t += XW) {
         const float* row = t == 0 ? own : oth + (long)t * D;
         const float mu = st[t], rs = st[T + t];
         const float a0 = sa[t], a1 = sa[T + t], a2 = sa[2 * T + t];
@@ -399,8 +407,10 @@ __global__ __launch_bounds__(256) void x_stream_bwd_kernel(const float* __restri
         red[(w * 5 + 4) * D + lane + 64 * i] = ab[i];
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < 5 * D; q += 256) {
-        const float v = red[q] + red[5 * D + q] + red[10 * D + q] + red[15 * D + q];
+    for (int q = threadIdx.x; q < 5 * D; q += XW * 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < XW; ++w2) v += red[w2 * 5 * D + q];
         if (q < NH * D) dkq[((long)dir * B + b) * NH * D + q] = v;
         else if (q < 4 * D) atomicAdd(dparams + L.ca[dir] + L.n_w + (q - 3 * D), v);
         else atomicAdd(dparams + L.ca[dir] + L.n_b + (q - 4 * D), v);
@@ -438,6 +448,7 @@ __global__ __launch_bounds__(128) void x_row0_bwd_kernel(const float* __restrict
 
 GemmP zg() { GemmP p; memset(&p, 0, sizeof(p)); return p; }
 
+constexpr int XW_FWD = 16, XW_BWD = 8;      // waves per workgroup of the streaming passes (the backward holds ~100 registers per lane)
 #define FUS_TRY(expr) do { int rc__ = (expr); if (rc__ != MFVIT_OK) return rc__; } while (0)
 
 bool fus_ok(const mfvit_fusion_cfg* c) {
@@ -481,11 +492,11 @@ static int xattn_core_forward(int ndir, const FusLayout& L, const FusWs& W, cons
         FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
     }
     {
-        const size_t lds = (size_t)(5 * T + 4 * NH * D) * 4;
+        const size_t lds = (size_t)(5 * T + XW_FWD * NH * D) * 4;
         static PerDeviceOnce attr;
-        if (attr.first()) { (void)hipFuncSetAttribute((const void*)x_stream_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        if (attr.first()) { (void)hipFuncSetAttribute((const void*)x_stream_fwd_kernel<XW_FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         ProfScope ps(PROF_XATTN_FWD, 0, 2.0 * B * T * D * 4 * 2, st);
-        MFVIT_LAUNCH(x_stream_fwd_kernel, dim3(B, ndir), dim3(256), lds, st, f_cxr, f_enh, params, L, eps_pre, scale, B, T,
+        MFVIT_LAUNCH(x_stream_fwd_kernel<XW_FWD>, dim3(B, ndir), dim3(XW_FWD * 64), lds, st, f_cxr, f_enh, params, L, eps_pre, scale, B, T,
                            ws + W.kq, ws + W.u, ws + W.a, ws + W.st);
         MFVIT_CHECK_LAUNCH();
     }
@@ -577,11 +588,11 @@ static int xattn_core_backward(int ndir, const FusLayout& L, const FusWs& W, con
         FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
     }
     {
-        const size_t lds = (size_t)(8 * T + 4 * 5 * D) * 4;
+        const size_t lds = (size_t)(8 * T + XW_BWD * 5 * D) * 4;
         static PerDeviceOnce attr;
-        if (attr.first()) { (void)hipFuncSetAttribute((const void*)x_stream_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+        if (attr.first()) { (void)hipFuncSetAttribute((const void*)x_stream_bwd_kernel<XW_BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         ProfScope ps(PROF_XATTN_BWD, 0, 2.0 * B * T * D * 4 * 3, st);
-        MFVIT_LAUNCH(x_stream_bwd_kernel, dim3(B, ndir), dim3(256), lds, st, f_cxr, f_enh, params, L, scale, B, T, ws + W.kq, ws + W.a,
+        MFVIT_LAUNCH(x_stream_bwd_kernel<XW_BWD>, dim3(B, ndir), dim3(XW_BWD * 64), lds, st, f_cxr, f_enh, params, L, scale, B, T, ws + W.kq, ws + W.a,
                            ws + W.st, ws + W.du, ws + W.dkq, ws + W.dz0p, dparams, df_cxr, df_enh);
         MFVIT_CHECK_LAUNCH();
     }

@@ -1221,6 +1221,7 @@ int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
         if (rc != MFVIT_OK) return rc;
         return colpart_reduce(p.cpart, (p.M + 127) / 128, p.N, 1, p.cs0, nullptr, nullptr, st);
     }
+    if (gemm_nt_small_supported(dtype, epi, p)) return gemm_nt_small(epi, p, st);   // gemm_small.hip: f32, M <= 512
     switch (epi) {
         case EPI_BIAS: return tile_by_dtype<EPI_BIAS>(dtype, p, st);
         case EPI_BIAS_GELU: return tile_by_dtype<EPI_BIAS_GELU>(dtype, p, st);
@@ -1244,6 +1245,7 @@ int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
 }
 int gemm_tn(int dtype, const GemmP& p, hipStream_t st) {
     if (gemm_tn_glds_supported(dtype, p)) return gemm_tn_glds(dtype, p, st);   // gemm_tn2.hip: LDS-DMA ring (16-bit types, large M)
+    if (gemm_tn_small_supported(dtype, p)) return gemm_tn_small(p, st);        // gemm_small.hip: f32, M <= 512
     return tn_by_dtype(dtype, p, st);
 }
 

@@ -16,6 +16,10 @@ int input_transform(const unsigned char* src, const long long* desc, const int* 
 int eval_counts(const float* scores, long ld, const int64_t* labels, int n, int C, unsigned long long* conf, unsigned long long* u2,
                 unsigned long long* npos, int64_t* preds, hipStream_t st);   // metrics.hip
 int gemm_tn(int dtype, const GemmP& p, hipStream_t st);
+bool gemm_nt_small_supported(int dtype, int epi, const GemmP& p);   // gemm_small.hip: f32, a handful of rows (the fusion module's per-sample rows)
+int gemm_nt_small(int epi, GemmP p, hipStream_t st);
+bool gemm_tn_small_supported(int dtype, const GemmP& p);
+int gemm_tn_small(GemmP p, hipStream_t st);
 bool gemm_tn_glds_supported(int dtype, const GemmP& p);   // gemm_tn2.hip
 int gemm_tn_glds(int dtype, GemmP p, hipStream_t st);
 int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float* d1, float* d2, hipStream_t st);

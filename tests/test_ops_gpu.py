@@ -83,6 +83,22 @@ def test_linear_wgrad(dtype, M, N, K):
     assert rel_err(dw3, 2 * ref) < (2e-5 if dtype == torch.float32 else 1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 384, 384), (37, 96, 64), (130, 128, 128), (128, 384, 384), (512, 160, 96)])
+def test_small_f32_gemms(M, N, K):
+    """csrc/gemm_small.hip (f32, M <= 512: one 32 x 32 tile per workgroup, the reduction split over its four waves) at ragged M / N / K
+    against float64: y = x W^T + b and dW += dy^T x (the fusion module's per-sample rows run on it; M = 1 and partial tiles here)."""
+    from mfvit import ops
+    x, w, b = rnd((M, K), torch.float32, 41), rnd((N, K), torch.float32, 42, 0.05), rnd((N,), torch.float32, 43)
+    y = ops.linear_fwd(x.to(dev()), w.to(dev()), b.to(dev()))
+    e = rel_err(y, x.double() @ w.double().t() + b.double())
+    dy = rnd((M, N), torch.float32, 44)
+    pre = rnd((N, K), torch.float32, 45)
+    dw = ops.linear_wgrad(dy.to(dev()), x.to(dev()), out=pre.to(dev()).clone())
+    e2 = rel_err(dw, pre.double() + dy.double().t() @ x.double())
+    log(f"small_f32_gemms[{M},{N},{K}] fwd / wgrad {e2:.2e}", e)
+    assert e < 1e-5 and e2 < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("M,K", [(200, 384), (197 * 2, 1536), (64, 768)])
 def test_linear_res_ln_fwd(dtype, M, K):
@@ -175,6 +191,12 @@ def test_cast_transpose_head_ce():
     assert torch.equal(d.cpu(), src.bfloat16()) and torch.equal(dt.cpu(), src.bfloat16().t().contiguous())
     d, dt = ops.cast_transpose(src.to(dev()), torch.float32, want_straight=False)
     assert d is None and torch.equal(dt.cpu(), src.t().contiguous())
+    # ragged shapes: (100, 36) stays on the four-elements-per-thread kernel (partial 64 x 64 tiles), (37, 50) falls back to the element-wise one
+    for shape in ((100, 36), (37, 50)):
+        s2 = rnd(shape, torch.float32, 29)
+        for dt_ in (torch.bfloat16, torch.float16, torch.float32):
+            d, dt = ops.cast_transpose(s2.to(dev()), dt_)
+            assert torch.equal(d.cpu(), s2.to(dt_)) and torch.equal(dt.cpu(), s2.to(dt_).t().contiguous()), (shape, dt_)
     # classifier head on the cls rows of (B,T,D) tokens, and its backward
     B, T, D, C = 5, 7, 384, 3
     feats, w, b = rnd((B, T, D), torch.float32, 25), rnd((C, D), torch.float32, 26, 0.05), rnd((C,), torch.float32, 27)

@@ -216,16 +216,14 @@ def test_attention_fwd_bwd(mode, B, T, H):
 
 
 @pytest.mark.parametrize("mode", ATT_MODES, ids=[m.name for m in ATT_MODES])
-@pytest.mark.parametrize("bwd", ["two-phase", "producer-wave"])
-def test_attention_persistent_kernels_behind_their_switches(monkeypatch, mode, bwd):
+def test_attention_persistent_kernels_behind_their_switches(monkeypatch, mode):
     """The persistent attention kernels that are NOT the default for a precision (csrc/attention_mfma.hip) against float64 at B * H = 540:
-    the producer-wave forward for the plain 16-bit types (MFVIT_ATTN_FWD_RING=2) and the two two-phase backward kernels - with register
-    prefetch (MFVIT_ATTN_BWD_SP=0) and with a producer wave (+ MFVIT_ATTN_BWD_PP=1); the default backward at this shape is the single-pass
+    the producer-wave forward for the plain 16-bit types (MFVIT_ATTN_FWD_RING=2) and the two-phase backward with register prefetch
+    (MFVIT_ATTN_BWD_SP=0: what other sequence lengths run); the default backward at this shape is the single-pass
     kernel (test_attention_fwd_bwd[45-197-12], test_attention_single_pass_backward_tile_edges)."""
     from mfvit import ops
     monkeypatch.setenv("MFVIT_ATTN_FWD_RING", "2")        # (tests/conftest.py sets MFVIT_AB_LIVE=1: switches are read at every launch)
     monkeypatch.setenv("MFVIT_ATTN_BWD_SP", "0")
-    monkeypatch.setenv("MFVIT_ATTN_BWD_PP", "1" if bwd == "producer-wave" else "0")
     B, T, H, D = 45, 197, 12, 384
     qkv, dout = rnd((B, T, 3 * D), 27), rnd((B, T, D), 28)
     qd = mode.rounded(qkv).requires_grad_(True)
@@ -235,7 +233,7 @@ def test_attention_persistent_kernels_behind_their_switches(monkeypatch, mode, b
     o_ref.backward(mode.rounded(dout))
     dqkv, dbias = ops.attention_bwd(mode.pack(qkv), out, mode.pack(dout), lse, H, split=mode.split)
     e_d, e_b = rel_err(mode.unpack(dqkv), qd.grad), rel_err(dbias, qd.grad.sum((0, 1)))
-    log(f"attention persistent kernels[{mode.name},B={B},{bwd}] out {e_o:.2e} lse {e_l:.2e} dqkv {e_d:.2e} dbias {e_b:.2e}")
+    log(f"attention persistent kernels[{mode.name},B={B}] out {e_o:.2e} lse {e_l:.2e} dqkv {e_d:.2e} dbias {e_b:.2e}")
     t = 2e-4 if mode.split else (4e-3 if mode.name == "fp16" else 2e-2)
     assert e_o < mode.tol and e_l < 1e-5 and e_d < t and e_b < t
 

@@ -1,5 +1,5 @@
-"""Attention backward A/B at the bench shape: the register-prefetch kernel ("0") against the producer-wave kernel ("pp", MFVIT_ATTN_BWD_PP=1)
-and the single-pass kernel ("sp", MFVIT_ATTN_BWD_SP=1, the default), interleaved rounds in ONE process (MFVIT_AB_LIVE=1); dqkv against float64 on the first
+"""Attention backward A/B at the bench shape: the two-phase register-prefetch kernel ("0") against
+the single-pass kernel ("sp", MFVIT_ATTN_BWD_SP=1, the default), interleaved rounds in ONE process (MFVIT_AB_LIVE=1); dqkv against float64 on the first
 images and the last one, the kernels against each other.   AB_KERNELS=0,sp python3 tools/attn_bwd_ab.py [bf16x3 bf16 fp16]"""
 import os, sys
 os.environ["MFVIT_AB_LIVE"] = "1"
@@ -10,11 +10,10 @@ from mfvit import ops
 dev = torch.device("cuda:0")
 B, T, H, D = int(os.environ.get("AB_B", 128)), int(os.environ.get("AB_T", 197)), 12, 384
 precs = sys.argv[1:] or ["bf16x3", "bf16", "fp16"]
-KS = os.environ.get("AB_KERNELS", "0,pp,sp").split(",")
+KS = os.environ.get("AB_KERNELS", "0,sp").split(",")
 
 
 def select(k):
-    os.environ["MFVIT_ATTN_BWD_PP"] = "1" if k == "pp" else "0"
     os.environ["MFVIT_ATTN_BWD_SP"] = "1" if k == "sp" else "0"
 
 
