@@ -34,6 +34,7 @@ struct FusLayout {  // parameter offsets (floats)
     long n_w, n_b, wq, wk, wv, wp, bp;  // inside a CA block
     long ca_stride;
     long total;
+    int no_norm;   // bare CrossAttention (MOD:123-137 without the PreNorm around it): z = x, the norm entries of a block are never touched
 };
 FusLayout fus_layout(int C) {
     FusLayout L;
@@ -46,6 +47,7 @@ FusLayout fus_layout(int C) {
     L.head[0] = oh; L.head[1] = oh + (long)C * D + C;
     L.ca_stride = o2 - o0;
     L.total = oh + 2 * ((long)C * D + C);
+    L.no_norm = 0;
     return L;
 }
 
@@ -81,6 +83,12 @@ __global__ __launch_bounds__(64) void x_cls_ln_kernel(const float* __restrict__ 
     float v[NPL], s = 0.f;
 #pragma unroll
     for (int i = 0; i < NPL; ++i) { v[i] = row[lane + 64 * i]; s += v[i]; }
+    if (L.no_norm) {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) z0[((long)dir * B + b) * D + lane + 64 * i] = v[i];
+        if (lane == 0) { st0[((long)dir * B + b) * 2] = 0.f; st0[((long)dir * B + b) * 2 + 1] = 1.f; }
+        return;
+    }
     const float mu = wave_sum(s) * (1.f / D);
     float q = 0.f;
 #pragma unroll
@@ -110,8 +118,8 @@ __global__ __launch_bounds__(XW * 64) void x_stream_fwd_kernel(const float* __re
     float g[NPL], be[NPL], kqv[NH][NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        g[i] = params[L.ca[dir] + L.n_w + lane + 64 * i];
-        be[i] = params[L.ca[dir] + L.n_b + lane + 64 * i];
+        g[i] = L.no_norm ? 1.f : params[L.ca[dir] + L.n_w + lane + 64 * i];
+        be[i] = L.no_norm ? 0.f : params[L.ca[dir] + L.n_b + lane + 64 * i];
 #pragma unroll
         for (int h = 0; h < NH; ++h) kqv[h][i] = kq[(((long)dir * B + b) * NH + h) * D + lane + 64 * i];
     }
@@ -120,11 +128,11 @@ __global__ __launch_bounds__(XW * 64) void x_stream_fwd_kernel(const float* __re
         float v[NPL], s = 0.f;
 #pragma unroll
         for (int i = 0; i < NPL; ++i) { v[i] = row[lane + 64 * i]; s += v[i]; }
-        const float mu = wave_sum(s) * (1.f / D);
+        const float mu = L.no_norm ? 0.f : wave_sum(s) * (1.f / D);
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NPL; ++i) { v[i] -= mu; q += v[i] * v[i]; }
-        const float rs = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+        const float rs = L.no_norm ? 1.f : rsqrtf(wave_sum(q) * (1.f / D) + eps);
         float d0 = 0.f, d1 = 0.f, d2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
@@ -332,8 +340,8 @@ __global__ __launch_bounds__(XW * 64) void x_stream_bwd_kernel(const float* __re
     float g[NPL], be[NPL], kqv[NH][NPL], duv[NH][NPL];
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
-        g[i] = params[L.ca[dir] + L.n_w + lane + 64 * i];
-        be[i] = params[L.ca[dir] + L.n_b + lane + 64 * i];
+        g[i] = L.no_norm ? 1.f : params[L.ca[dir] + L.n_w + lane + 64 * i];
+        be[i] = L.no_norm ? 0.f : params[L.ca[dir] + L.n_b + lane + 64 * i];
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             kqv[h][i] = kq[(((long)dir * B + b) * NH + h) * D + lane + 64 * i];
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(XW * 64) void x_stream_bwd_kernel(const float* __re
 #pragma unroll
             for (int i = 0; i < NPL; ++i) { ag[i] = fmaf(dz[i], xh[i], ag[i]); ab[i] += dz[i]; }
             if (doth) {
-                const float c1 = wave_sum(p1) * (1.f / D), c2 = wave_sum(p2) * (1.f / D);
+                const float c1 = L.no_norm ? 0.f : wave_sum(p1) * (1.f / D), c2 = L.no_norm ? 0.f : wave_sum(p2) * (1.f / D);
 #pragma unroll
                 for (int i = 0; i < NPL; ++i) doth[((long)b * T + t) * D + lane + 64 * i] = rs * (dz[i] * g[i] - c1 - xh[i] * c2);
             }
@@ -412,6 +420,7 @@ __global__ __launch_bounds__(XW * 64) void x_stream_bwd_kernel(const float* __re
 #pragma unroll
         for (int w2 = 0; w2 < XW; ++w2) v += red[w2 * 5 * D + q];
         if (q < NH * D) dkq[((long)dir * B + b) * NH * D + q] = v;
+        else if (L.no_norm) continue;
         else if (q < 4 * D) atomicAdd(dparams + L.ca[dir] + L.n_w + (q - 3 * D), v);
         else atomicAdd(dparams + L.ca[dir] + L.n_b + (q - 4 * D), v);
     }
@@ -434,12 +443,18 @@ __global__ __launch_bounds__(128) void x_row0_bwd_kernel(const float* __restrict
         const long o = ((long)dir * B + b) * D + lane + 64 * i;
         dz[i] = dz0p[o] + dz0q[o];
         xh[i] = (cls[lane + 64 * i] - mu) * rs;
+        if (L.no_norm) continue;
         const float t = dz[i] * g[lane + 64 * i];
         s1 += t; s2 += t * xh[i];
         atomicAdd(dparams + L.ca[dir] + L.n_w + lane + 64 * i, dz[i] * xh[i]);
         atomicAdd(dparams + L.ca[dir] + L.n_b + lane + 64 * i, dz[i]);
     }
     if (!down) return;
+    if (L.no_norm) {   // (st0 = (0, 1): xh = x; no normalisation to differentiate)
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) down[(long)b * T * D + lane + 64 * i] = dqp[((long)dir * B + b) * D + lane + 64 * i] + dz[i];
+        return;
+    }
     const float c1 = wave_sum(s1) * (1.f / D), c2 = wave_sum(s2) * (1.f / D);
 #pragma unroll
     for (int i = 0; i < NPL; ++i)
@@ -638,13 +653,20 @@ __global__ void x_copy_out_kernel(const float* __restrict__ src, float* __restri
 
 extern "C" {
 
-int mfvit_prenorm_xattn_forward(const mfvit_fusion_cfg* cfg, const float* params, const float* x_own, const float* x_oth,
-                                void* workspace, float* out, mfvit_stream_t stream) {
+// layout of ONE cross-attention block as the parameter arena: norm.{w,b}, wq, wk, wv, proj.{w,b}; bare: the block starts at wq
+// (L.ca[0] = -2 D puts wq at offset 0; the norm offsets are never dereferenced under no_norm)
+static FusLayout one_block_layout(const mfvit_fusion_cfg* cfg, bool bare) {
+    FusLayout L = fus_layout(cfg->num_classes);
+    L.ca[0] = bare ? -2L * D : 0;
+    L.no_norm = bare ? 1 : 0;
+    return L;
+}
+static int xattn_one_forward(const mfvit_fusion_cfg* cfg, bool bare, const float* params, const float* x_own, const float* x_oth,
+                             void* workspace, float* out, mfvit_stream_t stream) {
     if (!fus_ok(cfg) || !params || !x_own || !x_oth || !workspace || !out) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int B = cfg->batch, T = cfg->tokens;
-    FusLayout L = fus_layout(cfg->num_classes);
-    L.ca[0] = 0;                                   // params = one CA block: norm.{w,b}, wq, wk, wv, proj.{w,b}
+    const FusLayout L = one_block_layout(cfg, bare);
     const FusWs W = fus_ws(B, T);
     float* ws = (float*)workspace;
     FUS_TRY(xattn_core_forward(1, L, W, params, x_own, x_oth, ws, B, T, cfg->eps_pre, st));
@@ -653,23 +675,38 @@ int mfvit_prenorm_xattn_forward(const mfvit_fusion_cfg* cfg, const float* params
     return MFVIT_OK;
 }
 
-int mfvit_prenorm_xattn_backward(const mfvit_fusion_cfg* cfg, const float* params, const float* x_own, const float* x_oth,
-                                 void* workspace, const float* dout, float* dparams, float* dx_own, float* dx_oth,
-                                 mfvit_stream_t stream) {
+static int xattn_one_backward(const mfvit_fusion_cfg* cfg, bool bare, const float* params, const float* x_own, const float* x_oth,
+                              void* workspace, const float* dout, float* dparams, float* dx_own, float* dx_oth, mfvit_stream_t stream) {
     if (!fus_ok(cfg) || !params || !x_own || !x_oth || !workspace || !dout || !dparams) return MFVIT_EINVAL;
     if ((dx_own == nullptr) != (dx_oth == nullptr)) return MFVIT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int B = cfg->batch, T = cfg->tokens;
-    FusLayout L = fus_layout(cfg->num_classes);
-    L.ca[0] = 0;
+    const FusLayout L = one_block_layout(cfg, bare);
     const FusWs W = fus_ws(B, T);
     float* ws = (float*)workspace;
     MFVIT_LAUNCH(x_copy_out_kernel, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, st, dout, ws + W.dout, (long)B * D);
     MFVIT_CHECK_LAUNCH();
     if (hipMemsetAsync(ws + W.dqp, 0, sizeof(float) * B * D, st) != hipSuccess) return MFVIT_ELAUNCH;
     // d proj.bias = column sums of dout (x_finish_bwd does this in the fused model)
-    FUS_TRY(colsum_rows(dout, D, dparams + L.bp, B, 1, 0, D, st));
+    FUS_TRY(colsum_rows(dout, D, dparams + L.ca[0] + L.bp, B, 1, 0, D, st));
     return xattn_core_backward(1, L, W, params, x_own, x_oth, ws, B, T, dparams, dx_own, dx_oth, st);
+}
+
+int mfvit_prenorm_xattn_forward(const mfvit_fusion_cfg* cfg, const float* params, const float* x_own, const float* x_oth,
+                                void* workspace, float* out, mfvit_stream_t stream) {
+    return xattn_one_forward(cfg, false, params, x_own, x_oth, workspace, out, stream);
+}
+int mfvit_prenorm_xattn_backward(const mfvit_fusion_cfg* cfg, const float* params, const float* x_own, const float* x_oth,
+                                 void* workspace, const float* dout, float* dparams, float* dx_own, float* dx_oth,
+                                 mfvit_stream_t stream) {
+    return xattn_one_backward(cfg, false, params, x_own, x_oth, workspace, dout, dparams, dx_own, dx_oth, stream);
+}
+int mfvit_xattn_forward(const mfvit_fusion_cfg* cfg, const float* params, const float* x, void* workspace, float* out, mfvit_stream_t stream) {
+    return xattn_one_forward(cfg, true, params, x, x, workspace, out, stream);
+}
+int mfvit_xattn_backward(const mfvit_fusion_cfg* cfg, const float* params, const float* x, void* workspace, const float* dout,
+                         float* dparams, float* dx, mfvit_stream_t stream) {
+    return xattn_one_backward(cfg, true, params, x, x, workspace, dout, dparams, dx, dx, stream);
 }
 
 }  // extern "C"

@@ -86,6 +86,8 @@ SIGNATURES = {
     "mfvit_amp_unscale": (I, [P, I, F, P, P]),
     "mfvit_prenorm_xattn_forward": (I, [POINTER(FusionCfg), P, P, P, P, P, P]),
     "mfvit_prenorm_xattn_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P]),
+    "mfvit_xattn_forward": (I, [POINTER(FusionCfg), P, P, P, P, P]),
+    "mfvit_xattn_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P]),
     "mfvit_input_transform": (I, [P, P, P, I, I, I, P, P, P, P]),
     "mfvit_eval_counts": (I, [P, L, P, I, I, P, P, P, P, P]),
     "mfvit_prof_enable": (I, [I]),

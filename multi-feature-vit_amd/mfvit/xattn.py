@@ -1,5 +1,6 @@
 """Stand-alone entry points of the exchange modules on the HIP path:
   PreNorm(dim, CrossAttention(dim, num_heads=3))(x)                 (MOD:15-21,108-137)
+  CrossAttention(dim, num_heads=3)(x)                               (MOD:123-137; never called bare by the reference)
   MultiScaleTransformerEncoder(...)(xs, xl) -> (xs_out, xl_out)     (FUS:35-65)
 Same kernels as the fused Fus_CrossViT pipeline (csrc/fusion.hip), run for one direction at a time; the post-exchange
 LayerNorm over all token rows (dead inside Fus_CrossViT) is the row LayerNorm kernel."""
@@ -60,6 +61,49 @@ def prenorm_cross_attention(prenorm, x, x_other=None):
     """PreNorm(CrossAttention)(x): query = row 0 of x, keys / values = all rows of [x[:, :1] ; (x_other or x)[:, 1:]] -> (B, 1, C)."""
     a = _arena_of(prenorm)
     return _PreNormXAttnFn.apply(a, x, x if x_other is None else x_other, *a.params)
+
+
+class _XAttnFn(torch.autograd.Function):
+    """Bare CrossAttention(x) (MOD:123-137): the same folded kernels with the normalisation switched off."""
+
+    @staticmethod
+    def forward(ctx, arena, x, *params):
+        _lib.require_cuda(x)
+        x = x.contiguous().float()
+        B, T, D = x.shape
+        if D != 384:
+            raise _lib.MfvitError("CrossAttention is built for (B, T, 384) inputs, 3 heads")
+        flat = arena.ensure()
+        cfg = fusion_cfg(B, T, 3)
+        ws = torch.empty(lib().mfvit_fusion_workspace_bytes(cfg), device=x.device, dtype=torch.uint8)
+        out = torch.empty(B, 1, D, device=x.device, dtype=torch.float32)
+        check(lib().mfvit_xattn_forward(cfg, ptr(flat), ptr(x), ptr(ws), ptr(out), stream()), "mfvit_xattn_forward")
+        ctx.arena, ctx.cfg, ctx.ws = arena, cfg, ws
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, = ctx.saved_tensors
+        arena = ctx.arena
+        flat = arena.ensure()
+        gflat = torch.zeros_like(flat)
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[1] else None
+        check(lib().mfvit_xattn_backward(ctx.cfg, ptr(flat), ptr(x), ptr(ctx.ws), ptr(dout.contiguous().float()), ptr(gflat), ptr(dx), stream()),
+              "mfvit_xattn_backward")
+        ctx.ws = None
+        return (None, dx) + tuple(arena.grad_views(gflat))
+
+
+def cross_attention(ca, x):
+    """CrossAttention(dim, num_heads=3)(x) without a PreNorm around it -> (B, 1, C)."""
+    a = getattr(ca, "_mfvit_arena", None)
+    if a is None or not a.intact():
+        if ca.num_heads != 3 or ca.wq.weight.shape != (384, 384):
+            raise _lib.MfvitError("the fused cross-attention is built for dim 384 / 3 heads (FUS:73-75 defaults)")
+        a = ParamArena(list(ca.named_parameters()))                # wq.weight, wk.weight, wv.weight, proj.weight, proj.bias
+        object.__setattr__(ca, "_mfvit_arena", a)
+    return _XAttnFn.apply(a, x, *a.params)
 
 
 class _LNFn(torch.autograd.Function):

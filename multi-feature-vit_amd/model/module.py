@@ -69,5 +69,7 @@ class CrossAttention(nn.Module):
         self.proj_drop = nn.Dropout(0.)
 
     def forward(self, x):
-        raise NotImplementedError("CrossAttention runs fused with its PreNorm (the reference never calls it bare, FUS:25,30); "
-                                  "call PreNorm(dim, CrossAttention(...))(x), MultiScaleTransformerEncoder or Fus_CrossViT")
+        """MOD:123-137: (B, N, C) -> (B, 1, C).  The reference never calls the module without its PreNorm (FUS:25,30); when it is,
+        the same folded kernels run with the normalisation switched off."""
+        from mfvit.xattn import cross_attention
+        return cross_attention(self, x)

@@ -103,6 +103,28 @@ def golden_cross_attention():
     print("fusion_cross_attention.npz", y.abs().mean().item())
 
 
+def golden_cross_attention_bare():
+    """The reference's CrossAttention called WITHOUT its PreNorm (MOD:123-137; its live path never does that, FUS:25,30)."""
+    from model.module import CrossAttention
+    torch.manual_seed(0)
+    B, T, D = 3, 197, 384
+    fp = ref_fusion.seeded_fusion_params(111, dtype=torch.float64)
+    mod = CrossAttention(D, num_heads=3).double()
+    L = ref_fusion._L
+    mod.load_state_dict({k: fp[L + "2.fn." + k] for k in ("wq.weight", "wk.weight", "wv.weight", "proj.weight", "proj.bias")}, strict=True)
+    x = rng_tensor(112, (B, T, D), dtype=torch.float64).requires_grad_(True)
+    r = rng_tensor(113, (B, 1, D), dtype=torch.float64)
+    y = mod(x)
+    (y * r).sum().backward()
+    d = dict(seed_params=111, seed_x=112, seed_r=113)
+    put(d, "y", y, full=True)
+    put(d, "dx", x.grad)
+    for n, p in mod.named_parameters():
+        put(d, "d." + n, p.grad)
+    np.savez_compressed(os.path.join(OUT, "fusion_cross_attention_bare.npz"), **d)
+    print("fusion_cross_attention_bare.npz", y.abs().mean().item())
+
+
 class OracleBackbone:
     """Stands in for the absent vits_returnftrs model (oracle restatement; parity unpinned)."""
 
@@ -473,6 +495,7 @@ if __name__ == "__main__":
             globals()[name]()
         sys.exit(0)
     golden_cross_attention()
+    golden_cross_attention_bare()
     golden_fusion()
     golden_moco()
     golden_moco_v3()

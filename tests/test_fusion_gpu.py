@@ -179,6 +179,29 @@ def test_standalone_prenorm_cross_attention_against_reference_golden():
     assert e_y < 1e-3
 
 
+def test_bare_cross_attention_against_reference_golden():
+    """CrossAttention(384, num_heads=3)(x) WITHOUT a PreNorm (MOD:123-137; mfvit_xattn_forward / _backward: the folded kernels with the
+    normalisation switched off), forward and every gradient, vs the reference's own module (fusion_cross_attention_bare.npz)."""
+    mod = importlib.import_module("model.module")
+    g = np.load(os.path.join(GOLDEN, "fusion_cross_attention_bare.npz"), allow_pickle=False)
+    dev = torch.device("cuda:0")
+    fp = ref_fusion.seeded_fusion_params(int(g["seed_params"]))
+    L = ref_fusion._L
+    m = mod.CrossAttention(384, num_heads=3)
+    m.load_state_dict({k: fp[L + "2.fn." + k] for k in ("wq.weight", "wk.weight", "wv.weight", "proj.weight", "proj.bias")}, strict=True)
+    m = m.to(dev)
+    x = rng_tensor(int(g["seed_x"]), (3, 197, 384)).to(dev).requires_grad_(True)
+    r = rng_tensor(int(g["seed_r"]), (3, 1, 384)).to(dev)
+    y = m(x)
+    (y * r).sum().backward()
+    e_y = scale_err(y, torch.from_numpy(g["y"]))
+    check_sampled(g, "dx", x.grad, rtol=2e-3, atol=2e-3 * float(g["dx.abssum"]) / x.numel())
+    for name, p in m.named_parameters():
+        check_sampled(g, "d." + name, p.grad, rtol=2e-3, atol=2e-3 * float(g[f"d.{name}.abssum"]) / p.numel())
+    log(f"bare CrossAttention vs reference golden: fwd {e_y:.3e}")
+    assert e_y < 1e-3
+
+
 def test_standalone_exchange_against_reference_golden():
     """MultiScaleTransformerEncoder()(xs, xl) full (B,197,384) outputs vs the reference's own module (fusion_exchange.npz), and
     its gradients vs the oracle."""
