@@ -473,6 +473,48 @@ def test_two_stream_384_ca_step(precision, tol):
         assert preds.cpu().tolist() == r_preds.tolist()
 
 
+def test_two_stream_384_forward_at_the_configs_own_batch():
+    """BASELINE configs[4] at its per-GPU size: depth 12, 32 pairs of 384 x 384 inputs (577 tokens per stream), fp16 - the need-grad forward
+    of the train step (the kernels bench.py times for `--img 384 --precision fp16 --batch 32`: streaming attention at B * H = 384 pairs,
+    row kernels at M = 18,464) against the CPU oracle on the same weights and inputs; the backward at this shape is covered through the
+    sample-independence property (gradient of the batch = sum over its halves) with the oracle-compared B = 2 test above."""
+    import vits_returnftrs as vits
+    from mfvit.losses import cross_entropy
+    fus = importlib.import_module(FUS_MOD)
+    depth, B, img = 12, 32, 384
+    vit_p = [ref_vit.seeded_params(27 + i, num_classes=3, depth=depth, img_size=img) for i in range(2)]
+    fus_p = ref_fusion.seeded_fusion_params(29)
+    backs = []
+    for p in vit_p:
+        m = vits.vit_small(num_classes=3, depth=depth, precision="fp16", img_size=img)
+        m.load_state_dict(p)
+        backs.append(m.to("cuda:0"))
+    model = fus.Fus_CrossViT(backs[0], backs[1])
+    model.load_state_dict(fus_p)
+    model = model.to("cuda:0")
+    x, xe = rng_tensor(93, (B, 3, img, img)), rng_tensor(94, (B, 3, img, img))
+    y = torch.arange(B) % 3
+
+    def grads(lo, hi):
+        for m in backs:
+            for p_ in m.parameters():
+                p_.grad = None
+        fused, x_c, x_e = model(backs[0], backs[1], x[lo:hi].to("cuda:0"), xe[lo:hi].to("cuda:0"))
+        out = fused + x_c + x_e
+        loss, _ = cross_entropy(out, y[lo:hi].to("cuda:0"))
+        (loss * (hi - lo)).backward()                                   # sum over the samples: additive over sub-batches
+        return out.detach(), [backs[i].blocks[j].attn.qkv.weight.grad.clone() for i in (0, 1) for j in (0, 11)]
+    out, g_all = grads(0, B)
+    with torch.no_grad():
+        r_out, r_preds, r_loss, _ = ref_fusion.ca_step(fus_p, vit_p[0], vit_p[1], x, xe, y)
+    e_out = rel_err(out, r_out)
+    _, g_a = grads(0, B // 2)
+    _, g_b = grads(B // 2, B)
+    e_add = max(rel_err(ga + gb, g) for ga, gb, g in zip(g_a, g_b, g_all))
+    log(f"two-stream 384^2 forward [fp16, depth 12, B = {B}]: logits {e_out:.2e}; grad(batch) vs grad(half) + grad(half) {e_add:.2e}")
+    assert e_out < 2e-2 and e_add < 2e-2
+
+
 @pytest.mark.parametrize("mode", ATT_MODES, ids=[m.name for m in ATT_MODES])
 @pytest.mark.parametrize("B,T", [(2, 197), (3, 50), (1, 256), (2, 33)])
 def test_fused_mhsa_forward(mode, B, T):
