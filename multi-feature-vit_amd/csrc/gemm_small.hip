@@ -66,13 +66,29 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(GemmP p) {
             acc = mma_f32(aok ? a[s].w : 0.f, wok ? w[s].w : 0.f, acc);
         }
     } else {
-        for (int k = 0; k < kc; k += 8) {
-            const float4 a = *(const float4*)(ap + k), w = *(const float4*)(wp + k);
+        // any K: chunks of four 8-wide steps, the next chunk's eight loads in flight under the sixteen MFMAs of this one
+        auto mma4 = [&](const float4& a, const float4& w) __attribute__((always_inline)) {
             acc = mma_f32(aok ? a.x : 0.f, wok ? w.x : 0.f, acc);
             acc = mma_f32(aok ? a.y : 0.f, wok ? w.y : 0.f, acc);
             acc = mma_f32(aok ? a.z : 0.f, wok ? w.z : 0.f, acc);
             acc = mma_f32(aok ? a.w : 0.f, wok ? w.w : 0.f, acc);
+        };
+        const int nch = kc >> 5;                                        // whole chunks of 32 k
+        float4 a[4], w[4], an[4], wn[4];
+        if (nch > 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { a[s] = *(const float4*)(ap + 8 * s); w[s] = *(const float4*)(wp + 8 * s); }
         }
+        for (int c = 0; c < nch; ++c) {
+            const int kn = (c + 1 < nch ? c + 1 : c) * 32;              // (last chunk: a harmless reload of itself)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { an[s] = *(const float4*)(ap + kn + 8 * s); wn[s] = *(const float4*)(wp + kn + 8 * s); }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) mma4(a[s], w[s]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { a[s] = an[s]; w[s] = wn[s]; }
+        }
+        for (int k = nch * 32; k < kc; k += 8) mma4(*(const float4*)(ap + k), *(const float4*)(wp + k));
     }
     reduce_waves(acc, red, wave, lane);
     if (wave) return;
