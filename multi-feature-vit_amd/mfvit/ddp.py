@@ -10,15 +10,24 @@ algorithms while leaving 11 blocks of compute to hide each one behind.
 the gradient arena), the bucket is all-reduced, and the result is written back over the f32 slice when the group is joined.
 Joins are per owner: ``finish(vit)`` waits for one encoder's groups only, so the optimizer can start on the arenas whose exchange
 is complete (``optimizer.before_group``) while the rest is still on the links.
+
+``exchange='rs_ag'`` (``MFVIT_GRAD_EXCHANGE=rs_ag``) issues every bucket as reduce-scatter + all-gather instead of one
+all-reduce: each rank reduces 1/W of the bucket and the shards are gathered back - on 8 fully connected xGMI peers both phases use
+all seven links at once where a ring is bound by one.  Combine with ``MFVIT_GRAD_BUCKET_LAYERS=1`` for the per-block buckets of the
+survey.  The all-reduce stays the default until a measured scaling curve says otherwise (RCCL picks its own algorithm for it).
 """
 import torch
 import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, group=None, bucket_dtype=None):
+    def __init__(self, group=None, bucket_dtype=None, exchange=None):
         import os
         self.group = group
+        self.exchange = exchange or os.environ.get("MFVIT_GRAD_EXCHANGE", "allreduce")
+        if self.exchange not in ("allreduce", "rs_ag"):
+            raise ValueError(f"unknown gradient exchange {self.exchange!r} (allreduce | rs_ag)")
+        self._shards = {}                  # (data_ptr, numel, dtype) -> this rank's persistent shard buffer
         self.handles = []                  # (owner key, work handle, write-back or None)
         if bucket_dtype is None and os.environ.get("MFVIT_GRAD_BUCKET_DTYPE", "f32") in ("bf16", "bfloat16"):
             bucket_dtype = torch.bfloat16
@@ -42,6 +51,34 @@ class GradSync:
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
         t.div_(self.world)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def _reduce_async(self, t):
+        """Asynchronous mean over ranks of the flat tensor `t`, in place: the work handles to join (in order)."""
+        if self.exchange != "rs_ag" or t.numel() < self.world:
+            return [self._all_reduce(t, True)]
+        w = self.world
+        rank = dist.get_rank(self.group)
+        n0 = (t.numel() // w) * w
+        main, sh = t[:n0], n0 // w
+        key = (t.data_ptr(), n0, t.dtype)
+        mine = self._shards.get(key)
+        if mine is None:
+            if len(self._shards) > 256:    # (gradient arenas are reused step after step: the keys repeat; a caller that is not is bounded here)
+                self._shards.clear()
+            mine = self._shards[key] = torch.empty(sh, dtype=t.dtype, device=t.device)
+        hs = []
+        if not self.avg:
+            t.div_(w)
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        h1 = dist.reduce_scatter_tensor(mine, main, op=op, group=self.group, async_op=True)
+        if not self.avg:
+            h1.wait()                      # gloo (tests, rehearsals) runs asynchronous work on a thread pool: no issue order to rely on
+        else:
+            hs.append(h1)                  # RCCL: both collectives are queued on the communicator's stream, in order
+        hs.append(dist.all_gather_into_tensor(main, mine, group=self.group, async_op=True))
+        if n0 < t.numel():                 # the < W elements that do not divide over the ranks
+            hs.append(dist.all_reduce(t[n0:], op=op, group=self.group, async_op=True))
+        return hs
 
     # ---- encoder: called from VisionTransformerMoCo._run_backward after every stage
     def attach(self, vit, bucket_layers=None):
@@ -75,12 +112,20 @@ class GradSync:
         if b <= a:
             return
         if self.bucket_dtype is None:
-            self._push(self._all_reduce(gflat[a:b], True), id(vit))
+            for h in self._reduce_async(gflat[a:b]):
+                self._push(h, id(vit))
             return
         buf = self._buckets.get(id(vit))
         if buf is None or buf.numel() != gflat.numel() or buf.device != gflat.device:
             buf = self._buckets[id(vit)] = torch.empty(gflat.numel(), dtype=self.bucket_dtype, device=gflat.device)
         src, dst = gflat[a:b], buf[a:b]
+        if self.exchange == "rs_ag":
+            dst.copy_(src)                                               # (_reduce_async averages: AVG on RCCL, 1 / W + SUM on gloo)
+            hs = self._reduce_async(dst)
+            for h in hs[:-1]:
+                self._push(h, id(vit))
+            self._push(hs[-1], id(vit), lambda: src.copy_(dst))
+            return
         if self.avg:
             dst.copy_(src)
         else:

@@ -113,6 +113,25 @@ def _worker(rank, world, port, q):
         err16 = float((gflat - want).abs().max() / want.abs().max())   # every rank's term is rounded to bf16 (2^-9 of ITS size), then the mean
         ok2 = ok2 and sync16._buckets[id(vit)].dtype == torch.bfloat16 and gflat.dtype == torch.float32 and err16 < 8e-3 \
             and not torch.equal(before, gflat)                # the f32 arena is written at the join, not before
+        # (2c) reduce-scatter + all-gather exchange: same means as the all-reduce, bucket sizes that do and do not divide over
+        # the ranks, one block per bucket, f32 and bf16 buckets
+        for bdt in (None, torch.bfloat16):
+            rs = GradSync(exchange="rs_ag", bucket_dtype=bdt)
+            rs.attach(vit, bucket_layers=1)
+            gen = torch.Generator().manual_seed(29 + rank)
+            gflat = torch.randn(vit.flat_parameters().numel(), generator=gen)
+            want = gflat.clone()
+            dist.all_reduce(want)
+            want /= world
+            for s in range(vit.depth, -2, -1):
+                vit._grad_stage_hook(vit, s, s, gflat)
+            rs.finish(vit)
+            e = float((gflat - want).abs().max() / want.abs().max())
+            ok2 = ok2 and rs.pending() == 0 and e < (1e-6 if bdt is None else 8e-3)
+        odd = torch.arange(7, dtype=torch.float32) * (rank + 1)           # 7 elements over 2 ranks: 6 by reduce-scatter, 1 by all-reduce
+        for h in GradSync(exchange="rs_ag")._reduce_async(odd):
+            h.wait()
+        ok2 = ok2 and bool(torch.allclose(odd, torch.arange(7, dtype=torch.float32) * 1.5))
         vit._grad_stage_hook = None
         # (3) concat_all_gather order + enqueue of the gathered keys (BLD:91-105, 229-240)
         keys = torch.nn.functional.normalize(torch.full((4, 256), float(rank + 1)) + torch.arange(4).float()[:, None], dim=1)

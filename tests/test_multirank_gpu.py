@@ -131,6 +131,15 @@ def _grad_sync(rank, world):
     got16 = m._last_grad_arena
     assert got16.dtype == torch.float32
     res.update(sync_bf16=_err(got16, want), bf16_rounds=bool((got16 != want).any()))
+    # reduce-scatter + all-gather per one-block bucket (MFVIT_GRAD_EXCHANGE=rs_ag): the same means, issued from the same hooks
+    rs = GradSync(exchange="rs_ag")
+    rs.attach(m, bucket_layers=1)
+    for p in m.parameters():
+        p.grad = None
+    (m.features3D(x) * w).sum().backward()
+    assert rs.pending(m) >= 6
+    rs.finish(m)
+    res.update(sync_rs_ag=_err(m._last_grad_arena, want))
     m._grad_stage_hook = None
     return res
 
@@ -250,6 +259,7 @@ def test_two_ranks_syncbn_shufflebn_gradsync():
         assert r["sync"]["sync"] < 1e-6 and r["sync"]["differs_from_local"], (rank, r["sync"])
         # bf16 buckets: each rank's term and the mean are rounded to bf16 (2^-9 of their size); error relative to the largest gradient
         assert r["sync"]["sync_bf16"] < 4e-3 and r["sync"]["bf16_rounds"], (rank, r["sync"])
+        assert r["sync"]["sync_rs_ag"] < 1e-6, (rank, r["sync"])
         st = r["stock"]
         assert st["grad"] < 2e-3 and st["grad_is_mean"], (rank, st)
         # step 0 runs on identical weights: same logits bit for bit, gradients equal to reduction-order rounding.  Step 1 runs on
