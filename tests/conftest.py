@@ -20,6 +20,9 @@ os.environ.setdefault("MFVIT_AB_LIVE", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle's matmuls are small: on a 256-core host torch's default (one thread per core) oversubscribes them and the wall time
+    # of the suite swings by 2 x between boxes (270 - 580 s measured); 32 threads are both faster and steadier
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
 
 
 def pytest_collection_modifyitems(config, items):
