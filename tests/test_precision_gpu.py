@@ -406,6 +406,53 @@ def test_bf16x3_ca_step_meets_the_1e3_gate():
     assert abs(float(loss) - float(r_loss)) < 1e-4 * max(1.0, abs(float(r_loss)))
 
 
+def test_bf16x3_ca_step_at_the_bench_shape_against_the_oracle():
+    """The SAME step at the shape bench.py times (BASELINE configs[2]: 128 pairs, depth 12, M = 25,216 token rows per encoder - every
+    size-gated kernel of the timed step: tall row tiles with 7 fragments, the paired weight gradient, the persistent attention forward
+    and the single-pass backward at 1,536 (image, head) pairs) against the CPU oracle's forward AND backward on the same weights and
+    inputs: all 128 logit rows, argmax, loss, and the qkv / fc2 / patch-embedding weight gradients of both backbones plus a fusion
+    gradient."""
+    import vits_returnftrs as vits
+    from mfvit.losses import cross_entropy
+    fus = importlib.import_module(FUS_MOD)
+    depth, B = 12, 128
+    vit_p = [ref_vit.seeded_params(37 + i, num_classes=3, depth=depth) for i in range(2)]
+    fus_p = ref_fusion.seeded_fusion_params(39)
+    backs = []
+    for p in vit_p:
+        m = vits.vit_small(num_classes=3, depth=depth, precision="bf16x3")
+        m.load_state_dict(p)
+        backs.append(m.to("cuda:0"))
+    model = fus.Fus_CrossViT(backs[0], backs[1])
+    model.load_state_dict(fus_p)
+    model = model.to("cuda:0")
+    x, xe = rng_tensor(83, (B, 3, 224, 224)), rng_tensor(84, (B, 3, 224, 224))
+    y = torch.arange(B) % 3
+    fused, x_c, x_e = model(backs[0], backs[1], x.to("cuda:0"), xe.to("cuda:0"))
+    out = fused + x_c + x_e
+    loss, preds = cross_entropy(out, y.to("cuda:0"))
+    loss.backward()
+    fpd = {k: v.clone().requires_grad_(True) for k, v in fus_p.items()}
+    vpd = [{k: v.clone().requires_grad_(k != "pos_embed") for k, v in p.items()} for p in vit_p]
+    r_out, r_preds, r_loss, _ = ref_fusion.ca_step(fpd, vpd[0], vpd[1], x, xe, y)
+    r_loss.backward()
+    e_out = rel_err(out, r_out)
+    k = "multi_scale_transformers.0.cross_attn_layers.0.0.fn.wk.weight"
+    e_f = rel_err(dict(model.named_parameters())[k].grad, fpd[k].grad)
+    e_b = 0.0
+    for i in (0, 1):
+        for j in (0, 5, 11):
+            e_b = max(e_b, rel_err(backs[i].blocks[j].attn.qkv.weight.grad, vpd[i][f"blocks.{j}.attn.qkv.weight"].grad),
+                      rel_err(backs[i].blocks[j].mlp.fc2.weight.grad, vpd[i][f"blocks.{j}.mlp.fc2.weight"].grad),
+                      rel_err(backs[i].blocks[j].norm1.weight.grad, vpd[i][f"blocks.{j}.norm1.weight"].grad))
+        e_b = max(e_b, rel_err(backs[i].patch_embed.proj.weight.grad, vpd[i]["patch_embed.proj.weight"].grad))
+    log(f"CA step[bf16x3, depth 12, B = {B}: the bench shape] logits {e_out:.2e} fusion-grad {e_f:.2e} backbone-grads {e_b:.2e} "
+        f"loss {float(loss):.6f} vs {float(r_loss):.6f}")
+    assert e_out < 1e-3 and e_f < 2e-3 and e_b < 2e-3
+    assert preds.cpu().tolist() == r_preds.tolist()
+    assert abs(float(loss) - float(r_loss)) < 1e-4 * max(1.0, abs(float(r_loss)))
+
+
 def test_grad_scaler_semantics():
     """mfvit.amp.GradScaler against torch's documented behaviour (MAIN_MOCO:546-548): unscale + step on clean gradients, skip +
     backoff on an overflow, growth after `growth_interval` clean steps, state_dict keys."""
