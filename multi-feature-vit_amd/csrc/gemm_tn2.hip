@@ -78,7 +78,9 @@ template <typename T> __device__ __forceinline__ typename Vec8<T>::type t2_frag(
 // T = bf16 | f16 | sbf16 (split bf16, see T2Geo)
 // RM: the rows of A are REMAPPED (GemmP::orow_*: the patch-embedding weight gradient reads the token rows 1 .. np of every image of a [B][np + 1][D]
 // gradient tensor); instantiated for the default split-bf16 form only
-template <typename T, bool CS, bool W8, bool IL, bool RM = false>
+// TWO (opt-in, MFVIT_WGRAD_TERMS=2; pipelined split form only): the dY_lo x_hi term is dropped - two MFMAs per product, dY enters at bf16 precision
+// (2^-9 per element, averaged down by the sum over the token rows), x keeps both parts
+template <typename T, bool CS, bool W8, bool IL, bool RM = false, bool TWO = false>
 __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
     typedef T2Geo<T> G;
     constexpr int NWV = W8 ? 8 : 4;                          // waves
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
         auto mfma_t = [&](auto set_tag, int t) __attribute__((always_inline)) {
             constexpr int SET = decltype(set_tag)::value;
             const int term = t / (NL * NL), i = (t % (NL * NL)) / NL, j = t % NL;
+            if (TWO && term == 0) return;                        // (a_lo b_hi: its fragment reads become dead code as well)
             acc[i][j] = MmaTraits<T>::mma(fa[SET][2 * i + (term == 0 ? 1 : 0)], fb[SET][2 * j + (term == 1 ? 1 : 0)], acc[i][j]);
         };
         auto stage = [&](int st, auto set_tag, auto nset_tag, int slot) __attribute__((always_inline)) {
@@ -449,8 +452,19 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     static int sw8 = INT_MIN, swil = INT_MIN;                // read once, or at every launch under MFVIT_AB_LIVE=1 (A/B runs in one process)
     const bool w8 = env_switch("MFVIT_TN2_W8", 1, sw8) != 0, il = env_switch("MFVIT_TN2_IL", 1, swil) != 0;
     ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * (p.N + p.res_mod) * p.K, 0, st);
+    static int sw2 = INT_MIN;
+    const bool two = is_split<T>::value && w8 && il && !p.orow_in && env_switch("MFVIT_WGRAD_TERMS", 3, sw2) == 2;
     auto go = [&](auto cs, auto w, auto i) {
         constexpr bool CS = decltype(cs)::value, W8 = decltype(w)::value, IL = decltype(i)::value;
+        if constexpr (is_split<T>::value && W8 && IL) {
+            if (two) {
+                static PerDeviceOnce attr2;
+                if (attr2.first())
+                    (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<T, CS, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                MFVIT_LAUNCH((gemm_tn_glds_kernel<T, CS, true, true, false, true>), dim3(tiles * p.splits), dim3(512), bytes, st, p);
+                return;
+            }
+        }
         static PerDeviceOnce attr;
         if (attr.first()) {
             (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<T, CS, W8, IL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

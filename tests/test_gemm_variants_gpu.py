@@ -103,6 +103,27 @@ def test_weight_gradient_variants(monkeypatch, M, tag, w8, il):
             assert rel(out2, 2 * ref) < 2e-5, (tag, name, split, w8, il, "accumulate")
 
 
+def test_two_term_weight_gradient_is_opt_in_and_bf16_grade_in_dy(monkeypatch):
+    """MFVIT_WGRAD_TERMS=2 (csrc/gemm_tn2.hip, TWO): the dY_lo x_hi product is dropped - a throughput option (8 % of the weight-gradient class,
+    3.6 % of the train step), NOT the default: dW then carries dY at bf16 precision.  Against float64 on the split operands the
+    error is that of rounding dY to bf16 (a few 1e-3 of the largest element), against float64 on (bf16(dY), split x) it is f32-grade - and the
+    bias column sums, which keep both parts, stay f32-grade."""
+    g = _gen(91)
+    M = 197 * 128
+    dy32, x32 = rn(g, M, 3 * D, sc=.1), rn(g, M, D)
+    dy, x = sp(dy32), sp(x32)
+    ref = ops.split_unpack(dy).double().T @ ops.split_unpack(x).double()
+    ref_hi = dy32.to(torch.bfloat16).double().T @ ops.split_unpack(x).double()
+    full = ops.linear_wgrad(dy, x, split=True)
+    monkeypatch.setenv("MFVIT_WGRAD_TERMS", "2")
+    two = ops.linear_wgrad(dy, x, split=True)
+    e_full, e_two, e_two_hi = rel(full, ref), rel(two, ref), rel(two, ref_hi)
+    y1, attn = sp(rn(g, M, D)), sp(rn(g, M, D, sc=.1))
+    dw_a, db_a, dw_b = ops.linear_wgrad_pair(dy, x, attn, y1, split=True)     # the paired launch of the encoder backward takes the same switch
+    e_pair, e_bias = rel(dw_a, ref_hi), rel(db_a, ops.split_unpack(dy).double().sum(0))
+    assert e_full < 2e-5 and 2e-4 < e_two < 6e-3 and e_two_hi < 2e-5 and e_pair < 2e-5 and e_bias < 2e-5, (e_full, e_two, e_two_hi, e_pair, e_bias)
+
+
 @pytest.mark.parametrize("M,tag", SHAPES)
 @pytest.mark.parametrize("kind", ["split", "bf16", "fp16"])
 def test_paired_weight_gradient_launch(M, tag, kind):
