@@ -95,8 +95,9 @@ __device__ __forceinline__ void rp_dma4(unsigned voff, const char* sbase, unsign
 // T: sbf16 (split bf16: a 128-byte row = ONE 32-wide k group as [hi x 32 | lo x 32], three MFMAs per product) or a plain 16-bit type (bf16 / f16,
 // round 4: a 128-byte row = 64 k values = TWO k steps, one MFMA each).  The fragment addressing is the same in both - chunk q of a row is the hi part /
 // k step 0, chunk 4 + q the lo part / k step 1 - only the term table of the MFMAs and the output formats differ.
+// (the body of the kernels below: tile `tile` of the launch owns rows m0 .. m0 + rpt - 1)
 template <int MODE, int MF, typename T>
-__global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int npass) {
+__device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0, const int rpt, const int npass) {
     constexpr int REPI = MODE;
     constexpr bool SPLIT = is_split<T>::value;
     constexpr int KG = SPLIT ? 32 : 64;                                // logical k values per 128-byte row
@@ -107,7 +108,6 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * rpt;
     const int rows = p.M - m0 < rpt ? p.M - m0 : rpt;                 // valid rows of this tile (1 .. RP_TH)
     const int nk = p.K / KG;
     const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     {
         const unsigned lpr = (unsigned)(p.K / KG);                             // 128-byte lines per W row
         const unsigned lines = (unsigned)p.N * lpr;                            // all passes
-        const unsigned t0 = (unsigned)(blockIdx.x >> 3) * 512u + (unsigned)tid;
+        const unsigned t0 = (unsigned)(tile >> 3) * 512u + (unsigned)tid;
         const unsigned nthr = ((gridDim.x + 7u) >> 3) * 512u;
 #pragma unroll
         for (int k = 0; k < RP_TOUCH; ++k) {
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
                 }
             if (fre != 0) return;
             if (p.cpart) {
-                float* cp = p.cpart + ((long)blockIdx.x * 3 + q) * RP_N + ncol0;
+                float* cp = p.cpart + ((long)tile * 3 + q) * RP_N + ncol0;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     f32x4v v4 = {cv[j][0], cv[j][1], cv[j][2], cv[j][3]};
@@ -701,6 +701,21 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
     }
 }
 
+template <int MODE, int MF, typename T>
+__global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int npass) {
+    rowp_body<MODE, MF, T>(p, (int)blockIdx.x, (int)blockIdx.x * rpt, rpt, npass);
+}
+// MIXED tile heights (round 4): the first n_lo tiles carry 16 (MF - 1) rows and run the (MF - 1)-fragment body, the others rpt_hi <= 16 MF rows.  With one
+// tile per CU, 25,216 rows are 98.5 per tile: 99 rows in 7 fragments of 16 multiply 13 padding rows in EVERY tile (12 % of the MFMAs); 216 tiles of 96 rows
+// + 40 of 112 multiply none.  The launch is as long as its 7-fragment tiles either way - but it runs at the power cap (profiles/r04_clock_power_probe.txt), and
+// the work the other tiles no longer do is clock for those.
+template <int MODE, int MF, typename T>
+__global__ __launch_bounds__(512, 1) void gemm_rowp_mixed_kernel(GemmP p, int n_lo, int rpt_hi, int npass) {
+    const int tile = (int)blockIdx.x;
+    if (tile < n_lo) rowp_body<MODE, MF - 1, T>(p, tile, tile * 16 * (MF - 1), 16 * (MF - 1), npass);
+    else rowp_body<MODE, MF, T>(p, tile, n_lo * 16 * (MF - 1) + (tile - n_lo) * rpt_hi, rpt_hi, npass);
+}
+
 int rp_cus() { return device_cus(); }
 
 // rows per tile: the smallest whole number of rounds of one tile per CU that covers M with tiles of at most 112 rows, rows spread evenly
@@ -730,8 +745,28 @@ template <int MODE, typename T> int launch_rowp(const GemmP& p, hipStream_t st) 
 #ifdef MFVIT_ABLATE
     { const char* e = getenv("MFVIT_ROWP_NOEPI"); q.rows_per_wg = (e && atoi(e)) ? 78 : 0; }
 #endif
-    static int sw_mf = INT_MIN;                                          // MFVIT_ROWP_MF=7: every tile on the 7-fragment kernel (the round-3 behaviour)
+    static int sw_mf = INT_MIN, sw_mix = INT_MIN;                        // MFVIT_ROWP_MF=7: every tile on the 7-fragment kernel (the round-3 behaviour)
     const int mf = env_switch("MFVIT_ROWP_MF", 0, sw_mf) == 7 ? 7 : (rpt + 15) / 16;
+    if (mf == 7 && grid > 1 && rpt % 16 && env_switch("MFVIT_ROWP_MIX", 1, sw_mix) != 0 && env_switch("MFVIT_ROWP_MF", 0, sw_mf) != 7) {
+        // mixed heights: n_lo tiles of 96 rows, the rest as many rows as it takes, at most the mode's cap
+        static int sw_cap = INT_MIN;
+        // rows of the tall tiles at most.  Their epilogue is the launch's critical path, so in the SERIALIZED pass the forward launch is shortest with
+        // short tall tiles (74.9 us at 100 rows, 77.2 at 112) - but the timed step, at the power cap, follows the MFMA count: 26.85 ms uniform,
+        // 26.63 / 26.55 / 26.56 / 26.52 ms at 100 / 104 / 108 / 112 rows (profiles/r04_kernel_experiments.txt)
+        int cap = env_switch("MFVIT_ROWP_MIXCAP", RP_TH, sw_cap);
+        cap = cap > rp_cap<MODE>() ? rp_cap<MODE>() : (cap < 97 ? 97 : cap);
+        int n_lo = (cap * grid - p.M) / (cap - 96);                      // the most 96-row tiles that leave <= cap rows for each of the others
+        n_lo = n_lo < 0 ? 0 : (n_lo > grid - 1 ? grid - 1 : n_lo);
+        const int rpt_hi = (p.M - 96 * n_lo + (grid - n_lo) - 1) / (grid - n_lo);
+        if (n_lo > 0 && rpt_hi > 96 && rpt_hi <= cap) {
+            static PerDeviceOnce attr_m;
+            if (attr_m.first())
+                (void)hipFuncSetAttribute((const void*)gemm_rowp_mixed_kernel<MODE, 7, T>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
+            MFVIT_LAUNCH((gemm_rowp_mixed_kernel<MODE, 7, T>), dim3(grid), dim3(512), RP_LDS, st, q, n_lo, rpt_hi, q.N / RP_N);
+            MFVIT_CHECK_LAUNCH();
+            return MFVIT_OK;
+        }
+    }
     switch (mf) {
     case 1: return launch_rowp_mf<MODE, 1, T>(q, grid, rpt, st);
     case 2: return launch_rowp_mf<MODE, 2, T>(q, grid, rpt, st);
