@@ -10,9 +10,9 @@ from mfvit._lib import source_hash  # noqa: E402
 def klass(name):
     if "gemm_tn_kernel" in name or "gemm_tn_glds_kernel" in name:
         return "gemm_tn_wgrad"
-    if "gemm_rowp_kernel" in name:
+    if "gemm_rowp_kernel" in name or "gemm_rowp_mixed_kernel" in name:
         # the tall-tile row kernel: <0> residual + LayerNorm forward, <1> LayerNorm backward, >= 10 the (opt-in) plain linears
-        m = re.search(r"gemm_rowp_kernel(?:ILi|<)(\d+)", name)
+        m = re.search(r"gemm_rowp_(?:mixed_)?kernel(?:ILi|<)(\d+)", name)
         mode = int(m.group(1)) if m else 0
         return "gemm_nt_row_res_ln" if mode == 0 else "gemm_nt_row_lnbwd" if mode == 1 else "gemm_nt_tile"
     if "gemm_nt_row_kernel" in name:
