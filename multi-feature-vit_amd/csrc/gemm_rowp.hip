@@ -747,22 +747,35 @@ template <int MODE, typename T> int launch_rowp(const GemmP& p, hipStream_t st) 
 #endif
     static int sw_mf = INT_MIN, sw_mix = INT_MIN;                        // MFVIT_ROWP_MF=7: every tile on the 7-fragment kernel (the round-3 behaviour)
     const int mf = env_switch("MFVIT_ROWP_MF", 0, sw_mf) == 7 ? 7 : (rpt + 15) / 16;
-    if (mf == 7 && grid > 1 && rpt % 16 && env_switch("MFVIT_ROWP_MIX", 1, sw_mix) != 0 && env_switch("MFVIT_ROWP_MF", 0, sw_mf) != 7) {
-        // mixed heights: n_lo tiles of 96 rows, the rest as many rows as it takes, at most the mode's cap
-        static int sw_cap = INT_MIN;
+    if (mf >= 2 && grid > 1 && rpt % 16 && env_switch("MFVIT_ROWP_MIX", 1, sw_mix) != 0 && env_switch("MFVIT_ROWP_MF", 0, sw_mf) != 7) {
+        // mixed heights: n_lo tiles of 16 (mf - 1) rows, the rest as many rows as it takes, at most 16 mf and the mode's cap
         // rows of the tall tiles at most.  Their epilogue is the launch's critical path, so in the SERIALIZED pass the forward launch is shortest with
         // short tall tiles (74.9 us at 100 rows, 77.2 at 112) - but the timed step, at the power cap, follows the MFMA count: 26.85 ms uniform,
         // 26.63 / 26.55 / 26.56 / 26.52 ms at 100 / 104 / 108 / 112 rows (profiles/r04_kernel_experiments.txt)
+        static int sw_cap = INT_MIN;
+        const int lo = 16 * (mf - 1);
         int cap = env_switch("MFVIT_ROWP_MIXCAP", RP_TH, sw_cap);
-        cap = cap > rp_cap<MODE>() ? rp_cap<MODE>() : (cap < 97 ? 97 : cap);
-        int n_lo = (cap * grid - p.M) / (cap - 96);                      // the most 96-row tiles that leave <= cap rows for each of the others
+        cap = cap > rp_cap<MODE>() ? rp_cap<MODE>() : cap;
+        cap = cap > 16 * mf ? 16 * mf : (cap < lo + 1 ? lo + 1 : cap);
+        int n_lo = (cap * grid - p.M) / (cap - lo);                      // the most short tiles that leave <= cap rows for each of the others
         n_lo = n_lo < 0 ? 0 : (n_lo > grid - 1 ? grid - 1 : n_lo);
-        const int rpt_hi = (p.M - 96 * n_lo + (grid - n_lo) - 1) / (grid - n_lo);
-        if (n_lo > 0 && rpt_hi > 96 && rpt_hi <= cap) {
-            static PerDeviceOnce attr_m;
-            if (attr_m.first())
-                (void)hipFuncSetAttribute((const void*)gemm_rowp_mixed_kernel<MODE, 7, T>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
-            MFVIT_LAUNCH((gemm_rowp_mixed_kernel<MODE, 7, T>), dim3(grid), dim3(512), RP_LDS, st, q, n_lo, rpt_hi, q.N / RP_N);
+        const int rpt_hi = (p.M - lo * n_lo + (grid - n_lo) - 1) / (grid - n_lo);
+        if (n_lo > 0 && rpt_hi > lo && rpt_hi <= cap) {
+            auto go = [&](auto mtag) {
+                constexpr int MFH = decltype(mtag)::value;
+                static PerDeviceOnce attr_m;
+                if (attr_m.first())
+                    (void)hipFuncSetAttribute((const void*)gemm_rowp_mixed_kernel<MODE, MFH, T>, hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
+                MFVIT_LAUNCH((gemm_rowp_mixed_kernel<MODE, MFH, T>), dim3(grid), dim3(512), RP_LDS, st, q, n_lo, rpt_hi, q.N / RP_N);
+            };
+            switch (mf) {
+            case 2: go(std::integral_constant<int, 2>{}); break;
+            case 3: go(std::integral_constant<int, 3>{}); break;
+            case 4: go(std::integral_constant<int, 4>{}); break;
+            case 5: go(std::integral_constant<int, 5>{}); break;
+            case 6: go(std::integral_constant<int, 6>{}); break;
+            default: go(std::integral_constant<int, 7>{}); break;
+            }
             MFVIT_CHECK_LAUNCH();
             return MFVIT_OK;
         }
