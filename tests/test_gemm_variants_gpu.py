@@ -42,9 +42,12 @@ def rn(g, *shape, sc=1.0):
 
 @pytest.mark.parametrize("M,tag", ROW_SHAPES)
 @pytest.mark.parametrize("K", [D, F])
-@pytest.mark.parametrize("mode", ["0", "2"])
+@pytest.mark.parametrize("mode", ["0", "2", "2-uniform"])
 def test_row_kernel_forward_residual_layernorm(monkeypatch, M, tag, K, mode):
-    """x = a @ w.T + bias + res ; y = LayerNorm(x)  (proj / fc2 of timm's Block + the following norm): both row kernels, split and f32 y."""
+    """x = a @ w.T + bias + res ; y = LayerNorm(x)  (proj / fc2 of timm's Block + the following norm): both row kernels (the tall-tile one with
+    mixed tile heights - the default - and with uniform ones: MFVIT_ROWP_MIX=0), split and f32 y."""
+    monkeypatch.setenv("MFVIT_ROWP_MIX", "0" if mode.endswith("uniform") else "1")
+    mode = mode[0]
     monkeypatch.setenv("MFVIT_ROWP", mode)
     monkeypatch.setenv("MFVIT_ROWP_MINM", "1")                              # mode 2: the tall-tile kernel at every M, whatever the default gate
     g = _gen(11 + K)
@@ -64,9 +67,11 @@ def test_row_kernel_forward_residual_layernorm(monkeypatch, M, tag, K, mode):
 
 @pytest.mark.parametrize("M,tag", ROW_SHAPES)
 @pytest.mark.parametrize("K", [3 * D, F])
-@pytest.mark.parametrize("mode", ["0", "2"])
+@pytest.mark.parametrize("mode", ["0", "2", "2-uniform"])
 def test_row_kernel_dgrad_layernorm_backward(monkeypatch, M, tag, K, mode):
     """dx = LayerNorm-backward(dy @ wt.T; x) + dres, dgamma, dbeta, column sums of dx  (qkv / fc1 data gradients + norm1 / norm2 backward)."""
+    monkeypatch.setenv("MFVIT_ROWP_MIX", "0" if mode.endswith("uniform") else "1")
+    mode = mode[0]
     monkeypatch.setenv("MFVIT_ROWP", mode)
     monkeypatch.setenv("MFVIT_ROWP_MINM", "1")                              # mode 2: the tall-tile kernel at every M, whatever the default gate
     g = _gen(23 + K)
