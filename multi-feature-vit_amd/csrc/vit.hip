@@ -12,6 +12,15 @@ using namespace mfvit;
 
 namespace {
 
+// MFVIT_FC1B_TILE (default 1, round 4): the fc1 bias gradient comes from the accumulators of the fc2-dgrad tile epilogue (float atomics on 1536 addresses)
+// instead of the ones-fragment MFMAs of the fc1 weight gradient - those cost that launch 8 % (98.9 vs 91.5 us for the same flops without them: a third
+// more MFMAs on half the waves of a third of its workgroups).  Same box, 0 / 1 / 0 / 1: weight-gradient class 97.8 / 94.3 / 97.4 / 94.8 us per launch, tile
+// class unchanged (93.2 / 93.3 / 93.4 / 93.6), step 27.23 / 27.16 / 27.26 / 27.19 ms.
+bool fc1b_in_tile() {
+    static int sw = INT_MIN;
+    return env_switch("MFVIT_FC1B_TILE", 1, sw) != 0;
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Dims {
@@ -557,6 +566,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.M = d.M; p.N = d.F; p.K = d.D;
                 p.aux = b + W.hpre; p.ldaux = F;
                 p.out0 = dhpre; p.ldo0 = F * e;
+                if (fc1b_in_tile()) p.cs0 = gb + L.fc1_b;         // d fc1_b += column sums of dhpre from the accumulators of this epilogue (float atomics)
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_GELU_BWD, p, st));
             }
             MFVIT_TRY(fork());
@@ -564,7 +574,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 GemmP p = zero_gemm();
                 p.A = dhpre; p.lda = F * e; p.W = b + W.y2; p.ldw = D * e;
                 p.M = d.M; p.N = d.F; p.K = d.D;
-                p.cs0 = gb + L.fc1_b;                             // d fc1_b += column sums of dhpre (ones-fragment MFMA in the wgrad kernel)
+                if (!fc1b_in_tile()) p.cs0 = gb + L.fc1_b;        // d fc1_b += column sums of dhpre (ones-fragment MFMA in the wgrad kernel)
                 p.out0 = gb + L.fc1_w; p.ldo0 = D;
                 p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
                 MFVIT_TRY(gemm_tn(d.dtype, p, wst));
