@@ -38,7 +38,16 @@ typedef void* mfvit_stream_t; /* hipStream_t */
 /* fp16 operands (v_mfma_f32_32x32x16_f16), f32 accumulate / residual / statistics: the arithmetic of the reference's autocast
  * pretraining (MAIN_MOCO:349,533); pair with mfvit_amp_unscale for the GradScaler semantics (MAIN_MOCO:546-548). */
 #define MFVIT_F16 3
+/* SPLIT fp16, ATTENTION OPERANDS ONLY (round 5): the qkv tensor of mfvit_attention_fwd / _bwd in the I32 layout with hi = f16(x),
+ * lo = f16(x - hi) (|x| <= 65504; 22 mantissa bits above 2^-2, an absolute floor of 2^-25 below); out, dout and dqkv of those two calls
+ * stay MFVIT_BF16X3.  This is what the encoder runs in bf16x3 mode wherever the whole-head kernels apply (head_dim 32, T <= 224):
+ * mfvit_linear_fwd epilogue 5 writes the qkv projection in this form, and every MFMA of the attention core is the f16 one - the
+ * probabilities and score gradients are split (or, in the backward, rounded) to fp16 with a third of the vector instructions the
+ * bf16 split needs.  No other entry point accepts this tag. */
+#define MFVIT_X3F16 4
 
+/* ABI history: 3 = rounds 3 - 4.  4 (round 5, BREAKING): mfvit_linear_fwd_persistent / mfvit_linear_fwd_ws (dropped in round 4 without a
+ * version bump) and mfvit_mhsa_fused_fwd are gone; MFVIT_X3F16, linear epilogue 5 and mfvit_attention_qkv_dtype are new. */
 int mfvit_abi_version(void);
 const char* mfvit_build_info(void);
 
@@ -119,7 +128,8 @@ int mfvit_gpt_backward(const mfvit_vit_cfg* cfg, const float* params, const void
  * Single ops (exposed for parity tests and for the MoCo projector / predictor path).
  * ------------------------------------------------------------------------------------------------------------ */
 /* y[M][N] = x[M][K] W[N][K]^T + bias   (nn.Linear forward; x, W, y of `dtype`; epilogue 0 bias, 1 bias+GELU(erf)
- * writing gelu'(pre-activation) to y (what the backward needs) and the activation to y2, 3 none).  N % 128 == 0, K % 64 == 0.
+ * writing gelu'(pre-activation) to y (what the backward needs) and the activation to y2, 3 none, 5 bias with y written as
+ * MFVIT_X3F16 (MFVIT_BF16X3 only: the qkv projection feeding mfvit_attention_fwd)).  N % 128 == 0, K % 64 == 0.
  * Epilogue 1: y may be NULL (no-grad forward: the derivative is not computed); for MFVIT_BF16X3 y is PLAIN fp16 [M][N] (ldy in
  * fp16 elements) - the derivative only ever multiplies a gradient, the split copy cost 155 MB of stores per fc1 launch. */
 int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
@@ -155,7 +165,11 @@ int mfvit_linear_res_ln_fwd(int dtype, const void* a, int64_t lda, const void* w
 int mfvit_linear_dgrad_ln_bwd(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, const float* mean,
                               const float* rstd, const float* gamma, const float* dres, float* dx, void* dx_t, float* dgamma,
                               float* dbeta, float* dcol, int M, int K, mfvit_stream_t stream);
-/* softmax(q k^T / sqrt(d)) v per (image, head); qkv [B][T][3][H][d], out [B][T][H*d], lse [B][H][T]. */
+/* softmax(q k^T / sqrt(d)) v per (image, head); qkv [B][T][3][H][d], out [B][T][H*d], lse [B][H][T] (module.py:52-64 is the same math for
+ * the cross-attention; the self-attention of the timm block: SURVEY Appendix A).  dtype MFVIT_X3F16: qkv split fp16, out / dout / dqkv
+ * MFVIT_BF16X3.  mfvit_attention_qkv_dtype: the tag the encoder uses for the qkv tensor of an activation dtype at (T, head_dim) -
+ * MFVIT_X3F16 for MFVIT_BF16X3 where the whole-head kernels apply, the dtype itself otherwise. */
+int mfvit_attention_qkv_dtype(int dtype, int T, int head_dim);
 int mfvit_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int T, int H, int head_dim, mfvit_stream_t stream);
 int mfvit_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias_qkv,
                         int B, int T, int H, int head_dim, mfvit_stream_t stream);
@@ -169,13 +183,6 @@ int mfvit_attention_drop_fwd(int dtype, const void* qkv, void* out, float* lse, 
 int mfvit_attention_drop_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int T, int H,
                              int head_dim, float p, uint64_t seed, uint32_t site, mfvit_stream_t stream);
 int mfvit_dropout_mask(float p, uint64_t seed, uint32_t site, int64_t n, uint8_t* keep, mfvit_stream_t stream);
-/* FUSED multi-head self-attention forward (timm Attention.forward up to the output projection: qkv Linear -> softmax(q k^T / sqrt(d)) v;
- * the "fused-attention kernel" of the north star): one workgroup per (image, head) computes the head's q, k, v from the LayerNorm-ed
- * tokens x [B][T][D] and the packed weight wqkv [3D][D] (+ bias [3D] f32), keeps them on chip and runs the attention core.
- * qkv_out [B][T][3][H][32] (optional, NULL = not written: no-grad forwards), out [B][T][D], lse [B][H][T].  dtype: MFVIT_BF16 |
- * MFVIT_F16 | MFVIT_BF16X3 (x, wqkv, qkv_out, out in that type; split: leading dimensions in storage elements); head_dim 32, T <= 256. */
-int mfvit_mhsa_fused_fwd(int dtype, const void* x, int64_t ldx, const void* wqkv, int64_t ldw, const float* bias, void* qkv_out, void* out,
-                         float* lse, int B, int T, int H, int head_dim, int D, mfvit_stream_t stream);
 /* LayerNorm over rows of width N in {384, 768} (f32 in; y of dtype or f32). */
 int mfvit_layernorm_fwd(int dtype, const float* x, void* y, int y_f32, const float* gamma, const float* beta, float eps, float* mean,
                         float* rstd, int rows, int N, mfvit_stream_t stream);

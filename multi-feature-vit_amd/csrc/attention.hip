@@ -291,7 +291,13 @@ static bool force_tiled() {   // MFVIT_ATTN_TILED=1: the streaming kernels also 
 }
 // whole-(image, head)-in-LDS MFMA kernels where they fit (ViT-S at 224^2: fastest) -> streaming MFMA kernels (long sequences, wide
 // heads, split bf16 beyond the LDS limits) -> exact VALU kernels (f32)
+int attn_qkv_dtype(int dtype, int Tn, int HDim) {
+    if (dtype == MFVIT_BF16X3 && !force_tiled() && attn_mfma_supported(MFVIT_X3F16, Tn, HDim, false) && attn_mfma_supported(MFVIT_X3F16, Tn, HDim, true))
+        return MFVIT_X3F16;
+    return dtype;
+}
 int attn_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, hipStream_t st) {
+    if (dtype == MFVIT_X3F16) return attn_mfma_supported(dtype, Tn, HDim, false) ? attn_fwd_mfma(dtype, qkv, out, lse, B, Tn, H, st) : MFVIT_ENOSYS;
     const bool exact = force_exact() && dtype != MFVIT_BF16X3;
     if (!exact && !force_tiled() && attn_mfma_supported(dtype, Tn, HDim, false)) return attn_fwd_mfma(dtype, qkv, out, lse, B, Tn, H, st);
     if (!exact && attn_tiled_supported(dtype, Tn, HDim)) return attn_fwd_tiled(dtype, qkv, out, lse, B, Tn, H, HDim, st);
@@ -299,6 +305,8 @@ int attn_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, i
 }
 int attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
              int HDim, hipStream_t st) {
+    if (dtype == MFVIT_X3F16)
+        return attn_mfma_supported(dtype, Tn, HDim, true) ? attn_bwd_mfma(dtype, qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st) : MFVIT_ENOSYS;
     const bool exact = force_exact() && dtype != MFVIT_BF16X3;
     if (!exact && !force_tiled() && attn_mfma_supported(dtype, Tn, HDim, true))
         return attn_bwd_mfma(dtype, qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);

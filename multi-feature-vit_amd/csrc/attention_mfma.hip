@@ -30,6 +30,15 @@ namespace {
 // Element types: bf16, f16 (same data movement, v_mfma_f32_32x32x16_f16) and sbf16 = SPLIT bf16 (MFVIT_BF16X3): a head's row piece
 // is [hi x 32 | lo x 32] (128 B), every product of two tensors runs as three MFMAs (hi*hi + lo*hi + hi*lo) and P / dS are split
 // in registers (hi = bf16(p), lo = bf16(p - hi)) before they feed the second product - f32-grade attention on the bf16 matrix core.
+//
+// sf16 (MFVIT_X3F16, round 5; what the encoder runs in bf16x3 mode): q, k, v arrive as SPLIT FP16 (the qkv GEMM's epilogue writes them so,
+// common.cuh) and every MFMA of the kernel is v_mfma_f32_32x32x16_f16; out, dout and dqkv stay split bf16 (the neighbouring GEMMs' format).
+// Why: the kernels are VALU-bound, and a third of that VALU work was the hi / lo split of P and dS in bf16 - convert, shift, mask, subtract,
+// convert: 2.5 instructions per element.  In fp16 the split is v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16: 1.5 per element at the same 22 bits (P <= 2^14
+// by the lazy-maximum threshold, the absolute floor 2^-25 sits far below the row's largest probability) - or 0.5 per element and two MFMAs
+// instead of three where ONE fp16 part (11 bits) is enough (template parameter NP; measured precision: DESIGN.md 5, round 5).
+// dO has gradient scale (1e-6 ... 1e-2: below fp16's normal range), so the backward converts it on chip to split fp16 times a power of two
+// chosen per (image, head) from its largest element (|dO| 2^E in [4, 8)): dP, dS, dQ, dK, dV all carry 2^E, the final multipliers take it out.
 constexpr int HD = 32;
 // LDS images: padded pitch RB + 16 (80 B, split 144 B): the natural-order b128 row reads are bank-conflict free, the transposed
 // ds_read_b64_tr_b16 reads are 2-way conflicted (rows q and q + 2 of a 4-row block share banks).  Tried in round 2 and dropped: unpadded
@@ -41,14 +50,21 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 
 template <typename T> struct AttnT {
     static constexpr bool SP = is_split<T>::value;
+    static constexpr bool X = std::is_same<T, sf16>::value;   // split FP16 q / k / v (out, dout, dqkv: split bf16)
     static constexpr int EP = SP ? 2 : 1;
     static constexpr int RB = 64 * EP;        // bytes of one head row piece
     static constexpr int RSB = RB + 16;       // padded LDS row pitch: b128 row reads of 16 consecutive rows are conflict-free
     typedef typename Vec8<T>::type frag_t;
     typedef typename Vec4<T>::type vec4_t;
-    typedef typename Vec4<T>::elem E;
+    typedef typename Vec4<T>::elem E;         // element of qkv
+    typedef typename std::conditional<X, sbf16, T>::type OT;   // tensor type of out / dout / dqkv
+    typedef typename Vec4<OT>::elem OE;
+    typedef typename Vec8<OT>::type ofrag_t;
+    static constexpr float LAZY = X ? 14.f : 24.f;             // lazy-maximum threshold (log2): P <= 2^LAZY must fit the operand type
     static __device__ __forceinline__ f32x16 mma(frag_t a, frag_t b, f32x16 c) { return MmaTraits_mma(a, b, c); }
 };
+// parts of P / dS that feed the second products: plain types 1, split bf16 2 (hi + lo), split fp16 NPX (1: hi only = 11 bits; 2: hi + lo)
+template <typename T, int NPX> struct PParts { static constexpr int value = AttnT<T>::X ? NPX : (AttnT<T>::SP ? 2 : 1); };
 __device__ __forceinline__ f32x16 MmaTraits_mma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 MmaTraits_mma(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
@@ -70,8 +86,31 @@ template <typename T> __device__ __forceinline__ typename Vec8<T>::type tr_frag(
     return u.v;
 }
 // registers 8 s .. 8 s + 7 of an accumulator as a B fragment (k step s); split: hi and lo parts
-template <typename T> __device__ __forceinline__ void pack8(const f32x16& v, int s, typename Vec8<T>::type& hi, typename Vec8<T>::type& lo) {
+// split fp16: one v_cvt_pk_f16_f32 per pair for the hi parts, v_fma_mixlo / mixhi_f16 (lo = f16(x - f32(hi)), the f16 source read in place) for
+// the lo parts; NP == 1: hi only.  SUM (NP == 1): the row sum of the ROUNDED probabilities (v_dot2c_f32_f16 against (1, 1)) - the normaliser
+// then belongs to the same weights as the numerator.
+template <int NP, bool SUM = false> __device__ __forceinline__ void pack8x(const f32x16& v, int s, f16x8& hi, f16x8& lo, float* sum = nullptr) {
+    union { f16x8 f; unsigned u[4]; } h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = v[8 * s + 2 * j], b = v[8 * s + 2 * j + 1];
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h.u[j]) : "v"(a), "v"(b));
+        if constexpr (NP == 2) {
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l.u[j]) : "v"(h.u[j]), "v"(a));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l.u[j]) : "v"(h.u[j]), "v"(b));
+        }
+        if constexpr (SUM) asm("v_dot2c_f32_f16 %0, 0x3c003c00, %1" : "+v"(*sum) : "v"(h.u[j]));
+    }
+    hi = h.f;
+    if constexpr (NP == 2) lo = l.f;
+    else lo = h.f;
+}
+template <typename T, int NP = 2> __device__ __forceinline__ void pack8(const f32x16& v, int s, typename Vec8<T>::type& hi, typename Vec8<T>::type& lo) {
     typedef typename Vec4<T>::elem E;
+    if constexpr (AttnT<T>::X) {
+        pack8x<NP>(v, s, hi, lo);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
         E h0, h1, l0, l1;
@@ -90,6 +129,15 @@ template <typename T> __device__ __forceinline__ f32x16 mma3(typename Vec8<T>::t
     if constexpr (is_split<T>::value) {
         c = MmaTraits_mma(al, bh, c);
         c = MmaTraits_mma(ah, bl, c);
+    }
+    return MmaTraits_mma(ah, bh, c);
+}
+// acc += A (x) B with B = P or dS in NP parts (1: b_lo is not used - two MFMAs for a split A, 11 bits of B)
+template <typename T, int NP> __device__ __forceinline__ f32x16 mmap(typename Vec8<T>::type ah, typename Vec8<T>::type al, typename Vec8<T>::type bh,
+                                                                     typename Vec8<T>::type bl, f32x16 c) {
+    if constexpr (is_split<T>::value) {
+        c = MmaTraits_mma(al, bh, c);
+        if constexpr (NP == 2) c = MmaTraits_mma(ah, bl, c);
     }
     return MmaTraits_mma(ah, bh, c);
 }
@@ -119,13 +167,14 @@ template <typename T> __device__ __forceinline__ void store_tile_T(typename Vec4
 
 constexpr int NKC = 4;  // key tiles per register-resident chunk (4 x 16 = 64 score registers -> 2 waves per SIMD)
 
-template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<T>::elem* __restrict__ qkv, typename Vec4<T>::elem* __restrict__ out,
+template <typename T, int NPX>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<T>::elem* __restrict__ qkv, typename AttnT<T>::OE* __restrict__ out,
                                                             float* __restrict__ lse, int Tn, int H, float scale) {
     typedef AttnT<T> A;
     typedef typename A::E E;
+    typedef typename A::OT OT;
     typedef typename A::frag_t frag_t;
-    constexpr int EP = A::EP, KP = A::RSB, VP = A::RB, CPR = A::RB / 16;
+    constexpr int EP = A::EP, KP = A::RSB, VP = A::RB, CPR = A::RB / 16, NP = PParts<T, NPX>::value;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int Tpad = (Tn + 31) & ~31;
     char* Ks = lds;
@@ -204,20 +253,21 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const typename Vec4<
                     for (int r = 0; r < 16; ++r) {
                         const float p = __builtin_amdgcn_exp2f(fmaf(sc[t][r], c, -m2));
                         sc[t][r] = p;
-                        lsum += p;
+                        if constexpr (!(A::X && NP == 1)) lsum += p;
                     }
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         frag_t ph, pl;
-                        pack8<T>(sc[t], s, ph, pl);
+                        if constexpr (A::X && NP == 1) pack8x<1, true>(sc[t], s, ph, pl, &lsum);
+                        else pack8<T, NP>(sc[t], s, ph, pl);
                         if constexpr (!A::SP) pl = ph;
-                        o = mma3<T>(tr_frag<T>(Vs, VP, (k0 + t) * 32, s, lane, 0), tr_frag<T>(Vs, VP, (k0 + t) * 32, s, lane, A::SP ? 1 : 0), ph, pl, o);
+                        o = mmap<T, NP>(tr_frag<T>(Vs, VP, (k0 + t) * 32, s, lane, 0), tr_frag<T>(Vs, VP, (k0 + t) * 32, s, lane, A::SP ? 1 : 0), ph, pl, o);
                     }
                 }
         }
         lsum += __shfl_xor(lsum, 32, 64);
         if (q < Tn) {
-            store_tile_T<T>(out + (((long)b * Tn + q) * H * HD + h * HD) * EP, o, 1.0f / lsum, lane);
+            store_tile_T<OT>(out + (((long)b * Tn + q) * H * HD + h * HD) * EP, o, 1.0f / lsum, lane);
             if (lane < 32) lse[((long)b * H + h) * Tn + q] = (m2 + log2f(lsum)) * 0.6931471805599453f;
         }
     }
@@ -300,15 +350,18 @@ __device__ __forceinline__ float xhalf(float x) {
     return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
 }
 
-template <typename T>
-__global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>::elem* __restrict__ qkv, typename Vec4<T>::elem* __restrict__ out,
+template <typename T, int NPX>
+__global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>::elem* __restrict__ qkv, typename AttnT<T>::OE* __restrict__ out,
                                                           float* __restrict__ lse, int Tn, int H, float scale, int npair) {
     typedef AttnT<T> A;
     typedef RingGeo<T> G;
     typedef typename A::E E;
+    typedef typename A::OE OE;
     typedef typename A::frag_t frag_t;
-    constexpr int EP = A::EP, RB = G::RB, CPR = G::CPR, RPP = G::RPP, LO = A::SP ? 1 : 0, SPB = G::SPB, NCW = G::NCW;
-    constexpr int NQK = A::SP ? 6 : 2;                                 // MFMAs of one score tile / of one PV tile
+    constexpr int EP = A::EP, RB = G::RB, CPR = G::CPR, RPP = G::RPP, LO = A::SP ? 1 : 0, SPB = G::SPB, NCW = G::NCW, NP = PParts<T, NPX>::value;
+    constexpr int NQK = A::SP ? 6 : 2;                                 // MFMAs of one score tile
+    constexpr int NPV = A::SP ? 2 * (NP + 1) : 2;                      // ... of one PV tile (P in NP parts)
+    constexpr bool PSUM = A::X && NP == 1;                             // row sum taken from the rounded probabilities (pack8x)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int nt = (Tn + 31) >> 5;                                     // row tiles = key tiles per pair (<= NCW: checked by the launcher)
     const int Timg = G::timg(Tn);
@@ -316,7 +369,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long hs = (long)H * HD * EP, rs = 3 * hs;
     const int npl = (npair - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // pairs of this workgroup: blockIdx.x + k * gridDim.x
-    const int NP = 2 * (Timg / RPP);                                   // LDS-DMA pieces per pair
+    const int NPC = 2 * (Timg / RPP);                                  // LDS-DMA pieces per pair
     char* stage = lds + 2 * slotb + G::pad_bytes(Tn) + wave * (32 * SPB);
     {   // the V overrun of slot 0 (= the head of slot 1) and of slot 1 (= the pad behind it) start out as zeros
         const int pad = G::pad_bytes(Tn);
@@ -324,6 +377,8 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
             *(uint4*)(lds + slotb + i) = make_uint4(0, 0, 0, 0);
             *(uint4*)(lds + 2 * slotb + i) = make_uint4(0, 0, 0, 0);
         }
+        // the staging tiles too: the first pair's steps send the (not yet written) tile to the row's own output lines - zeros, not stale LDS
+        for (int i = threadIdx.x * 16; i < NCW * 32 * SPB; i += 512 * 16) *(uint4*)(lds + 2 * slotb + pad + i) = make_uint4(0, 0, 0, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         ATTN_SB();
@@ -331,10 +386,10 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
     auto pair_bid = [&](int k) __attribute__((always_inline)) {
         return xcd_remap((int)blockIdx.x + k * (int)gridDim.x, npair);                 // the pairs of a workgroup stay on its XCD
     };
-    // LDS-DMA piece pi (0 .. NP - 1: K image pieces, then V image pieces) of the pair at `base` into slot `slot`
+    // LDS-DMA piece pi (0 .. NPC - 1: K image pieces, then V image pieces) of the pair at `base` into slot `slot`
     auto dma_piece = [&](const E* base, int slot, int pi) __attribute__((always_inline)) {
-        const int which = pi >= (NP >> 1) ? 1 : 0;
-        const int pj = pi - which * (NP >> 1);
+        const int which = pi >= (NPC >> 1) ? 1 : 0;
+        const int pj = pi - which * (NPC >> 1);
         const int row = pj * RPP + lane / CPR, cpos = lane % CPR;
         const int cc = cpos ^ (which ? G::vswz(row) : G::kswz(row));                  // the chunk that belongs at this LDS position
         const int rowc = row < Tn ? row : Tn - 1;                                      // image rows past Tn: a finite copy of the last row
@@ -371,7 +426,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
         const int bid = pair_bid(0);
         const E* base = qkv + (long)(bid / H) * Tn * rs + (bid % H) * HD * EP;
         if (act) load_q(base, wave, qnf, qnl);
-        for (int pi = wave; pi < NP; pi += 8) dma_piece(base, 0, pi);
+        for (int pi = wave; pi < NPC; pi += 8) dma_piece(base, 0, pi);
         wait_vm<0>();
         touch_q(qnf, qnl);
     }
@@ -394,7 +449,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
     // pair - a burst of stores at the end of a row held the vector-memory path for ~3,000 cycles, and the next loads queued behind it
     // (first pair: nothing is pending yet - the steps then send the unwritten staging tile to the row's OWN output lines, which the same wave
     // overwrites with the real row one pair later, in program order)
-    E* pend_out = nullptr;
+    OE* pend_out = nullptr;
     int pend_rows = 1;                                                 // valid rows of the pending tile
     auto flush_one = [&](int i) __attribute__((always_inline)) {
         const int r = i * RPI + lane / CPR, ch = lane % CPR;
@@ -418,7 +473,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
         const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
         if (producer) {
             if (kp + 1 < npl) {
-                for (int pi = 0; pi < NP; ++pi) {
+                for (int pi = 0; pi < NPC; ++pi) {
                     dma_piece(basen, (kp + 1) & 1, pi);
                     __builtin_amdgcn_s_sleep(1);                       // paced: ~50 pieces over the round, never a burst
                 }
@@ -479,6 +534,15 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
                 acc = MmaTraits_mma(a[0][i], bh[i], acc);
             }
         };
+        // MFMA number i of the PV product (B = P in NP parts): NP == 1: k-step i / 2, terms v_lo * p, v_hi * p
+        auto mma_pv = [&](int i, const frag_t (&a)[2][2], const frag_t (&bh)[2], const frag_t (&bl)[2], f32x16& acc) __attribute__((always_inline)) {
+            if constexpr (A::SP && NP == 1) {
+                const int s = i / 2, term = i % 2;
+                acc = MmaTraits_mma(term == 0 ? a[1][s] : a[0][s], bh[s], acc);
+            } else {
+                mma_i(i, a, bh, bl, acc);
+            }
+        };
         auto max16 = [&](const f32x16& sc) __attribute__((always_inline)) {   // (v_max3 by hand: fmaxf on MFMA results gets a canonicalising v_max each)
             float cm;
             asm("v_max3_f32 %0, %1, %2, %3" : "=v"(cm) : "v"(sc[0]), "v"(sc[1]), "v"(sc[2]));
@@ -505,7 +569,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
             constexpr int JOB = decltype(job)::value;
             {   // running maximum, lazily: rescale only when this tile exceeds the reference by more than 2^24 in the probabilities
                 const float cm = fmaxf(cmax, xhalf(cmax)) * c;
-                if (__builtin_amdgcn_ballot_w64(cm > m2 + 24.f) != 0) {
+                if (__builtin_amdgcn_ballot_w64(cm > m2 + A::LAZY) != 0) {
                     const float mn = fmaxf(m2, cm);
                     const float alpha = __builtin_amdgcn_exp2f(m2 - mn);
                     m2 = mn;
@@ -522,12 +586,13 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
                 for (int r = r0; r < r1; ++r) {
                     const float pr = __builtin_amdgcn_exp2f(fmaf(cur[r], c, -m2));
                     cur[r] = pr;
-                    lsum += pr;
+                    if constexpr (!PSUM) lsum += pr;
                 }
             };
             frag_t ph[2], pl[2];
             auto pk = [&](int s) __attribute__((always_inline)) {
-                pack8<T>(cur, s, ph[s], pl[s]);
+                if constexpr (PSUM) pack8x<1, true>(cur, s, ph[s], pl[s], &lsum);
+                else pack8<T, NP>(cur, s, ph[s], pl[s]);
                 if constexpr (!A::SP) pl[s] = ph[s];
             };
             // (branch-free: rows past the tile's end repeat its last row - same bytes to the same address; the Q fetch of the last pair
@@ -566,15 +631,17 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
                 mma_i(5, fin_k, qf, ql, nxt); ex(11, 14); ATTN_SB();
                 ATTN_FSTAMP(18);
                 // PV MFMAs of tile t under the rest of its exp2 / packing and the row maximum of tile t + 1
-                mma_i(0, fin_v, ph, pl, o); ex(14, 16); ATTN_SB();
+                mma_pv(0, fin_v, ph, pl, o); ex(14, 16); ATTN_SB();
                 ATTN_FSTAMP(19);
-                mma_i(1, fin_v, ph, pl, o); pk(1); ATTN_SB();
+                mma_pv(1, fin_v, ph, pl, o); pk(1); ATTN_SB();
                 ATTN_FSTAMP(20);
-                mma_i(2, fin_v, ph, pl, o); ATTN_SB();
+                mma_pv(2, fin_v, ph, pl, o); ATTN_SB();
                 side();
-                mma_i(3, fin_v, ph, pl, o); ATTN_SB();
-                mma_i(4, fin_v, ph, pl, o); ATTN_SB();
-                mma_i(5, fin_v, ph, pl, o); ATTN_SB();
+                mma_pv(3, fin_v, ph, pl, o); ATTN_SB();
+                if constexpr (NPV > 4) {
+                    mma_pv(4, fin_v, ph, pl, o); ATTN_SB();
+                    mma_pv(5, fin_v, ph, pl, o); ATTN_SB();
+                }
                 ATTN_FSTAMP(21);
                 mask_tile(nxt, t + 1);
                 cmax = max16(nxt);
@@ -605,7 +672,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
         auto last_step = [&](f32x16& cur, frag_t (&fin_v)[2][2], int t, float cmax) __attribute__((always_inline)) {
             {
                 const float cm = fmaxf(cmax, xhalf(cmax)) * c;
-                if (__builtin_amdgcn_ballot_w64(cm > m2 + 24.f) != 0) {
+                if (__builtin_amdgcn_ballot_w64(cm > m2 + A::LAZY) != 0) {
                     const float mn = fmaxf(m2, cm);
                     const float alpha = __builtin_amdgcn_exp2f(m2 - mn);
                     m2 = mn;
@@ -625,7 +692,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
                             for (int r = 4 * g; r < 4 * g + 4; ++r) {
                                 const float pr = __builtin_amdgcn_exp2f(fmaf(cur[r], c, -m2));   // (masked keys: exp2(-inf) = 0)
                                 cur[r] = pr;
-                                lsum += pr;
+                                if constexpr (!PSUM) lsum += pr;
                             }
                         } else {
 #pragma unroll
@@ -633,9 +700,10 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
                         }
                     }
                     frag_t ph, pl;
-                    pack8<T>(cur, s, ph, pl);
+                    if constexpr (PSUM) pack8x<1, true>(cur, s, ph, pl, &lsum);
+                    else pack8<T, NP>(cur, s, ph, pl);
                     if constexpr (!A::SP) pl = ph;
-                    o = mma3<T>(fin_v[0][s], fin_v[LO][s], ph, pl, o);
+                    o = mmap<T, NP>(fin_v[0][s], fin_v[LO][s], ph, pl, o);
                 }
             }
         };
@@ -679,14 +747,14 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
         {
             const float inv = 1.0f / lsum;
             char* srow = stage + (lane & 31) * SPB;
-            typedef typename Vec4<T>::type V4;
+            typedef typename Vec4<typename A::OT>::type V4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 V4 oh, ol;
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
-                    E h0, h1, l0, l1;
-                    cvt_pair<E, A::SP>(o[4 * g + j] * inv, o[4 * g + j + 1] * inv, h0, h1, l0, l1);
+                    OE h0, h1, l0, l1;
+                    cvt_pair<OE, A::SP>(o[4 * g + j] * inv, o[4 * g + j + 1] * inv, h0, h1, l0, l1);
                     oh[j] = h0;
                     oh[j + 1] = h1;
                     if constexpr (A::SP) { ol[j] = l0; ol[j + 1] = l1; }
@@ -713,15 +781,30 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
 // (padded pitch: conflict-free row reads; unpadded when only that fits the 160 KB of LDS).  -lse/scale and
 // -D = -rowsum(dO o O) enter the score MFMAs as accumulator initial values, so S - lse/scale and dP - D come out of the
 // matrix core and the VALU work per element is mul, exp2, mul, cvt (+ the hi / lo split of P and dS for split tensors).
-template <typename T, int PITCH>
-__global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename Vec4<T>::elem* __restrict__ out,
-                                                            const typename Vec4<T>::elem* __restrict__ dout, const float* __restrict__ lse,
-                                                            typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale, int nbh) {
+// 2^E (and 2^-E) with mx 2^E in [4, 8) for the largest |dO| of a pair: dO 2^E <= 8 leaves dP = dO . v (<= 8 x 32 |v|) and dS = P (dP - D)
+// inside fp16's range for |v| up to ~250, and everything above 2^-2 keeps its 22 bits in split fp16.  All-zero dO: E = 100 (anything works).
+__device__ __forceinline__ void pow2_scale(float mx, float& s, float& sinv) {
+    const int eb = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xffu);
+    int e = 129 - eb;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    s = __builtin_bit_cast(float, (unsigned)(e + 127) << 23);
+    sinv = __builtin_bit_cast(float, (unsigned)(127 - e) << 23);
+}
+
+template <typename T, int PITCH, int NPX>
+__global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename AttnT<T>::OE* __restrict__ out,
+                                                            const typename AttnT<T>::OE* __restrict__ dout, const float* __restrict__ lse,
+                                                            typename AttnT<T>::OE* __restrict__ dqkv, int Tn, int H, float scale, int nbh) {
     typedef AttnT<T> A;
     typedef typename A::E E;
+    typedef typename A::OE OE;
+    typedef typename A::OT OT;
     typedef typename A::frag_t frag_t;
-    constexpr int EP = A::EP, CPR = A::RB / 16, LO = A::SP ? 1 : 0;
+    typedef typename A::ofrag_t ofrag_t;
+    constexpr int EP = A::EP, CPR = A::RB / 16, LO = A::SP ? 1 : 0, NP = PParts<T, NPX>::value;
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ float red[8];                                           // (split fp16: block maximum of |dO|)
+    (void)red;
     const int Tpad = (Tn + 31) & ~31;
     char* Qs = lds;
     char* Ks = Qs + Tpad * PITCH;
@@ -746,13 +829,13 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
         const int bid = xcd_remap(vi, npair);                          // the heads of one image share an XCD: their row pieces share L2 lines
         const int b = bid / H, h = bid % H;
         const E* base = qkv + (long)b * Tn * rs + h * HD * EP;
-        const E* obase = out + (long)b * Tn * os + h * HD * EP;
-        const E* dobase = dout + (long)b * Tn * os + h * HD * EP;
+        const OE* obase = out + (long)b * Tn * os + h * HD * EP;
+        const OE* dobase = dout + (long)b * Tn * os + h * HD * EP;
         // chunk i of this thread: row t0 + RSTEP i, 16-byte piece cidx - ONE per-lane address per tensor, the rows of the other chunks are a
         // uniform stride away (per-chunk addresses were spilled, and every scratch reload waits for ALL loads in flight: the prefetch ran
         // one chunk at a time)
         const E* rp = base + (long)t0 * rs + 8 * cidx;
-        const E* dp_ = dobase + (long)t0 * os + 8 * cidx;
+        const OE* dp_ = dobase + (long)t0 * os + 8 * cidx;
         const float* lp = lse + ((long)b * H + h) * Tn + t0;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
@@ -779,7 +862,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
         for (int i = 0; i < NCH; ++i) {
             int t = tl + RSTEP * i;
             t = t < Tn ? t : Tn - 1;
-            const unsigned voff = ((unsigned)t * (unsigned)os + 8u * (unsigned)cl) * (unsigned)sizeof(E);
+            const unsigned voff = ((unsigned)t * (unsigned)os + 8u * (unsigned)cl) * (unsigned)sizeof(OE);
             // wave-exact guard: a wave covers 64 / CPR whole rows and Tpad is a multiple of 32, so a wave's 1 KB piece lies entirely inside or
             // entirely outside the Tpad * RB bytes of Os (a block-uniform guard let waves 4 - 7 of the last chunk write past the allocation)
             if (RSTEP * i + (__builtin_amdgcn_readfirstlane(wave) * 64) / CPR < Tpad) {
@@ -800,7 +883,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
     auto reduce_D = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            union { uint4 u; frag_t f; } cd, co, cx;
+            union { uint4 u; ofrag_t f; } cd, co, cx;
             const int t = t0 + RSTEP * i;
             cd.u = pd[i];
             co.u = *(const uint4*)(Os + ((t < Tpad ? t : 0) * CPR + cidx) * 16);
@@ -841,10 +924,43 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
     for (int vi = blockIdx.x; vi < npair; vi += gridDim.x) {
     const int bid = xcd_remap(vi, npair);
     const int b = bid / H, h = bid % H;
-    E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
+    OE* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's O pieces have landed ...
     __syncthreads();                                                   // ... and everybody else's
     reduce_D();
+    float sE = 1.f, sEinv = 1.f;                                       // 2^E, 2^-E of this pair's dO (split fp16 only)
+    if constexpr (A::X) {
+        // dO (split bf16, gradient scale) -> split fp16 of dO 2^E, E from the pair's largest |dO| (hi parts: lanes cidx < 4): dP, D, dS and with
+        // them dQ, dK, dV carry 2^E; the store multipliers take it out
+        float mx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            union { uint4 u; ofrag_t f; } cd;
+            cd.u = pd[i];
+            if (cidx < 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf((float)cd.f[j]));
+            }
+        }
+        mx = block_max<512>(mx, red);
+        pow2_scale(mx, sE, sEinv);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            union { uint4 u; ofrag_t f; } me, ot;
+            union { uint4 u; frag_t f; } res;
+            me.u = pd[i];
+            ot.u.x = __shfl_xor(me.u.x, 4, 64); ot.u.y = __shfl_xor(me.u.y, 4, 64);     // the other part of the same 8 d's
+            ot.u.z = __shfl_xor(me.u.z, 4, 64); ot.u.w = __shfl_xor(me.u.w, 4, 64);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xs = ((float)me.f[j] + (float)ot.f[j]) * sE;
+                const f16 hh = (f16)xs;
+                res.f[j] = cidx < 4 ? hh : (f16)(xs - (float)hh);
+            }
+            pd[i] = res.u;
+            pD[i] *= sE;
+        }
+    }
     stage();
     __syncthreads();                                                   // (also: Os may be refilled)
     if (vi + (int)gridDim.x < npair) fetch(vi + gridDim.x);
@@ -882,9 +998,9 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 frag_t sh, sl;
-                pack8<T>(st, s, sh, sl);
+                pack8<T, NP>(st, s, sh, sl);
                 if constexpr (!A::SP) sl = sh;
-                dq = mma3<T>(tr_frag<T>(Ks, PITCH, kt * 32, s, lane, 0), tr_frag<T>(Ks, PITCH, kt * 32, s, lane, LO), sh, sl, dq);
+                dq = mmap<T, NP>(tr_frag<T>(Ks, PITCH, kt * 32, s, lane, 0), tr_frag<T>(Ks, PITCH, kt * 32, s, lane, LO), sh, sl, dq);
             }
         }
         // (store addresses from a laundered lane id: carried across the persistent loop they were spilled, and the reload - placed right behind
@@ -892,7 +1008,7 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
         int lane_s = lane;
         asm volatile("" : "+v"(lane_s));
         const int q = qt * 32 + (lane_s & 31);
-        if (q < Tn) store_tile_T<T>(dbase + (long)q * rs, dq, scale, lane_s);
+        if (q < Tn) store_tile_T<OT>(dbase + (long)q * rs, dq, scale * sEinv, lane_s);
     }
     // ---------------- phase B: dK, dV, wave = key tile
     for (int kt = wave; kt < nt; kt += 8) {
@@ -930,19 +1046,19 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 frag_t ph, pl, sh, sl;
-                pack8<T>(sm, s, ph, pl);
-                pack8<T>(dp, s, sh, sl);
+                pack8<T, NP>(sm, s, ph, pl);
+                pack8<T, NP>(dp, s, sh, sl);
                 if constexpr (!A::SP) { pl = ph; sl = sh; }
-                dv = mma3<T>(tr_frag<T>(dOs, PITCH, qt * 32, s, lane, 0), tr_frag<T>(dOs, PITCH, qt * 32, s, lane, LO), ph, pl, dv);
-                dk = mma3<T>(tr_frag<T>(Qs, PITCH, qt * 32, s, lane, 0), tr_frag<T>(Qs, PITCH, qt * 32, s, lane, LO), sh, sl, dk);
+                dv = mmap<T, NP>(tr_frag<T>(dOs, PITCH, qt * 32, s, lane, 0), tr_frag<T>(dOs, PITCH, qt * 32, s, lane, LO), ph, pl, dv);
+                dk = mmap<T, NP>(tr_frag<T>(Qs, PITCH, qt * 32, s, lane, 0), tr_frag<T>(Qs, PITCH, qt * 32, s, lane, LO), sh, sl, dk);
             }
         }
         int lane_s = lane;
         asm volatile("" : "+v"(lane_s));
         const int k = kt * 32 + (lane_s & 31);
         if (k < Tn) {
-            store_tile_T<T>(dbase + (long)k * rs + hs, dk, scale, lane_s);
-            store_tile_T<T>(dbase + (long)k * rs + 2 * hs, dv, 1.0f, lane_s);
+            store_tile_T<OT>(dbase + (long)k * rs + hs, dk, scale * sEinv, lane_s);
+            store_tile_T<OT>(dbase + (long)k * rs + 2 * hs, dv, sEinv, lane_s);
         }
     }
     __syncthreads();                                               // every wave is done with the images before the next pair overwrites them
@@ -1026,21 +1142,26 @@ template <typename T> struct SpGeo {
     static __host__ __device__ int off_k(int Tn) { return 3 * img(Tn); }
     static __host__ __device__ int off_scr(int Tn, int b) { return 4 * img(Tn) + b * NCW * SCR; }
     static __host__ __device__ int off_ld(int Tn) { return 4 * img(Tn) + 2 * NCW * SCR; }              // -lse/scale rows, then -D rows
-    static __host__ __device__ int lds_bytes(int Tn) { return off_ld(Tn) + 2 * tpad(Tn) * 4; }
+    static __host__ __device__ int lds_bytes(int Tn) { return off_ld(Tn) + 2 * tpad(Tn) * 4 + 32; }   // + the tiles' |dO| maxima (split fp16)
     static __device__ __forceinline__ int swz(int row) { return SP ? ((((row >> 1) & 1) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3); }
 };
 
 // NT: row tiles of a pair (= computing waves): 7 (T = 193 .. 224); other lengths stay with the two-phase kernels
-template <typename T, int NT>
-__global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename Vec4<T>::elem* __restrict__ out,
-                                                          const typename Vec4<T>::elem* __restrict__ dout, const float* __restrict__ lse,
-                                                          typename Vec4<T>::elem* __restrict__ dqkv, int Tn, int H, float scale, int npair) {
+template <typename T, int NT, int NPX>
+__global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename AttnT<T>::OE* __restrict__ out,
+                                                          const typename AttnT<T>::OE* __restrict__ dout, const float* __restrict__ lse,
+                                                          typename AttnT<T>::OE* __restrict__ dqkv, int Tn, int H, float scale, int npair) {
     typedef AttnT<T> A;
     typedef SpGeo<T> G;
     typedef typename A::E E;
+    typedef typename A::OE OE;
+    typedef typename A::OT OT;
     typedef typename A::frag_t frag_t;
-    constexpr int EP = A::EP, RB = G::RB, CPR = G::CPR, RPP = G::RPP, LO = A::SP ? 1 : 0, NCW = G::NCW, SCR = G::SCR;
-    constexpr int NM = A::SP ? 6 : 2;                                  // MFMAs of one 32 x 32 x 32 product
+    typedef typename A::ofrag_t ofrag_t;
+    constexpr int EP = A::EP, RB = G::RB, CPR = G::CPR, RPP = G::RPP, LO = A::SP ? 1 : 0, NCW = G::NCW, SCR = G::SCR, NP = PParts<T, NPX>::value;
+    constexpr int NM = A::SP ? 6 : 2;                                  // MFMAs of one 32 x 32 x 32 product of two tensors
+    constexpr int NPT = A::SP ? NP + 1 : 1;                            // MFMAs per k-step of a product with P / dS (NP parts)
+    constexpr int PLO = NP - 1;                                        // index of the last P / dS part
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int nt = NT;                                             // (checked by the launcher: (Tn + 31) / 32 == NT <= NCW)
     const int Timg = G::timg(Tn), Tpad = G::tpad(Tn), np = Timg / RPP;
@@ -1091,7 +1212,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
     // entry i (0 .. 15) of step window w: i < 8: piece 8 w + i of the K-then-O stream (window 0: 16 of them); i >= 8: piece i - 8 of query tile w - 1 of Q (then dO).
     // Everything is a select on scalars - indices past the end repeat the last piece (identical bytes into rows nobody reads any more).
     constexpr int PPT = 32 / RPP;                                      // pieces per tile and image
-    auto dma_entry = [&](const E* ksrc, const E* osrc, const E* qsrc, const E* dosrc, int w, int i) __attribute__((always_inline)) {
+    auto dma_entry = [&](const E* ksrc, const OE* osrc, const E* qsrc, const OE* dosrc, int w, int i) __attribute__((always_inline)) {
         const bool kv = i < 8 || w == 0;
         int pi = w == 0 ? i : 16 + 8 * (w - 1) + i;                    // piece of the K (first) / O stream
         pi = pi < 2 * np ? pi : 2 * np - 1;
@@ -1116,6 +1237,9 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
     char* const Ks = lds + G::off_k(Tn);
     float* const Ls = (float*)(lds + G::off_ld(Tn));
     float* const Ds = Ls + Tpad;
+    float* const Mx = Ds + Tpad;                                       // [8]: largest |dO| of the query tiles (split fp16; entry 7 stays 0)
+    (void)Mx;
+    float sE = 1.f, sEinv = 1.f;                                       // 2^E, 2^-E of the pair in hand (split fp16; uniform)
 
     // V never enters LDS: a key wave needs only ITS key tile of V, as B fragments whose 16 bytes per lane are 16 contiguous bytes of a V row -
     // it loads them straight from global memory into the fragment registers at the start of the last step (their last use of the pair is
@@ -1176,6 +1300,90 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
         acc += xhalf(acc);
         if (hh == 0) Ds[q] = q < Tn ? -acc : 0.f;
     };
+    // Split fp16.  The pair's scale 2^E comes from the largest |dO| of the pair, and that must be known before the first row of dO is converted -
+    // while the last query tile's rows land after the first step barrier.  So every key wave fetches the hi parts of ITS query tile's dO rows of the
+    // NEXT pair straight from global memory (two 16-byte loads per lane, beside the V fragments, in front of the last step), takes their largest
+    // magnitude in the head of the next pair and publishes it in Mx[wave] in front of barrier X; behind X everybody (the helper too) reads the seven
+    // maxima: no extra barrier, nobody waits for the late rows.  consts_x: D of query tile `wave` as above, times 2^E, and the row goes back into the
+    // dO image as split FP16 of dO 2^E (same chunk positions) - every tile by the wave of the same number, the last one behind the first step barrier.
+    uint4 dpf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    // (lane-derived values of these helpers come from a laundered copy of the lane id handed in by the caller: derived from `lane` itself they are
+    // loop invariants, which the compiler keeps across the pair loop in scratch - and every reload is a drain of the vector-memory queue)
+    auto do_prefetch = [&](const OE* dosrc, int lane_) __attribute__((always_inline)) {
+#ifdef MFVIT_SP_NOPF
+        return;
+#endif
+        const int q = wave * 32 + (lane_ & 31), qc = q < Tn ? q : Tn - 1;
+        const OE* dp_ = dosrc + (long)qc * os + 16 * (lane_ >> 5);
+        dpf[0] = *(const uint4*)dp_;
+        dpf[1] = *(const uint4*)(dp_ + 8);
+    };
+    auto publish_max = [&]() __attribute__((always_inline)) {
+        // 16 bf16 magnitudes as 15-bit integers (monotonic in |x|): packed 16-bit maxima, then the wave's maximum without touching LDS
+        const unsigned w[8] = {dpf[0].x, dpf[0].y, dpf[0].z, dpf[0].w, dpf[1].x, dpf[1].y, dpf[1].z, dpf[1].w};
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned a_ = w[i] & 0x7fff7fffu;
+            asm("v_pk_max_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(a_));
+        }
+        unsigned mm = (m & 0xffffu) > (m >> 16) ? (m & 0xffffu) : (m >> 16);
+        mm = max(mm, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+        mm = max(mm, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+        mm = max(mm, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0x141, 0xf, 0xf, false));   // row_half_mirror
+        mm = max(mm, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mm, 0x140, 0xf, 0xf, false));   // row_mirror: every lane of a row of 16 holds the row's maximum
+        const unsigned r0 = __builtin_amdgcn_readlane(mm, 0), r1 = __builtin_amdgcn_readlane(mm, 16), r2 = __builtin_amdgcn_readlane(mm, 32),
+                       r3 = __builtin_amdgcn_readlane(mm, 48);
+        const unsigned mw = max(max(r0, r1), max(r2, r3));
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) Mx[wave] = __builtin_bit_cast(float, mw << 16);
+    };
+    auto pair_scale = [&]() __attribute__((always_inline)) {
+        const float4 m0 = *(const float4*)Mx, m1 = *(const float4*)(Mx + 4);
+        const float mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+        float s_, si_;
+        pow2_scale(mx, s_, si_);
+        sE = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_)));
+        sEinv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, si_)));
+    };
+    auto consts_x = [&](int lane_) __attribute__((always_inline)) {
+        const int kr = lane_ & 31, hh = lane_ >> 5;
+        const int q = wave * 32 + kr, qc = q < Tn ? q : Tn - 1;
+        float acc = 0.f;
+        uint4 hw[2], lw[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            union { uint4 u; ofrag_t f; } o0, o1, d0, d1;
+            o0.u = *(const uint4*)(Os + qc * RB + 16 * ((2 * hh + i) ^ G::swz(qc)));
+            d0.u = *(const uint4*)(dOs + qc * RB + 16 * ((2 * hh + i) ^ G::swz(qc)));
+            o1.u = *(const uint4*)(Os + qc * RB + 16 * ((4 + 2 * hh + i) ^ G::swz(qc)));
+            d1.u = *(const uint4*)(dOs + qc * RB + 16 * ((4 + 2 * hh + i) ^ G::swz(qc)));
+            union { uint4 u; unsigned w[4]; } h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float oa = (float)o0.f[2 * j] + (float)o1.f[2 * j], ob = (float)o0.f[2 * j + 1] + (float)o1.f[2 * j + 1];
+                const float da = (float)d0.f[2 * j] + (float)d1.f[2 * j], db = (float)d0.f[2 * j + 1] + (float)d1.f[2 * j + 1];
+                acc = fmaf(oa, da, acc);
+                acc = fmaf(ob, db, acc);
+                const float x0 = da * sE, x1 = db * sE;
+                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h.w[j]) : "v"(x0), "v"(x1));
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l.w[j]) : "v"(h.w[j]), "v"(x0));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l.w[j]) : "v"(h.w[j]), "v"(x1));
+            }
+            hw[i] = h.u;
+            lw[i] = l.u;
+        }
+        acc += xhalf(acc);
+        if (q < Tn) {
+            if (hh == 0) Ds[q] = -acc * sE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *(uint4*)(dOs + q * RB + 16 * ((2 * hh + i) ^ G::swz(q))) = hw[i];
+                *(uint4*)(dOs + q * RB + 16 * ((4 + 2 * hh + i) ^ G::swz(q))) = lw[i];
+            }
+        } else if (hh == 0) {
+            Ds[q] = 0.f;
+        }
+    };
 
     // per-lane offsets inside an image: row fragments [part][k-step], transposed reads [part][first / second 4-row block], dS^T writes [part][g].
     // The key waves derive them AFRESH behind barrier Z of every pair, from a laundered lane id: carried across the head of the pair (the row
@@ -1211,9 +1419,9 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
 #pragma unroll
             for (int part = 0; part <= LO; ++part) f[part][s] = *(const frag_t*)(image + tile * 32 * RB + roff[part][s]);
     };
-    auto rd_tr = [&](frag_t (&f)[2], const char* image, int tile, int s) __attribute__((always_inline)) {   // [part], k-step s
+    auto rd_tr = [&](frag_t (&f)[2], const char* image, int tile, int s, int lastpart = (AttnT<T>::SP ? 1 : 0)) __attribute__((always_inline)) {   // [part], k-step s
 #pragma unroll
-        for (int part = 0; part <= LO; ++part) {
+        for (int part = 0; part <= lastpart; ++part) {
             union { struct { s16x4 a, b; } s2; frag_t v; } u;
             const char* p0 = image + (tile * 32 + 16 * s) * RB;
             u.s2.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + toff[part][0]));
@@ -1229,8 +1437,9 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             acc = MmaTraits_mma(a[0][i], bh[i], i == 0 ? init : acc);
         }
     };
+    // MFMA i (0 .. NPT - 1) of one k-step of a product with P / dS: a_lo b_hi, [a_hi b_lo,] a_hi b_hi
     auto mt = [&](int i, const frag_t (&a)[2], const frag_t& bh, const frag_t& bl, f32x16& acc) __attribute__((always_inline)) {
-        if constexpr (A::SP) acc = MmaTraits_mma(i == 0 ? a[1] : a[0], i == 1 ? bl : bh, acc);
+        if constexpr (A::SP) acc = MmaTraits_mma(i == 0 ? a[1] : a[0], (NP == 2 && i == 1) ? bl : bh, acc);
         else acc = MmaTraits_mma(a[0], bh, acc);
     };
     auto zero_frag = [&](frag_t& f) __attribute__((always_inline)) {
@@ -1242,7 +1451,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
     {   // prologue: pair 0 by everybody
         const int bid = pair_bid(0);
         const E* base = qkv + (long)(bid / H) * Tn * rs + (bid % H) * HD * EP;
-        const E* dob = dout + (long)(bid / H) * Tn * os + (bid % H) * HD * EP;
+        const OE* dob = dout + (long)(bid / H) * Tn * os + (bid % H) * HD * EP;
         for (int pj = wave; pj < np; pj += 8) {
             dma_sv((const char*)(base + hs) + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_k(Tn), pj);
             dma_sv((const char*)base + (long)pj * RPP * rs * 2, voff_rs(pj), G::off_q(Tn), pj);
@@ -1268,12 +1477,12 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
         for (int kp = 0; kp < npl; ++kp) {
             const int bid = pair_bid(kp);
             const int b = bid / H, h = bid % H;
-            E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
+            OE* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
             const bool more = kp + 1 < npl;
             const int bidn = pair_bid(more ? kp + 1 : kp);
             const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
-            const E* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
-            const E* obn = out + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
+            const OE* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
+            const OE* obn = out + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             ++rnd_no;
             ATTN_STAMP(10);
@@ -1295,6 +1504,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if ((nt - 1) * 32 + 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3) >= Tn) ktr[nt - 1][s][part][e] = (E)0.0f;
+            if constexpr (A::X) pair_scale();                          // (the tiles' |dO| maxima were published in front of X)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                              // Z: K / V are dead
             ATTN_SB();
@@ -1332,18 +1542,18 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
                 frag_t bfr[2][2];                                      // dS^T fragments [k-step][part] of the key tile in hand
 #pragma unroll
                 for (int j = 0; j < nt; ++j) {
-                    rd_tr(bfr[0], sc + j * SCR, 0, 0);
-                    rd_tr(bfr[1], sc + j * SCR, 0, 1);
+                    rd_tr(bfr[0], sc + j * SCR, 0, 0, PLO);
+                    rd_tr(bfr[1], sc + j * SCR, 0, 1, PLO);
 #pragma unroll
-                    for (int i = 0; i < NM / 2; ++i) {
-                        mt(i, ktr[j][0], bfr[0][0], bfr[0][LO], dq);
-                        mt(i, ktr[j][1], bfr[1][0], bfr[1][LO], dq1);
+                    for (int i = 0; i < NPT; ++i) {
+                        mt(i, ktr[j][0], bfr[0][0], bfr[0][PLO], dq);
+                        mt(i, ktr[j][1], bfr[1][0], bfr[1][PLO], dq1);
                     }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dq[r] += dq1[r];
                 const int q = u * 32 + kr;
-                if (q < Tn) store_tile_T16<T>(dbase + (long)q * rs, dq, scale, lane);
+                if (q < Tn) store_tile_T16<OT>(dbase + (long)q * rs, dq, scale * sEinv, lane);
             }
         }
         return;
@@ -1352,7 +1562,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
     // reach the step barrier ~1,000 cycles ahead of their SIMD partners (waves 4 - 6) - an LDS-DMA stalls only the wave that issues it.
     auto key_role = [&](auto dma_tag) __attribute__((always_inline)) {
         constexpr bool DMA = decltype(dma_tag)::value;
-        auto window = [&](const E* ksrc, const E* osrc, const E* qsrc, const E* dosrc, int w) __attribute__((always_inline)) {
+        auto window = [&](const E* ksrc, const OE* osrc, const E* qsrc, const OE* dosrc, int w) __attribute__((always_inline)) {
             if constexpr (DMA) {
 #pragma unroll
                 for (int e3 = 0; e3 < 6; ++e3) {
@@ -1364,6 +1574,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
         // head of a pair: barrier X, this wave's K / V fragments, the row constants D of query tile `wave` (O rows requested a tail ago), barrier Z
         frag_t kfB[2][2], vfB[2][2];
         auto head = [&]() __attribute__((always_inline)) {
+            if constexpr (A::X) publish_max();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             ++rnd_no;
             ATTN_STAMP(10);
@@ -1378,7 +1589,14 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
     #pragma unroll
                     for (int s = 0; s < 2; ++s) { zero_frag(kfB[part][s]); zero_frag(vfB[part][s]); }
             }
-            if (wave + 1 < nt) consts();                                   // (the last query tile's: behind the first step barrier, see the helper)
+            if constexpr (A::X) {
+                int lane_h = lane;
+                asm volatile("" : "+v"(lane_h));
+                pair_scale();
+                if (wave + 1 < nt) consts_x(lane_h);
+            } else {
+                if (wave + 1 < nt) consts();                               // (the last query tile's: behind the first step barrier, see the helper)
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                  // Z: the row constants are in place
             ATTN_SB();
@@ -1387,17 +1605,18 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
         {
             const int bid0 = pair_bid(0);
             v_fetch(vfB, qkv + (long)(bid0 / H) * Tn * rs + (bid0 % H) * HD * EP + 2 * hs);
+            if constexpr (A::X) do_prefetch(dout + (long)(bid0 / H) * Tn * os + (bid0 % H) * HD * EP, lane);
         }
         head();
         for (int kp = 0; kp < npl; ++kp) {
             const int bid = pair_bid(kp);
             const int b = bid / H, h = bid % H;
-            E* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
+            OE* dbase = dqkv + (long)b * Tn * rs + h * HD * EP;
             const bool more = kp + 1 < npl;
             const int bidn = pair_bid(more ? kp + 1 : kp);
             const E* basen = qkv + (long)(bidn / H) * Tn * rs + (bidn % H) * HD * EP;
-            const E* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
-            const E* obn = out + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
+            const OE* dobn = dout + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
+            const OE* obn = out + (long)(bidn / H) * Tn * os + (bidn % H) * HD * EP;
             int lane_l = lane;                                             // (every lane-derived value of the steps comes from this laundered copy)
             asm volatile("" : "+v"(lane_l));
             calc_offsets(lane_l);
@@ -1448,16 +1667,16 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
                     }
                 };
                 auto pkP = [&](int s) __attribute__((always_inline)) {
-                    pack8<T>(sm, s, ph, pl);
+                    pack8<T, NP>(sm, s, ph, pl);
                     if constexpr (!A::SP) pl = ph;
                 };
                 auto pkS = [&](int s) __attribute__((always_inline)) {      // dS fragments of k-step s; the same bytes go to the dS^T tile
-                    pack8<T>(dp, s, sh, sl);
+                    pack8<T, NP>(dp, s, sh, sl);
                     union { frag_t f; uint2 u[2]; } a;
                     a.f = sh;
                     *(uint2*)(sw + woff[0][2 * s]) = a.u[0];
                     *(uint2*)(sw + woff[0][2 * s + 1]) = a.u[1];
-                    if constexpr (A::SP) {
+                    if constexpr (A::SP && NP == 2) {
                         a.f = sl;
                         *(uint2*)(sw + woff[1][2 * s]) = a.u[0];
                         *(uint2*)(sw + woff[1][2 * s + 1]) = a.u[1];
@@ -1475,7 +1694,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
                     if constexpr (!LAST) mm(2, dofr, vfB[0], vfB[1], ndp, ndp); ev(14, 16); ATTN_SB();
                     mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
                     mt(1, dotr, ph, pl, dv); mt(1, qtr, sh, sl, dk); ATTN_SB();
-                    mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB();
+                    if constexpr (NPT == 3) { mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB(); }
                     rd_tr(dotr, dOs, qt, 1);
                     rd_tr(qtr, Qs, qt, 1);
                     ATTN_SB();
@@ -1489,7 +1708,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
                     ATTN_SB();
                     mt(0, dotr, ph, pl, dv); mt(0, qtr, sh, sl, dk); ATTN_SB();
                     mt(1, dotr, ph, pl, dv); mt(1, qtr, sh, sl, dk); ATTN_SB();
-                    mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB();
+                    if constexpr (NPT == 3) { mt(2, dotr, ph, pl, dv); mt(2, qtr, sh, sl, dk); ATTN_SB(); }
                 } else {
                     ev(0, 8); ATTN_SB();
                     if constexpr (!LAST) mm(0, qfr, kfB[0], kfB[0], nsm, nsm); pkP(0); pkS(0); ATTN_SB();
@@ -1524,7 +1743,8 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             }
                 step(smA, dpA, smB, dpB, 0, std::false_type{});
             if (wave + 1 == nt) {                                          // the last query tile's Q / dO rows are guaranteed from here on
-                consts();
+                if constexpr (A::X) consts_x(lane_l);
+                else consts();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (read four step barriers from here)
             }
 #pragma unroll 1
@@ -1534,11 +1754,12 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             }
             step(smB, dpB, smA, dpA, nt - 2, std::false_type{});
             v_fetch(vfB, basen + 2 * hs);                                  // the next pair's V fragments (this pair's last dP MFMAs are behind us)
+            if constexpr (A::X) do_prefetch(dobn, lane_l);
             step(smA, dpA, smB, dpB, nt - 1, std::true_type{});
             const int k = wave * 32 + kr;
             if (k < Tn) {
-                store_tile_T16<T>(dbase + (long)k * rs + hs, dk, scale, lane);
-                store_tile_T16<T>(dbase + (long)k * rs + 2 * hs, dv, 1.0f, lane);
+                store_tile_T16<OT>(dbase + (long)k * rs + hs, dk, scale * sEinv, lane);
+                store_tile_T16<OT>(dbase + (long)k * rs + 2 * hs, dv, sEinv, lane);
             }
             ATTN_STAMP(11);
             wait_vm<0>();                                                  // this wave's pieces have landed (the stores above have left)
@@ -1574,22 +1795,32 @@ __global__ __launch_bounds__(256) void colsum_t_kernel(const typename Vec4<T>::e
     }
 }
 
-int attn_cus() { return device_cus() & ~7; }   // CUs of the CURRENT device, a multiple of 8 (a persistent workgroup's pairs stay on its XCD)
+int attn_cus() {   // CUs of the CURRENT device, a multiple of 8 (a persistent workgroup's pairs stay on its XCD)
+    const int n = device_cus() & ~7;
+    return n >= 8 ? n : 8;
+}
 
-template <typename T> int launch_fwd_t(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
+// parts of P / dS in the split-fp16 kernels (see the top of the file): forward 2 (hi + lo: f32-grade outputs), backward 1 (11 bits, like the
+// saved activation derivative of the MLP: gradients at 2^-11 relative); MFVIT_ATTN_PF / MFVIT_ATTN_PB = 1 / 2 override (A/B, tests)
+static int parts_fwd() { static int sw = INT_MIN; return env_switch("MFVIT_ATTN_PF", 2, sw) == 1 ? 1 : 2; }
+static int parts_bwd() { static int sw = INT_MIN; return env_switch("MFVIT_ATTN_PB", 1, sw) == 2 ? 2 : 1; }
+
+template <typename T, int NPX> int launch_fwd_t(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
     typedef typename Vec4<T>::elem E;
+    typedef typename AttnT<T>::OE OE;
     {   // persistent pair-synchronous kernel: enough pairs to fill every CU twice, 5 - 7 row tiles per pair (one per computing wave)
         static int sw = INT_MIN;
         const int cus = attn_cus();
         const int nt = (Tn + 31) >> 5;
         const int bytes = RingGeo<T>::lds_bytes(Tn);
-        // Default: split bf16 only (53 vs 57 - 60 us at the bench shape); the plain 16-bit types are faster on the per-pair kernel (27.5 vs 30 us:
-        // their steps are too short for the per-step overheads of the pipeline) - MFVIT_ATTN_FWD_RING=2 forces the persistent kernel for them too.
+        // Default: the split types only (53 vs 57 - 60 us at the bench shape in split bf16); the plain 16-bit types are faster on the per-pair kernel
+        // (27.5 vs 30 us: their steps are too short for the per-step overheads of the pipeline) - MFVIT_ATTN_FWD_RING=2 forces the persistent kernel for them too.
         const int want = env_switch("MFVIT_ATTN_FWD_RING", 1, sw);
         if ((want == 2 || (want == 1 && is_split<T>::value)) && B * H >= 2 * cus && nt >= 5 && nt <= RingGeo<T>::NCW && bytes <= 160 * 1024) {
-            (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            static PerDeviceOnce attr_pp;
+            if (attr_pp.first()) (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<T, NPX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
-            MFVIT_LAUNCH((attn_fwd_pp_kernel<T>), dim3(cus), dim3(512), bytes, st, (const E*)qkv, (E*)out, lse, Tn, H, 1.0f / sqrtf((float)HD), B * H);
+            MFVIT_LAUNCH((attn_fwd_pp_kernel<T, NPX>), dim3(cus), dim3(512), bytes, st, (const E*)qkv, (OE*)out, lse, Tn, H, 1.0f / sqrtf((float)HD), B * H);
             MFVIT_CHECK_LAUNCH();
             return MFVIT_OK;
         }
@@ -1597,44 +1828,49 @@ template <typename T> int launch_fwd_t(const void* qkv, void* out, float* lse, i
     const int Tpad = (Tn + 31) & ~31;
     const int bytes = Tpad * (AttnT<T>::RSB + AttnT<T>::RB);
     static PerDeviceOnce attr;
-    if (attr.first()) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<T, NPX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
     ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
-    MFVIT_LAUNCH((attn_fwd_mfma_kernel<T>), dim3(B * H), dim3(256), bytes, st, (const E*)qkv, (E*)out, lse, Tn, H, 1.0f / sqrtf((float)HD));
+    MFVIT_LAUNCH((attn_fwd_mfma_kernel<T, NPX>), dim3(B * H), dim3(256), bytes, st, (const E*)qkv, (OE*)out, lse, Tn, H, 1.0f / sqrtf((float)HD));
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
-template <typename T> int launch_bwd_t(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
-                                       int H, hipStream_t st) {
+template <typename T, int NPX> int launch_bwd_t(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
+                                                int H, hipStream_t st) {
     typedef typename Vec4<T>::elem E;
+    typedef typename AttnT<T>::OE OE;
+    typedef typename AttnT<T>::OT OT;
     constexpr int RSB = AttnT<T>::RSB, RB = AttnT<T>::RB;
     const int Tpad = (Tn + 31) & ~31;
-    const bool wide = 4 * Tpad * RSB + 2 * Tpad * 4 + Tpad * RB <= 160 * 1024;
+    const bool wide = 4 * Tpad * RSB + 2 * Tpad * 4 + Tpad * RB + 64 <= 160 * 1024;
     const int bytes = 4 * Tpad * (wide ? RSB : RB) + 2 * Tpad * 4 + Tpad * RB;      // Q, K, V, dO images, lse / D rows, the next pair's O rows
     static PerDeviceOnce attr;
     if (attr.first()) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RSB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RSB, NPX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<T, RB, NPX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     }
-    {   // single-pass kernel: seven row tiles (T = 193 .. 224), enough pairs to give every CU two.  Default for all three 16-bit types
+    auto colsum = [&]() -> int {
+        if (!dbias) return MFVIT_OK;
+        const int M = B * Tn, N = 3 * H * HD;
+        MFVIT_LAUNCH((colsum_t_kernel<OT>), dim3((M + 63) / 64), dim3(256), 0, st, (const OE*)dqkv, (long)N * AttnT<T>::EP, dbias, M, N);
+        MFVIT_CHECK_LAUNCH();
+        return MFVIT_OK;
+    };
+    {   // single-pass kernel: seven row tiles (T = 193 .. 224), enough pairs to give every CU two.  Default for all 16-bit types
         // (bench shape: split bf16 115 vs 155 us, bf16 / fp16 62.5 vs 71 us: profiles/r04_kernel_experiments.txt); MFVIT_ATTN_BWD_SP=0: off
         static int sws = INT_MIN;
         const int cus3 = attn_cus();
         const int nt = (Tn + 31) >> 5;
         const int b3 = SpGeo<T>::lds_bytes(Tn);
         if (env_switch("MFVIT_ATTN_BWD_SP", 1, sws) != 0 && B * H >= 2 * cus3 && nt == 7 && b3 <= 160 * 1024) {
-            (void)hipFuncSetAttribute((const void*)attn_bwd_sp_kernel<T, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            static PerDeviceOnce attr_sp;
+            if (attr_sp.first()) (void)hipFuncSetAttribute((const void*)attn_bwd_sp_kernel<T, 7, NPX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             {
                 ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
-                MFVIT_LAUNCH((attn_bwd_sp_kernel<T, 7>), dim3(cus3), dim3(512), b3, st, (const E*)qkv, (const E*)out, (const E*)dout, lse, (E*)dqkv, Tn, H,
+                MFVIT_LAUNCH((attn_bwd_sp_kernel<T, 7, NPX>), dim3(cus3), dim3(512), b3, st, (const E*)qkv, (const OE*)out, (const OE*)dout, lse, (OE*)dqkv, Tn, H,
                              1.0f / sqrtf((float)HD), B * H);
                 MFVIT_CHECK_LAUNCH();
             }
-            if (dbias) {
-                const int M = B * Tn, N = 3 * H * HD;
-                MFVIT_LAUNCH((colsum_t_kernel<T>), dim3((M + 63) / 64), dim3(256), 0, st, (const E*)dqkv, (long)N * AttnT<T>::EP, dbias, M, N);
-                MFVIT_CHECK_LAUNCH();
-            }
-            return MFVIT_OK;
+            return colsum();
         }
     }
     {
@@ -1644,28 +1880,23 @@ template <typename T> int launch_bwd_t(const void* qkv, const void* out, const v
         static int swp = INT_MIN;                                      // MFVIT_ATTN_BWD_PERSIST=0: one workgroup per pair
         const int grid = (B * H < cus || env_switch("MFVIT_ATTN_BWD_PERSIST", 1, swp) == 0) ? B * H : cus;
         if (wide)
-            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RSB>), dim3(grid), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
-                         (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD), B * H);
+            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RSB, NPX>), dim3(grid), dim3(512), bytes, st, (const E*)qkv, (const OE*)out, (const OE*)dout, lse,
+                         (OE*)dqkv, Tn, H, 1.0f / sqrtf((float)HD), B * H);
         else
-            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RB>), dim3(grid), dim3(512), bytes, st, (const E*)qkv, (const E*)out, (const E*)dout, lse,
-                         (E*)dqkv, Tn, H, 1.0f / sqrtf((float)HD), B * H);
+            MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RB, NPX>), dim3(grid), dim3(512), bytes, st, (const E*)qkv, (const OE*)out, (const OE*)dout, lse,
+                         (OE*)dqkv, Tn, H, 1.0f / sqrtf((float)HD), B * H);
         MFVIT_CHECK_LAUNCH();
     }
-    if (dbias) {
-        const int M = B * Tn, N = 3 * H * HD;
-        MFVIT_LAUNCH((colsum_t_kernel<T>), dim3((M + 63) / 64), dim3(256), 0, st, (const E*)dqkv, (long)N * AttnT<T>::EP, dbias, M, N);
-        MFVIT_CHECK_LAUNCH();
-    }
-    return MFVIT_OK;
+    return colsum();
 }
 
 }  // namespace
 
 bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward) {
-    if ((dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || HDim != HD || Tn < 1) return false;
+    if ((dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16 && dtype != MFVIT_X3F16) || HDim != HD || Tn < 1) return false;
     const int Tpad = (Tn + 31) & ~31;
-    const int rb = dtype == MFVIT_BF16X3 ? 128 : 64;
-    const int bytes = backward ? 4 * Tpad * rb + 2 * Tpad * 4 + Tpad * rb : Tpad * (rb + 16) + Tpad * rb;
+    const int rb = (dtype == MFVIT_BF16X3 || dtype == MFVIT_X3F16) ? 128 : 64;
+    const int bytes = backward ? 4 * Tpad * rb + 2 * Tpad * 4 + Tpad * rb + 64 : Tpad * (rb + 16) + Tpad * rb;
     if (backward && Tpad * (rb / 16) > 4 * 512) return false;      // the backward keeps 4 chunks per thread and image in registers
     return bytes <= 160 * 1024;
 }
@@ -1682,16 +1913,20 @@ int attn_colsum(int dtype, const void* dqkv, int M, int N, float* dbias, hipStre
 }
 
 int attn_fwd_mfma(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
-    if (dtype == MFVIT_BF16) return launch_fwd_t<bf16>(qkv, out, lse, B, Tn, H, st);
-    if (dtype == MFVIT_BF16X3) return launch_fwd_t<sbf16>(qkv, out, lse, B, Tn, H, st);
-    if (dtype == MFVIT_F16) return launch_fwd_t<f16>(qkv, out, lse, B, Tn, H, st);
+    if (dtype == MFVIT_BF16) return launch_fwd_t<bf16, 2>(qkv, out, lse, B, Tn, H, st);
+    if (dtype == MFVIT_BF16X3) return launch_fwd_t<sbf16, 2>(qkv, out, lse, B, Tn, H, st);
+    if (dtype == MFVIT_F16) return launch_fwd_t<f16, 2>(qkv, out, lse, B, Tn, H, st);
+    if (dtype == MFVIT_X3F16) return parts_fwd() == 1 ? launch_fwd_t<sf16, 1>(qkv, out, lse, B, Tn, H, st) : launch_fwd_t<sf16, 2>(qkv, out, lse, B, Tn, H, st);
     return MFVIT_EINVAL;
 }
 int attn_bwd_mfma(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
                   hipStream_t st) {
-    if (dtype == MFVIT_BF16) return launch_bwd_t<bf16>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
-    if (dtype == MFVIT_BF16X3) return launch_bwd_t<sbf16>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
-    if (dtype == MFVIT_F16) return launch_bwd_t<f16>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+    if (dtype == MFVIT_BF16) return launch_bwd_t<bf16, 2>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+    if (dtype == MFVIT_BF16X3) return launch_bwd_t<sbf16, 2>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+    if (dtype == MFVIT_F16) return launch_bwd_t<f16, 2>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+    if (dtype == MFVIT_X3F16)
+        return parts_bwd() == 1 ? launch_bwd_t<sf16, 1>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st)
+                                : launch_bwd_t<sf16, 2>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
     return MFVIT_EINVAL;
 }
 

@@ -36,8 +36,15 @@ constexpr int WAVE = 64;
 // 32-wide k group of both parts, and a head_dim-32 attention head's row piece is one such group.  Leading dimensions of split
 // tensors are given in STORAGE elements (twice the logical width).
 struct sbf16 { bf16 v; };
+// SPLIT fp16 (dtype tag MFVIT_X3F16, the qkv tensor of the attention core in bf16x3 mode only): the same I32 layout with hi = f16(x),
+// lo = f16(x - hi) - 22 mantissa bits for |x| >= 2^-2, an absolute floor of 2^-25 below that, |x| <= 65504.  The attention kernels take q, k, v
+// in this form so that the probabilities P (in [0, 2^14]) and the scaled score gradients dS can feed the f16 MFMA: their hi / lo split is
+// one packed conversion + one mixed-precision FMA per element (v_cvt_pk_f16_f32, v_fma_mixlo/hi_f16) instead of convert, shift / mask,
+// subtract, convert (attention_mfma.hip).
+struct sf16 { _Float16 v; };
 template <typename T> struct is_split { static constexpr bool value = false; };
 template <> struct is_split<sbf16> { static constexpr bool value = true; };
+template <> struct is_split<sf16> { static constexpr bool value = true; };
 // storage elements per logical element (1, or 2 for split tensors)
 template <typename T> struct elems_per { static constexpr int value = is_split<T>::value ? 2 : 1; };
 // storage column of the hi part of logical column n (lo part: + 32)
@@ -89,10 +96,12 @@ template <typename T> struct Vec8;
 template <> struct Vec8<bf16> { typedef bf16x8 type; };
 template <> struct Vec8<sbf16> { typedef bf16x8 type; };
 template <> struct Vec8<f16> { typedef f16x8 type; };
+template <> struct Vec8<sf16> { typedef f16x8 type; };
 template <typename T> struct Vec4;
 template <> struct Vec4<bf16> { typedef bf16x4 type; typedef bf16 elem; };
 template <> struct Vec4<sbf16> { typedef bf16x4 type; typedef bf16 elem; };
 template <> struct Vec4<f16> { typedef f16x4 type; typedef f16 elem; };
+template <> struct Vec4<sf16> { typedef f16x4 type; typedef f16 elem; };
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16 x) { return (float)x; }
@@ -118,10 +127,11 @@ template <typename T> __device__ __forceinline__ void store_elem_pair(T* row0, T
         row0[n] = v0;
         row1[n] = v1;
     } else if constexpr (is_split<T>::value) {
-        bf16 h0, h1, l0, l1;
-        cvt_pair<bf16, true>(v0, v1, h0, h1, l0, l1);
-        bf16* r0 = (bf16*)row0 + split_col(n);
-        bf16* r1 = (bf16*)row1 + split_col(n);
+        typedef typename Vec4<T>::elem E;
+        E h0, h1, l0, l1;
+        cvt_pair<E, true>(v0, v1, h0, h1, l0, l1);
+        E* r0 = (E*)row0 + split_col(n);
+        E* r1 = (E*)row1 + split_col(n);
         r0[0] = h0;
         r0[32] = l0;
         r1[0] = h1;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
     for (int j = 0; j < Loop::TN; ++j) {
         csums[j] = 0.f;
         const int n = n0 + (wn * Loop::TN + j) * 32 + (lane & 31);
-        bj[j] = ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) && p.bias) ? p.bias[n] : 0.f;
+        bj[j] = ((EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_X3F16) && p.bias) ? p.bias[n] : 0.f;
     }
     if constexpr (EPI == EPI_GELU_BWD) {
         // aux = act'(pre-activation) saved by the forward: its tile comes in with 16-byte reads, every lane multiplies its accumulators in
@@ -149,6 +149,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
                         acc[i][j][r + 1] = fmaxf(v1, 0.f);
                         store_elem_pair<AX>((AX*)trow(i, r, AROWB + 16), (AX*)trow(i, r + 1, AROWB + 16), ecol(j), v0 > 0.f ? 1.f : 0.f,
                                             v1 > 0.f ? 1.f : 0.f);         // out0 = relu'(pre) (fuseattention.py:69: nn.ReLU)
+                    } else if (EPI == EPI_BIAS_X3F16) {             // the same tile bytes, hi / lo parts in fp16 (the attention core's operand format)
+                        store_elem_pair<sf16>((sf16*)trow(i, r, ROWB + 16), (sf16*)trow(i, r + 1, ROWB + 16), ecol(j), v0, v1);
                     } else {
                         store_elem_pair<T>((T*)trow(i, r, ROWB + 16), (T*)trow(i, r + 1, ROWB + 16), ecol(j), v0, v1);
                     }
@@ -1228,6 +1230,7 @@ int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
         case EPI_GELU_BWD: return tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
         case EPI_NONE: return tile_by_dtype<EPI_NONE>(dtype, p, st);
         case EPI_BIAS_RELU: return tile_by_dtype<EPI_BIAS_RELU>(dtype, p, st);
+        case EPI_BIAS_X3F16: return dtype == MFVIT_BF16X3 ? launch_tile<sbf16, EPI_BIAS_X3F16>(p, st) : MFVIT_EINVAL;
     }
     return MFVIT_EINVAL;
 }

@@ -4,7 +4,8 @@
 
 namespace mfvit {
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GELU_BWD = 2, EPI_NONE = 3, EPI_BIAS_RELU = 4 };   // 4: out0 = relu'(pre), out1 = relu(pre)
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GELU_BWD = 2, EPI_NONE = 3, EPI_BIAS_RELU = 4,    // 4: out0 = relu'(pre), out1 = relu(pre)
+       EPI_BIAS_X3F16 = 5 };                                                                  // 5: bias, output written as split FP16 (sbf16 inputs only: qkv)
 enum { REPI_RES_LN = 0, REPI_LNBWD_RES = 1 };
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st);
@@ -37,14 +38,11 @@ int attn_fwd_exact(int dtype, const void* qkv, void* out, float* lse, int B, int
 int attn_bwd_exact(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
                    int H, int HD, hipStream_t st);
 
+// dtype of the qkv tensor the attention kernels want for activations of `dtype` (MFVIT_X3F16 for split bf16 where the whole-head kernels apply)
+int attn_qkv_dtype(int dtype, int Tn, int HD);
 int attn_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HD, hipStream_t st);
 int attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
              int H, int HD, hipStream_t st);
-
-// mhsa_fused.hip: QKV projection + attention core in one workgroup per (image, head) (head_dim 32, T <= 256; 16-bit types and split bf16)
-bool mhsa_fused_supported(int dtype, int Tn, int HDim, int D);
-int mhsa_fused_fwd(int dtype, const void* x, long ldx, const void* wqkv, long ldw, const float* bias, void* qkv_out, void* out, float* lse, int B,
-                   int Tn, int H, int D, hipStream_t st);
 
 int im2col16(int dtype, const float* img, void* P, int B, int H, int W, hipStream_t st);
 int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long ld1, int mod1, float* xout, long ldx, void* y, long ldy,

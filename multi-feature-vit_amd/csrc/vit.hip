@@ -256,12 +256,12 @@ SideStream& side_stream(hipStream_t caller) {
 
 extern "C" {
 
-int mfvit_abi_version(void) { return 3; }
+int mfvit_abi_version(void) { return 4; }
 int mfvit_set_wgrad_stream(int enabled) {
     g_wgrad_stream.store(enabled ? 1 : 0, std::memory_order_relaxed);
     return MFVIT_OK;
 }
-const char* mfvit_build_info(void) { return "libmfvit_hip gfx950 (MFMA bf16 | split-bf16 x3 | f16 32x32x16, f32 32x32x2), wave64, abi 2"; }
+const char* mfvit_build_info(void) { return "libmfvit_hip gfx950 (MFMA bf16 | split-bf16 x3 | f16 32x32x16, f32 32x32x2), wave64, abi 4"; }
 
 size_t mfvit_vit_param_count(const mfvit_vit_cfg* cfg) {
     Dims d;
@@ -369,16 +369,8 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
         char* b = blk(l);
         const float* pb = pblk(l);
         const char* sb = sblk(l);
-        // MFVIT_MHSA_FUSED: 0 = separate qkv GEMM + attention core (default), 1 = the fused kernel (mhsa_fused.hip) wherever it applies,
-        // 2 = the fused kernel only where qkv need not be kept (no-grad forwards: momentum encoder, frozen backbones)
-        // Default (unset): 2 for split bf16, 0 otherwise - measured at the bench shape (B = 128, T = 197): bf16 fused 66.2 us without / 78.8 us
-        // with the qkv store against 37.9 + 28.5 us separate; split bf16 142.4 / 176.8 us against 92.9 + 62.6 us.
-        static const int fused_env = [] { const char* ev = getenv("MFVIT_MHSA_FUSED"); return ev ? atoi(ev) : -1; }();
-        const int fused_mode = fused_env >= 0 ? fused_env : (d.dtype == MFVIT_BF16X3 ? 2 : 0);
-        if (hw && fused_mode && (fused_mode == 1 || !d.save) && !(d.p_attn > 0.f) && mhsa_fused_supported(d.dtype, d.T, d.HD, d.D)) {
-            MFVIT_TRY(mhsa_fused_fwd(d.dtype, b + W.y1, D * e, sb + S.qkv_w, D * e, pb + L.qkv_b, d.save ? b + W.qkv : nullptr, b + W.attn,
-                                     (float*)(b + W.lse), d.B, d.T, d.H, d.D, st));
-        } else {
+        // qkv tensor format: split FP16 for the whole-head attention kernels in bf16x3 mode (attention_mfma.hip), the activation dtype otherwise
+        const int qdt = d.p_attn > 0.f ? d.dtype : attn_qkv_dtype(d.dtype, d.T, d.HD);
         {   // qkv = y1 Wqkv^T + b
             GemmP p = zero_gemm();
             p.A = b + W.y1; p.lda = D * e;
@@ -386,15 +378,14 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
             p.M = d.M; p.N = 3 * d.D; p.K = d.D;
             p.bias = pb + L.qkv_b;
             p.out0 = b + W.qkv; p.ldo0 = 3 * D * e;
-            MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS, p, st));
+            MFVIT_TRY(gemm_nt_tile(d.dtype, qdt == MFVIT_X3F16 ? EPI_BIAS_X3F16 : EPI_BIAS, p, st));
         }
         if (d.p_attn > 0.f) {
             if (!attn_tiled_supported(d.dtype, d.T, d.HD)) return MFVIT_ENOSYS;
             MFVIT_TRY(attn_fwd_tiled_drop(d.dtype, b + W.qkv, b + W.attn, (float*)(b + W.lse), d.B, d.T, d.H, d.HD,
                                           make_drop(d.p_attn, d.seed, site(l, 2)), st));
         } else {
-            MFVIT_TRY(attn_fwd(d.dtype, b + W.qkv, b + W.attn, (float*)(b + W.lse), d.B, d.T, d.H, d.HD, st));
-        }
+            MFVIT_TRY(attn_fwd(qdt, b + W.qkv, b + W.attn, (float*)(b + W.lse), d.B, d.T, d.H, d.HD, st));
         }
         {   // xmid = x + attn Wproj^T + b ; y2 = LN2(xmid)
             GemmP p = zero_gemm();
@@ -630,7 +621,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 MFVIT_TRY(attn_bwd_tiled_drop(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, d.B, d.T, d.H, d.HD,
                                               make_drop(d.p_attn, d.seed, site(l, 2)), st));
             else
-            MFVIT_TRY(attn_bwd(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, nullptr,
+            MFVIT_TRY(attn_bwd(attn_qkv_dtype(d.dtype, d.T, d.HD), b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, nullptr,
                                d.B, d.T, d.H, d.HD, st));
             MFVIT_TRY(fork());
             {   // dWqkv += dqkv^T y1 ; d qkv_b += column sums of dqkv (ones-fragment MFMA inside the wgrad kernel)
@@ -734,7 +725,7 @@ int mfvit_eval_counts(const float* scores, int64_t ld, const int64_t* labels, in
 int mfvit_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* y,
                      int64_t ldy, void* y2, int64_t ldy2, int M, int N, int K, mfvit_stream_t stream) {
     if (!x || !w || (!y && epilogue != EPI_BIAS_GELU)) return MFVIT_EINVAL;      // GELU: y = NULL skips the saved derivative
-    if (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU && epilogue != EPI_NONE) return MFVIT_EINVAL;
+    if (epilogue != EPI_BIAS && epilogue != EPI_BIAS_GELU && epilogue != EPI_NONE && epilogue != EPI_BIAS_X3F16) return MFVIT_EINVAL;
     if (epilogue == EPI_BIAS_GELU && !y2) return MFVIT_EINVAL;
     GemmP p = zero_gemm();
     p.A = x; p.lda = ldx; p.W = w; p.ldw = ldw; p.M = M; p.N = N; p.K = K;
@@ -803,12 +794,7 @@ int mfvit_attention_fwd(int dtype, const void* qkv, void* out, float* lse, int B
     if (!qkv || !out || !lse || B <= 0 || T <= 0 || H <= 0) return MFVIT_EINVAL;
     return attn_fwd(dtype, qkv, out, lse, B, T, H, head_dim, (hipStream_t)stream);
 }
-int mfvit_mhsa_fused_fwd(int dtype, const void* x, int64_t ldx, const void* wqkv, int64_t ldw, const float* bias, void* qkv_out, void* out,
-                         float* lse, int B, int T, int H, int head_dim, int D, mfvit_stream_t stream) {
-    if (!x || !wqkv || !out || !lse || B <= 0 || H <= 0) return MFVIT_EINVAL;
-    if (!mhsa_fused_supported(dtype, T, head_dim, D)) return MFVIT_ENOSYS;
-    return mhsa_fused_fwd(dtype, x, ldx, wqkv, ldw, bias, qkv_out, out, lse, B, T, H, D, (hipStream_t)stream);
-}
+int mfvit_attention_qkv_dtype(int dtype, int T, int head_dim) { return attn_qkv_dtype(dtype, T, head_dim); }
 int mfvit_attention_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias_qkv,
                         int B, int T, int H, int head_dim, mfvit_stream_t stream) {
     if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || T <= 0 || H <= 0) return MFVIT_EINVAL;

@@ -14,8 +14,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_size
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MFVIT_LIB") or os.path.join(_HERE, "libmfvit_hip.so")   # MFVIT_LIB: experiment builds
 
-F32, BF16, BF16X3, F16 = 0, 1, 2, 3
-EPI_BIAS, EPI_BIAS_GELU, EPI_NONE = 0, 1, 3
+F32, BF16, BF16X3, F16, X3F16 = 0, 1, 2, 3, 4   # X3F16: split fp16, the qkv operand of the attention core in bf16x3 mode
+EPI_BIAS, EPI_BIAS_GELU, EPI_NONE, EPI_BIAS_X3F16 = 0, 1, 3, 5
 
 
 class VitCfg(Structure):
@@ -57,7 +57,7 @@ SIGNATURES = {
     "mfvit_linear_dgrad_ln_bwd": (I, [I, P, L, P, L, P, P, P, P, P, P, P, P, P, P, I, I, P]),
     "mfvit_attention_fwd": (I, [I, P, P, P, I, I, I, I, P]),
     "mfvit_attention_bwd": (I, [I, P, P, P, P, P, P, I, I, I, I, P]),
-    "mfvit_mhsa_fused_fwd": (I, [I, P, L, P, L, P, P, P, P, I, I, I, I, I, P]),
+    "mfvit_attention_qkv_dtype": (I, [I, I, I]),
     "mfvit_attention_drop_fwd": (I, [I, P, P, P, I, I, I, I, F, c_uint64, c_uint32, P]),
     "mfvit_attention_drop_bwd": (I, [I, P, P, P, P, P, I, I, I, I, F, c_uint64, c_uint32, P]),
     "mfvit_dropout_mask": (I, [F, c_uint64, c_uint32, L, P, P]),

@@ -6,7 +6,7 @@ launches on torch's current HIP stream and returns freshly allocated tensors own
 import torch
 
 from . import _lib
-from ._lib import BF16, BF16X3, EPI_BIAS, EPI_BIAS_GELU, EPI_NONE, F16, F32, check, lib, ptr, require_cuda, stream
+from ._lib import BF16, BF16X3, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_X3F16, EPI_NONE, F16, F32, X3F16, check, lib, ptr, require_cuda, stream
 
 _TORCH_OF = {BF16: torch.bfloat16, BF16X3: torch.bfloat16, F16: torch.float16, F32: torch.float32}
 
@@ -44,7 +44,24 @@ def split_unpack(s):
     return (g[..., 0, :] + g[..., 1, :]).reshape(*lead, N2 // 2)
 
 
-def linear_fwd(x, w, bias=None, gelu=False, split=False, want_grad=True):
+def split_pack_f16(x):
+    """f32 [..., N] -> split-FP16 storage [..., 2N] (dtype tag X3F16: the attention core's qkv operand in bf16x3 mode): the I32 layout
+    of split_pack with hi = f16(x), lo = f16(x - hi)."""
+    x = x.float()
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    *lead, N = x.shape
+    g = torch.stack([hi.reshape(*lead, N // 32, 32), lo.reshape(*lead, N // 32, 32)], dim=-2)
+    return g.reshape(*lead, 2 * N).contiguous()
+
+
+def attention_qkv_dtype(code, T, head_dim):
+    """dtype tag of the qkv tensor the encoder hands the attention core for activations of dtype `code` (X3F16 for BF16X3 where the
+    whole-head kernels apply)."""
+    return lib().mfvit_attention_qkv_dtype(code, T, head_dim)
+
+
+def linear_fwd(x, w, bias=None, gelu=False, split=False, want_grad=True, qkv_f16=False):
     """y = x @ w.T + bias (x [M,K], w [N,K] of the same dtype).  gelu=True returns (gelu'(y), gelu(y)); want_grad=False skips the
     derivative (returns (None, gelu(y))).  split=True: x, w and the results are split-bf16 storage ([M,2K], [N,2K] -> [M,2N]) - except
     gelu'(y), which the library keeps as plain fp16 [M,N] for split tensors (it only ever multiplies a gradient)."""
@@ -54,6 +71,8 @@ def linear_fwd(x, w, bias=None, gelu=False, split=False, want_grad=True):
     M, K = x.shape[0], x.shape[1] // e
     N = w.shape[0]
     epi = EPI_BIAS_GELU if gelu else (EPI_BIAS if bias is not None else EPI_NONE)
+    if qkv_f16:   # split inputs only: y comes back as split FP16 (same shape; a float16 view of the storage)
+        epi = EPI_BIAS_X3F16
     if gelu:
         y2 = torch.empty(M, N * e, device=x.device, dtype=x.dtype)
         y = torch.empty(M, N, device=x.device, dtype=torch.float16 if split else x.dtype) if want_grad else None
@@ -62,6 +81,8 @@ def linear_fwd(x, w, bias=None, gelu=False, split=False, want_grad=True):
         y, y2, ldy = torch.empty(M, N * e, device=x.device, dtype=x.dtype), None, N * e
     check(lib().mfvit_linear_fwd(code, epi, ptr(x), x.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(y), ldy, ptr(y2), N * e, M, N, K,
                                  stream()), "mfvit_linear_fwd")
+    if qkv_f16:
+        return y.view(torch.float16)
     return (y, y2) if gelu else y
 
 
@@ -157,42 +178,34 @@ def linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, gamma, dres, want_copy=True, spli
     return dx, dx_t, dgamma, dbeta, dcol
 
 
+def _attn_code(qkv, split):
+    # a float16 tensor in the split layout is the X3F16 qkv operand (out / dout / dqkv: split bf16)
+    if split and qkv.dtype == torch.float16:
+        return X3F16, torch.bfloat16
+    return _code_of(qkv, split), qkv.dtype
+
+
 def attention_fwd(qkv, heads, split=False):
-    """qkv [B,T,3*D] (layout [B][T][3][H][d]) -> (out [B,T,D], lse [B,H,T]).  split=True: split-bf16 storage ([B,T,6*D] -> [B,T,2*D])."""
+    """qkv [B,T,3*D] (layout [B][T][3][H][d]) -> (out [B,T,D], lse [B,H,T]).  split=True: split-bf16 storage ([B,T,6*D] -> [B,T,2*D]);
+    split=True with a float16 qkv: split-FP16 qkv (split_pack_f16), split-bf16 out."""
     require_cuda(qkv)
-    code = _code_of(qkv, split)
+    code, odt = _attn_code(qkv, split)
     e = 2 if split else 1
     B, T, D3 = qkv.shape
     D = D3 // (3 * e)
-    out = torch.empty(B, T, D * e, device=qkv.device, dtype=qkv.dtype)
+    out = torch.empty(B, T, D * e, device=qkv.device, dtype=odt)
     lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
     check(lib().mfvit_attention_fwd(code, ptr(qkv), ptr(out), ptr(lse), B, T, heads, D // heads, stream()), "mfvit_attention_fwd")
     return out, lse
 
 
-def mhsa_fused_fwd(x, wqkv, bias, heads, want_qkv=True, split=False):
-    """Fused qkv projection + attention core: x [B,T,D], wqkv [3D,D] (both of the same 16-bit type; split: storage layout), bias [3D] f32
-    -> (out [B,T,D], lse [B,H,T], qkv [B,T,3D] or None)."""
-    require_cuda(x, wqkv, bias)
-    code = _code_of(x, split)
-    e = 2 if split else 1
-    B, T, De = x.shape
-    D = De // e
-    out = torch.empty(B, T, D * e, device=x.device, dtype=x.dtype)
-    lse = torch.empty(B, heads, T, device=x.device, dtype=torch.float32)
-    qkv = torch.empty(B, T, 3 * D * e, device=x.device, dtype=x.dtype) if want_qkv else None
-    check(lib().mfvit_mhsa_fused_fwd(code, ptr(x), x.stride(1), ptr(wqkv), wqkv.stride(0), ptr(bias), ptr(qkv), ptr(out), ptr(lse), B, T, heads,
-                                     D // heads, D, stream()), "mfvit_mhsa_fused_fwd")
-    return out, lse, qkv
-
-
 def attention_bwd(qkv, out, dout, lse, heads, want_dbias=True, split=False):
     require_cuda(qkv, out, dout, lse)
-    code = _code_of(qkv, split)
+    code, odt = _attn_code(qkv, split)
     e = 2 if split else 1
     B, T, D3 = qkv.shape
     D = D3 // (3 * e)
-    dqkv = torch.empty_like(qkv)
+    dqkv = torch.empty(qkv.shape, device=qkv.device, dtype=odt)
     dbias = torch.zeros(3 * D, device=qkv.device, dtype=torch.float32) if want_dbias else None
     check(lib().mfvit_attention_bwd(code, ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(dbias), B, T, heads, D // heads,
                                     stream()), "mfvit_attention_bwd")
@@ -216,11 +229,11 @@ def attention_drop_fwd(qkv, heads, p, seed, site, split=False):
 
 def attention_drop_bwd(qkv, out, dout, lse, heads, p, seed, site, split=False):
     require_cuda(qkv, out, dout, lse)
-    code = _code_of(qkv, split)
+    code, odt = _attn_code(qkv, split)
     e = 2 if split else 1
     B, T, D3 = qkv.shape
     D = D3 // (3 * e)
-    dqkv = torch.empty_like(qkv)
+    dqkv = torch.empty(qkv.shape, device=qkv.device, dtype=odt)
     check(lib().mfvit_attention_drop_bwd(code, ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, T, heads, D // heads, float(p), int(seed),
                                          int(site), stream()), "mfvit_attention_drop_bwd")
     return dqkv

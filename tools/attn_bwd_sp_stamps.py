@@ -13,6 +13,9 @@ B, T, H, D = 128, 197, 12, 384
 x = torch.randn(B, T, 3 * D, device=dev)
 d = torch.randn(B, T, D, device=dev)
 qkv, do = ops.split_pack(x.view(-1, 3 * D)).view(B, T, -1), ops.split_pack(d.view(-1, D)).view(B, T, -1)
+if os.environ.get("STAMP_QKV", "f16") == "f16":     # the encoder's format in bf16x3 mode (MFVIT_X3F16); STAMP_QKV=bf16: the split-bf16 kernels
+    qkv = ops.split_pack_f16(x.view(-1, 3 * D).cpu()).view(B, T, -1).to(dev)
+print("qkv", qkv.dtype, "parts bwd", os.environ.get("MFVIT_ATTN_PB", "default"))
 o, lse = ops.attention_fwd(qkv, H, split=True)
 for _ in range(3):
     ops.attention_bwd(qkv, o, do, lse, H, want_dbias=False, split=True)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# builds multi-feature-vit_amd/build/libmfvit_attnvar_$1.so with attention_mfma.hip compiled with extra defines $2.. (experiments only)
+# usage: build_attn_variant_lib.sh <name> [defs ...]  ->  multi-feature-vit_amd/build/variants/libmfvit_<name>.so: the shipping objects with
+# attention_mfma.hip recompiled under the given -D switches (timing experiments, loaded through MFVIT_LIB).  Diagnostic only - never shipped.
 set -e
-R=$(cd $(dirname $0)/.. && pwd)
-B=$R/multi-feature-vit_amd/build
-tag=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize "$@" -c $R/multi-feature-vit_amd/csrc/attention_mfma.hip -o $B/attention_mfma_var_$tag.o
-objs=$(ls $B/*.o | grep -v "attention_mfma.o" | grep -v attention_mfma_stamp | grep -v attention_mfma_var)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $B/libmfvit_attnvar_$tag.so $objs $B/attention_mfma_var_$tag.o
+R=$(cd $(dirname $0)/.. && pwd); B=$R/multi-feature-vit_amd/build; V=$B/variants; n=$1; shift
+mkdir -p $V
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize "$@" -c $R/multi-feature-vit_amd/csrc/attention_mfma.hip -o $V/attention_mfma_$n.o
+objs=$(ls $B/*.o | grep -v "attention_mfma")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libmfvit_$n.so $objs $V/attention_mfma_$n.o
