@@ -312,11 +312,11 @@ def test_fp16_query_chain_gradients_with_injected_dq():
     HIP `fp16` mode against the float64 oracle, per-tensor L2 error of every gradient, in TWO forms:
       * against the plain float64 oracle: bound 8e-2.  Round 4 measured 0.4 % on the predictor's last Linear and 4.5 - 7 % on everything
         upstream of the predictor's ReLU - a jump across ONE Linear-dgrad + BatchNorm-backward + ReLU that a wrong term would also produce;
-      * against the float64 oracle run with the HIP path's OWN ReLU masks (forward hooks on the four fused BatchNorm + ReLU modules; the oracle
+      * against the float64 oracle run with the HIP path's OWN ReLU masks (forward hooks on the three fused BatchNorm + ReLU modules; the oracle
         multiplies by them instead of taking its own ReLU, oracle/ref_moco.py::mlp_forward(masks=)), so that pre-activations within an fp16
-        rounding of zero cannot fall on different sides in the two computations: bound 2e-2 per tensor, the uniform fp16 level.  If the jump
-        were a wrong term of the fp16 BatchNorm backward / dgrad it would survive the shared masks; tests/test_bn_gpu.py pins the kernels
-        themselves in fp16.
+        rounding of zero cannot fall on different sides in the two computations: bound 1e-2 per tensor.  MEASURED (round 5): 4.1e-3 at worst,
+        on EVERY tensor, the predictor's first Linear (3.5e-3) and the encoder included - the 11 x jump is the masks and nothing else; a wrong term
+        of the fp16 BatchNorm backward / dgrad would survive shared masks.  tests/test_bn_gpu.py pins the BatchNorm kernels themselves in fp16.
     Recorded beside both: the operand-rounding oracle (oracle/ref_vit.py::rounded_matmul)."""
     from mfvit import mlp as hip_mlp
     depth, mlp_dim, dim, n = 2, 512, 256, 32
@@ -388,7 +388,7 @@ def test_fp16_query_chain_gradients_with_injected_dq():
         f"{sorted(allm, reverse=True)[:6]}")
     assert all(l2 == l2 for l2, _ in allv), "non-finite gradient"
     assert e_q < 1e-2 and worst64[1] < 8e-2, (e_q, worst64)
-    assert worst64m[1] < 2e-2, worst64m
+    assert worst64m[1] < 1e-2, worst64m      # measured: 4.1e-3 (every tensor), against 4.5 - 7 % with the oracle's own masks
 
 
 def test_moco_v3_symmetric_loss_vs_oracle_and_golden():
