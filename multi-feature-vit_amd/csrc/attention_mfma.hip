@@ -1066,7 +1066,9 @@ __global__ __launch_bounds__(512) void attn_bwd_mfma_kernel(const typename Vec4<
 }
 
 // X^T[d][col] accumulator tile (col on the lane) -> rows of a [.., HD] tensor of T as 16-byte stores: the half-waves exchange their 8-byte
-// pieces (v_permlane32_swap) so that every lane owns 16 contiguous bytes of its row
+// pieces (v_permlane32_swap) so that every lane owns 16 contiguous bytes of its row.  (Plain stores on purpose: the system-scope streaming form of
+// common.cuh::store16_stream, which saves the tile GEMMs their write-allocate fetches, is acknowledged only when the data is out of the L2 - and the
+// persistent kernels WAIT for their stores (vmcnt(0) before the next pair's LDS-DMA): single-pass backward 95 -> 133 us with it, round 5.)
 template <typename T> __device__ __forceinline__ void store_tile_T16(typename Vec4<T>::elem* row_ptr, const f32x16& acc, float mul, int lane) {
     typedef typename Vec4<T>::elem E;
     unsigned hi[4][2], lo[4][2];

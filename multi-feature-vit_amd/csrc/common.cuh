@@ -232,6 +232,29 @@ template <int NT> __device__ __forceinline__ float block_max(float v, float* scr
     return t;
 }
 
+// Streaming 16-byte OUTPUT store (`sc0 sc1 nt`: system scope, non-temporal).  Round 5, measured with FETCH_SIZE: with plain or nt-only stores the L2
+// FETCHES every output line it allocates (write-allocate: fc1 + GELU read 135 MB from HBM for 41 MB of operands, the fc2 data gradient 221 for 119 -
+// the "1.4 - 1.5 x wasted traffic" of rounds 3 - 4 was never operand re-reads); with the scope bits the line goes through without the fetch: 56 / 152 MB,
+// -3 ... -4 % per launch (profiles/r05_tile_store_policy.txt).  For tensors the NEXT kernel streams from HBM anyway (hundreds of MB per launch).
+typedef unsigned int u32x4_st __attribute__((ext_vector_type(4)));
+// (s_nop behind it: a vector-memory store of more than 64 bits reads its data registers late - the next write of those registers needs wait states
+// (CDNA3 ISA 4.5, "VMEM store more than 8 bytes followed by a write of the write-data VGPRs").  The compiler inserts them for the stores it knows;
+// it cannot see into an asm statement.  Without them the fc1 epilogue's second phase overwrote gelu' values still waiting to be read: ~8,000 wrong
+// elements per launch at M = 25,216, different ones every run - tests/test_precision_gpu.py::test_linear_fwd caught it.)
+__device__ __forceinline__ void store16_stream(void* gp, u32x4_st v) {
+#ifdef MFVIT_PLAIN_OUTPUT_STORES        // A/B builds only (tools/build_variant_lib.sh): the round-4 behaviour
+    __builtin_nontemporal_store(v, (u32x4_st*)gp);
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(gp), "v"(v) : "memory");
+#endif
+}
+__device__ __forceinline__ void store8_stream(void* gp, uint2 v) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(gp), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store4_stream(void* gp, float v) {
+    asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" ::"v"(gp), "v"(v) : "memory");
+}
+
 // XCD-aware bijective block remap (8 XCDs, blocks dealt round-robin): blocks that are neighbours in the
 // remapped id share an XCD / L2.  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -23,9 +23,11 @@ namespace mfvit {
 
 
 // ------------------------------------------------------------------------------------------ tile kernel
-template <typename T, int EPI, int DEEP = 0>     // DEEP: K tiles kept in flight by the main loop (0: NtLoop's one; 2: NtLoopDeep, 16-bit types)
-__global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 workgroups per CU (64 - 68 KB of LDS each): register budget 256 per wave
-    constexpr int BM = 128, BN = 128, BKB = 128, WM = 2, WN = 2;
+// WIDE (round-5 experiment, MFVIT_NT_WIDE=1): an N-wide 128 x 256 tile of 8 waves (2 x 4, 64 x 64 per wave as before), ONE workgroup per CU - half
+// the A re-reads across the N tiles of a row block and 3/4 of the staged operand bytes per MFMA (VERDICT r4 task 2b)
+template <typename T, int EPI, int DEEP = 0, int WIDE = 0>     // DEEP: K tiles kept in flight by the main loop (0: NtLoop's one; 2: NtLoopDeep, 16-bit types)
+__global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 workgroups per CU (64 - 68 KB of LDS each): register budget 256 per wave
+    constexpr int BM = 128, BN = WIDE ? 256 : 128, BKB = 128, WM = 2, WN = WIDE ? 4 : 2, NTHR = WM * WN * 64;
     typedef NtLoop<T, BM, BN, BKB, WM, WN> Loop;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     apply_batch<T>(p, sizeof(T));
@@ -74,17 +76,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
     auto ecol = [&](int j) -> int { return (wn * Loop::TN + j) * 32 + (lane & 31); };   // LOGICAL column inside the tile
     // tile rows of RB bytes (LDS pitch RB + 16)  <->  global rows (ld_bytes apart, the tile's columns start col_bytes into the row)
     auto copy_tile = [&](auto rb_c, auto to_global_c, char* g, long ld_bytes, long col_bytes) {
-        constexpr int RB = decltype(rb_c)::value, CP = RB / 16, NC = BM * CP / 256;
+        constexpr int RB = decltype(rb_c)::value, CP = RB / 16, NC = BM * CP / NTHR;
         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const int q = tid + i * 256, row = q / CP, c = q % CP;
+            const int q = tid + i * NTHR, row = q / CP, c = q % CP;
             int m = m0 + row;
             m = m < p.M ? m : p.M - 1;
             u32x4* gp = (u32x4*)(g + (long)m * ld_bytes + col_bytes + 16 * c);
             u32x4* lp = (u32x4*)(tile + row * (RB + 16) + 16 * c);
             if constexpr (decltype(to_global_c)::value) {
-                if (p.rows_per_wg == 1) __builtin_nontemporal_store(*lp, gp);   // (field unused by the tile kernel otherwise) streaming output:
+                if (p.rows_per_wg >= 2) {                                        // default (2): system-scope streaming stores - no write-allocate fetch (common.cuh)
+                    const u32x4 v = *lp;
+                    if (p.rows_per_wg == 2) store16_stream(gp, v);
+                    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(gp), "v"(v) : "memory");
+                } else
+                if (p.rows_per_wg == 1) __builtin_nontemporal_store(*lp, gp);   // (field unused by the tile kernel otherwise) nt only: MFVIT_NT_STORE=1
                 else *gp = *lp;                                                  // keeps the operand tiles in L2, see launch_tile
             } else {
                 *lp = *gp;
@@ -964,8 +971,9 @@ template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStrea
     if (std::is_same<T, bf16>::value && use_glds) p.y_f32 = 99;
     // Output tile stores marked non-temporal: the 58 - 310 MB a launch writes otherwise evict the A / W tiles the other N tiles of the
     // same rows are about to re-read (L2 hit rate of the operand reads 77 %).  Isolated qkv 80.7 -> 77.1 us, fc1 + GELU 157.5 -> 151.4 us.
-    static const int nt_store = [] { const char* e = getenv("MFVIT_NT_STORE"); return e ? atoi(e) : 1; }();      // A/B switch
-    p.rows_per_wg = nt_store ? 1 : 0;
+    static int nt_sw = INT_MIN;
+    const int nt_store = env_switch("MFVIT_NT_STORE", 2, nt_sw);      // A/B switch (0: plain stores, 1: nt, 2: sc0 sc1 nt (default), 3: sc1)
+    p.rows_per_wg = nt_store;
     const int nwg = (p.N / 128) * ((p.M + 127) / 128);
     constexpr int epi_bytes = 128 * (128 * (int)sizeof(T) * EP + 16);
     constexpr int lds_bytes = Loop::LDS_BYTES > epi_bytes ? Loop::LDS_BYTES : epi_bytes;
@@ -1005,6 +1013,25 @@ template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStrea
         }
     }
     MFVIT_LAUNCH((gemm_nt_tile_kernel<T, EPI>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(256), lds_bytes, st, p);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+// the N-wide experiment form of the split-bf16 tile kernel (see the kernel): N % 256 == 0, an even number of K tiles, 32-bit operand offsets
+template <int EPI> static int launch_tile_wide(const GemmP& pin, hipStream_t st) {
+    typedef sbf16 T;
+    typedef NtLoop<T, 128, 256, 128, 2, 4> Loop;
+    GemmP p = pin;
+    p.rows_per_wg = 2;
+    const int nk = p.K * 2 / Loop::BK;
+    const bool fits = (unsigned long long)(p.M - 1) * p.lda * 2 + 256 < (1ull << 32) && (unsigned long long)(p.N - 1) * p.ldw * 2 + 256 < (1ull << 32);
+    if (p.N % 256 || p.K * 2 % Loop::BK || nk < 2 || nk % 2 || !fits || p.M <= 0) return MFVIT_ENOSYS;
+    const int nwg = (p.N / 256) * ((p.M + 127) / 128);
+    constexpr int epi_bytes = 128 * (256 * 4 + 16);
+    constexpr int lds_bytes = Loop::LDS_BYTES > epi_bytes ? Loop::LDS_BYTES : epi_bytes;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI, 12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
+    MFVIT_LAUNCH((gemm_nt_tile_kernel<T, EPI, 12, 1>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(512), lds_bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -1218,12 +1245,25 @@ template <int REPI> static int row_by_dtype(int dtype, const GemmP& p, hipStream
 static int tn_by_dtype(int dtype, const GemmP& p, hipStream_t st) { MFVIT_BY_DTYPE(dtype, (launch_tn<TT>(p, st))) }
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
+    static int sw_wide = INT_MIN;      // round-5 experiment: the N-wide tile (MFVIT_NT_WIDE=1), see gemm_nt_tile_kernel
+    const bool wide = dtype == MFVIT_BF16X3 && env_switch("MFVIT_NT_WIDE", 0, sw_wide) != 0;
     if (epi == EPI_GELU_BWD && p.cpart && p.cs0) {
-        const int rc = tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
+        int rc = wide ? launch_tile_wide<EPI_GELU_BWD>(p, st) : MFVIT_ENOSYS;
+        if (rc == MFVIT_ENOSYS) rc = tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
         if (rc != MFVIT_OK) return rc;
         return colpart_reduce(p.cpart, (p.M + 127) / 128, p.N, 1, p.cs0, nullptr, nullptr, st);
     }
     if (gemm_nt_small_supported(dtype, epi, p)) return gemm_nt_small(epi, p, st);   // gemm_small.hip: f32, M <= 512
+    {   // the N-wide tile for the split-bf16 linears with N % 256 == 0 (falls through when it does not apply)
+        if (wide) {
+            int rc = MFVIT_ENOSYS;
+            if (epi == EPI_BIAS) rc = launch_tile_wide<EPI_BIAS>(p, st);
+            else if (epi == EPI_BIAS_GELU) rc = launch_tile_wide<EPI_BIAS_GELU>(p, st);
+            else if (epi == EPI_GELU_BWD) rc = launch_tile_wide<EPI_GELU_BWD>(p, st);
+            else if (epi == EPI_BIAS_X3F16) rc = launch_tile_wide<EPI_BIAS_X3F16>(p, st);
+            if (rc != MFVIT_ENOSYS) return rc;
+        }
+    }
     switch (epi) {
         case EPI_BIAS: return tile_by_dtype<EPI_BIAS>(dtype, p, st);
         case EPI_BIAS_GELU: return tile_by_dtype<EPI_BIAS_GELU>(dtype, p, st);

@@ -445,7 +445,7 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
             const u32x4 v = *(const u32x4 __attribute__((may_alias))*)(ybuf + row * YP + 16 * ch);
             int r = 16 * i0 + row;
             r = r < rows ? r : rows - 1;
-            __builtin_nontemporal_store(v, (u32x4*)((char*)out + (long)(m0 + r) * ldo * 2 + 16 * ch));
+            store16_stream((char*)out + (long)(m0 + r) * ldo * 2 + 16 * ch, v);
         }
         __syncthreads();
     };
@@ -503,7 +503,7 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int n = ncol0 + 16 * j;
-                if (xo) *(f32x4v*)(xo + m * (unsigned)p.ldo0 + n) = acc[i][j];
+                if (xo) store16_stream(xo + m * (unsigned)p.ldo0 + n, __builtin_bit_cast(u32x4_st, acc[i][j]));   // (64 contiguous bytes per row and instruction: the L2 would fetch the line)
                 const f32x4v g = *(const f32x4v*)(p.gamma + n), be = *(const f32x4v*)(p.beta + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] - mu[i]) * rs * g[r] + be[r];
@@ -689,7 +689,7 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
                     acc[i][j][r] = dx;
                     cx[j][r] += ok ? dx : 0.f;
                 }
-                if (dxo) *(f32x4v*)(dxo + (unsigned)row_of(i) * (unsigned)p.ldo0 + ncol0 + 16 * j) = acc[i][j];
+                if (dxo) store16_stream(dxo + (unsigned)row_of(i) * (unsigned)p.ldo0 + ncol0 + 16 * j, __builtin_bit_cast(u32x4_st, acc[i][j]));
             }
         }
         col_out(cx, 2, p.cs2);

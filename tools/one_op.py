@@ -21,9 +21,15 @@ if SPLIT:
     ops.linear_fwd, ops.linear_wgrad = functools.partial(_lf, split=True), functools.partial(_wg, split=True)
     ops.linear_res_ln_fwd, ops.linear_dgrad_ln_bwd = functools.partial(_rl, split=True), functools.partial(_db, split=True)
     ops.attention_fwd, ops.attention_bwd = functools.partial(_af, split=True), functools.partial(_ab, split=True)
+    ops.linear_dgrad_act = functools.partial(ops.linear_dgrad_act, split=True)
 if op == "qkv":
     x, w, b = r(M, D), r(3 * D, D, sc=.05), r(3 * D, dt=torch.float32)
-    fn = lambda: ops.linear_fwd(x, w, b)
+    fn = (lambda: ops.linear_fwd(x, w, b, qkv_f16=True)) if SPLIT else (lambda: ops.linear_fwd(x, w, b))   # bf16x3: the encoder's split-fp16 epilogue
+elif op == "fc2_dgrad":     # dX[M, 1536] = (dY[M, 384] W2) * gelu'(pre): the tile GEMM with the GELU-backward epilogue
+    x, w, b = r(M, D), r(4 * D, D, sc=.05), r(4 * D, dt=torch.float32)
+    dact, _ = ops.linear_fwd(x, w, b, gelu=True)
+    dy, wt = r(M, D), r(4 * D, D, sc=.05)
+    fn = lambda: ops.linear_dgrad_act(dy, wt, dact)
 elif op == "fc1":
     x, w, b = r(M, D), r(4 * D, D, sc=.05), r(4 * D, dt=torch.float32)
     fn = lambda: ops.linear_fwd(x, w, b, gelu=True)

@@ -6,7 +6,7 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
         k = row["Kernel_Name"]
         if "mfvit" not in k:
             continue
-        k = k.split("(")[0].replace("void mfvit::(anonymous namespace)::", "")[:60]
+        k = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void mfvit::", "")[:72]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 lines = []
 for k, cs in acc.items():
