@@ -47,7 +47,7 @@ typedef void* mfvit_stream_t; /* hipStream_t */
 #define MFVIT_X3F16 4
 
 /* ABI history: 3 = rounds 3 - 4.  4 (round 5, BREAKING): mfvit_linear_fwd_persistent / mfvit_linear_fwd_ws (dropped in round 4 without a
- * version bump) and mfvit_mhsa_fused_fwd are gone; MFVIT_X3F16, linear epilogue 5 and mfvit_attention_qkv_dtype are new. */
+ * version bump) and mfvit_mhsa_fused_fwd are gone; MFVIT_X3F16, linear epilogue 5, mfvit_attention_qkv_dtype and mfvit_adam_step_dev are new. */
 int mfvit_abi_version(void);
 const char* mfvit_build_info(void);
 
@@ -150,7 +150,7 @@ int mfvit_linear_wgrad_ws(int dtype, const void* dy, int64_t lddy, const void* x
 /* TWO weight gradients with the same reduction rows M and the same K in ONE launch (the encoder backward's default for dWqkv + dWproj,
  * the nn.Linear pair of the timm attention block, call sites crossvit_2vits_..._sum.py:128-135):
  *   dw_a[Na][K] += dy_a^T x_a ; dbias_a[Na] += column sums of dy_a (may be NULL) ; dw_b[Nb][K] += dy_b^T x_b.
- * 16-bit dtypes, M >= 4096, Na / Nb / K multiples of 128; anything else returns MFVIT_ENOSYS (the caller then issues two
+ * 16-bit dtypes, M >= 2048, Na / Nb / K multiples of 128; anything else returns MFVIT_ENOSYS (the caller then issues two
  * mfvit_linear_wgrad calls). */
 int mfvit_linear_wgrad_pair(int dtype, const void* dy_a, int64_t lddy_a, const void* x_a, int64_t ldx_a, float* dw_a, int64_t lddw_a, float* dbias_a,
                             int Na, const void* dy_b, int64_t lddy_b, const void* x_b, int64_t ldx_b, float* dw_b, int64_t lddw_b, int Nb, int M, int K,
@@ -289,6 +289,11 @@ int mfvit_prof_enable(int class_mask); /* bit c set = time class c; 0 = off */
  * MFVIT_WGRAD_STREAM=0).  0 serialises them on the caller's stream - used by bench.py's attribution pass so that a kernel's
  * event-timed duration is its own, not a share of a co-scheduled GPU.  Results are identical either way. */
 int mfvit_set_wgrad_stream(int enabled);
+/* How many independent kernel streams the caller runs side by side on this GPU (default 1: a kernel may size its grid for the whole chip).  The
+ * two-stream CA model sets 2 (both encoders at once, crossvit_2vits_..._sum.py:128-135 are independent): for SMALL problems the
+ * one-workgroup-per-CU kernels (row-complete GEMMs, weight gradients) then launch about half as many, longer workgroups, and the two encoders'
+ * kernels run beside each other.  A hint only: results do not depend on it beyond the summation order of the weight-gradient splits. */
+int mfvit_set_stream_share(int n);
 int mfvit_prof_collect(double* out, int ncls);
 const char* mfvit_prof_class_name(int cls);
 
@@ -336,6 +341,10 @@ int mfvit_lars_step(const int64_t* table, int nchunks, int ntensors, float* norm
                     float trust_coefficient, mfvit_stream_t stream);
 int mfvit_adam_step(const int64_t* table, int nchunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     mfvit_stream_t stream);
+/* The same update with the hyper-parameters in DEVICE memory - hyper[0..5] = lr, beta1, beta2, eps, weight_decay, step count (a float,
+ * counting from 1 at the first update) - for train steps captured into a HIP graph (a step number passed by value would freeze the bias
+ * correction at the capture's).  advance != 0: hyper[5] += 1 on the device before the update (once per optimizer step). */
+int mfvit_adam_step_dev(const int64_t* table, int nchunks, float* hyper, int advance, mfvit_stream_t stream);
 int mfvit_sgd_step(const int64_t* table, int nchunks, float lr, float momentum, float weight_decay, int first_step,
                    mfvit_stream_t stream);
 /* torch.cuda.amp.GradScaler.unscale_ over the same chunk table (MAIN_MOCO:349,546-548: scaler.scale(loss).backward();

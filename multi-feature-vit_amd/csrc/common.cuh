@@ -287,6 +287,13 @@ inline int device_cus() {
     }
     return cache[dev];
 }
+// How many independent kernel streams the caller runs side by side on this GPU (mfvit_set_stream_share; 1 = a kernel may take the whole chip).
+// The two-stream CA model sets 2: the one-workgroup-per-CU kernels then size their grids for HALF the chip when the problem is small - a row tile
+// streams the whole W[384][K] out of L2 whatever its height and a weight-gradient split costs a prologue and a round of atomics whatever its length,
+// so fewer, longer workgroups cost a launch little, and the other encoder's kernels run BESIDE it instead of behind it (round 5: B = 16 8.13 -> 7.23 ms,
+// B = 32 9.86 -> 8.78 ms per step; B = 128 unchanged: its tiles are taller than the floor anyway).
+int stream_share();
+
 // A/B switch from the environment: read ONCE per process into the caller's static cache (INT_MIN = unread), or at every launch when
 // MFVIT_AB_LIVE=1 (the in-process A/B tools and the kernel-variant tests set it) - no getenv on the launch path otherwise.
 inline int env_switch(const char* name, int dflt, int& cache) {

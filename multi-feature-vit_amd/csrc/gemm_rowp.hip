@@ -722,7 +722,15 @@ int rp_cus() { return device_cus(); }
 int rp_rows_per_tile(int M, int cap = RP_TH) {
     const int cus = rp_cus();
     const int rounds = (M + cus * cap - 1) / (cus * cap);
-    return (M + cus * rounds - 1) / (cus * rounds);
+    int rpt = (M + cus * rounds - 1) / (cus * rounds);
+    // small M with another kernel stream beside this one (stream_share() >= 2, common.cuh): at least 64 rows per tile, i.e. FEWER workgroups than
+    // CUs - a tile streams the whole W[384][K] whatever its height, and a launch that leaves CUs free lets the other encoder's kernels run beside it.
+    // MFVIT_ROWP_MINROWS overrides the floor (0: none).
+    static int sw_min = INT_MIN;
+    const int minr_env = env_switch("MFVIT_ROWP_MINROWS", -1, sw_min);
+    const int minr = minr_env >= 0 ? minr_env : (stream_share() >= 2 ? 64 : 0);
+    if (minr > 0 && rpt < minr) rpt = minr < cap ? minr : cap;
+    return rpt;
 }
 template <int MODE> constexpr int rp_cap() { return MODE == REPI_LNBWD_RES ? RP_XROWS : RP_TH; }
 

@@ -412,7 +412,9 @@ bool gemm_tn_glds_supported(int dtype, const GemmP& p) {
         static int sw8r = INT_MIN, swilr = INT_MIN;
         if (dtype != MFVIT_BF16X3 || p.cs0 || p.res_mod || env_switch("MFVIT_TN2_W8", 1, sw8r) == 0 || env_switch("MFVIT_TN2_IL", 1, swilr) == 0) return false;
     }
-    if (p.N % 128 || p.K % 128 || p.M < 4096) return false;     // 128 x 128 LOGICAL tiles in every mode
+    static int sw_minm = INT_MIN;
+    // (M >= 2,048 since round 5: at B = 16 (M = 3,152) the LDS-DMA kernel with the paired dWqkv + dWproj launch is ~3 % of the step ahead of gemm_tn)
+    if (p.N % 128 || p.K % 128 || p.M < env_switch("MFVIT_TN2_MINM", 2048, sw_minm)) return false;     // 128 x 128 LOGICAL tiles in every mode
     if (p.lda % 8 || p.ldw % 8) return false;
     return true;
 }
@@ -432,8 +434,11 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     const int tiles = ((p.N + p.res_mod) / 128) * (p.K / 128);          // res_mod = N of the paired second GEMM (0: none)
     if (p.res_mod) p.cpart = nullptr;                                   // (the plain-store partial path is single-GEMM)
     if (p.splits <= 0) {
-        static const int target = [] { const char* e = getenv("MFVIT_TN2_TARGET"); return e ? atoi(e) : 256; }();
-        int s = target / tiles;                              // one workgroup per CU (96 KB of LDS): tiles x splits <= 256
+        static const int target_env = [] { const char* e = getenv("MFVIT_TN2_TARGET"); return e ? atoi(e) : 0; }();
+        // one workgroup per CU (96 KB of LDS): tiles x splits <= 256; with a second kernel stream beside this one (stream_share(), common.cuh) and a
+        // reduction short enough that the splits are latency (M < 8,192 rows) half of that, so that the other encoder's launch fits beside it
+        const int target = target_env > 0 ? target_env : (stream_share() >= 2 && p.M < 8192 ? 128 : 256);
+        int s = target / tiles;
         const int maxs = (p.M + 4 * G::KR - 1) / (4 * G::KR);
         p.splits = s < 1 ? 1 : (s > maxs ? maxs : s);
     }

@@ -10,6 +10,11 @@
 
 using namespace mfvit;
 
+namespace mfvit {
+static std::atomic<int> g_stream_share{1};
+int stream_share() { return g_stream_share.load(std::memory_order_relaxed); }
+}  // namespace mfvit
+
 namespace {
 
 // MFVIT_FC1B_TILE (default 1, round 4): the fc1 bias gradient comes from the accumulators of the fc2-dgrad tile epilogue (float atomics on 1536 addresses)
@@ -257,6 +262,10 @@ SideStream& side_stream(hipStream_t caller) {
 extern "C" {
 
 int mfvit_abi_version(void) { return 4; }
+int mfvit_set_stream_share(int n) {
+    mfvit::g_stream_share.store(n < 1 ? 1 : (n > 8 ? 8 : n), std::memory_order_relaxed);
+    return MFVIT_OK;
+}
 int mfvit_set_wgrad_stream(int enabled) {
     g_wgrad_stream.store(enabled ? 1 : 0, std::memory_order_relaxed);
     return MFVIT_OK;

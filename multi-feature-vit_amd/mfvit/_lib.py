@@ -82,6 +82,7 @@ SIGNATURES = {
     "mfvit_ema_update": (I, [P, P, F, L, P]),
     "mfvit_lars_step": (I, [P, I, I, P, F, F, F, F, P]),
     "mfvit_adam_step": (I, [P, I, F, F, F, F, F, I, P]),
+    "mfvit_adam_step_dev": (I, [P, I, P, I, P]),
     "mfvit_sgd_step": (I, [P, I, F, F, F, I, P]),
     "mfvit_amp_unscale": (I, [P, I, F, P, P]),
     "mfvit_prenorm_xattn_forward": (I, [POINTER(FusionCfg), P, P, P, P, P, P]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "mfvit_eval_counts": (I, [P, L, P, I, I, P, P, P, P, P]),
     "mfvit_prof_enable": (I, [I]),
     "mfvit_set_wgrad_stream": (I, [I]),
+    "mfvit_set_stream_share": (I, [I]),
     "mfvit_prof_collect": (I, [POINTER(ctypes.c_double), I]),
     "mfvit_prof_class_name": (c_char_p, [I]),
     "mfvit_fusion_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),

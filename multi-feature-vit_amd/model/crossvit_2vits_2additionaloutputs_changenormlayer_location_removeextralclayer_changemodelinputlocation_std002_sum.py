@@ -14,6 +14,7 @@ import os
 import torch
 import torch.nn as nn
 
+from mfvit import _lib
 from mfvit.arena import ParamArena
 from mfvit.fusion import FusionFn
 from model.module import Attention, CrossAttention, FeedForward, PreNorm  # noqa: F401  (same import list as FUS:6)
@@ -94,7 +95,10 @@ class Fus_CrossViT(nn.Module):
         return None
 
     def forward(self, vit_cxr, vit_enh, img_cxr, img_enh):
-        if self._two_streams and img_enh is not None and img_enh.is_cuda:
+        two = bool(self._two_streams and img_enh is not None and img_enh.is_cuda)
+        if img_cxr is not None and img_cxr.is_cuda:
+            _lib.lib().mfvit_set_stream_share(2 if two else 1)     # grid-size hint for small batches: two encoders side by side (include/mfvit.h)
+        if two:
             # the two encoders are independent: run the ENH stream's ~100 kernels on a second HIP stream so that its
             # MFMA phases overlap the CXR stream's HBM-bound epilogues (and vice versa); autograd replays each
             # encoder's backward on the stream its forward ran on, so the overlap holds for the backward too

@@ -16,7 +16,7 @@ from mfvit import ops
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 D, F = 384, 1536
-SHAPES = [(128 * 197, "full"), (128 * 197 - 57, "ragged"), (4096 + 40, "small")]
+SHAPES = [(128 * 197, "full"), (128 * 197 - 57, "ragged"), (4096 + 40, "small"), (16 * 197, "b16")]
 # the tall-tile kernel is instantiated per number of 16-row fragments a tile carries (1 .. 7): one M for each, and tiles of a single row
 ROW_SHAPES = SHAPES + [(16 * 197, "B16: 1 fragment"), (32 * 197 - 3, "B32: 2"), (48 * 197, "B48: 3"), (64 * 197, "B64: 4"), (96 * 197, "B96: 5"),
                        (112 * 197, "B112: 6"), (197, "one row per tile")]
@@ -133,7 +133,7 @@ def test_two_term_weight_gradient_is_opt_in_and_bf16_grade_in_dy(monkeypatch):
 @pytest.mark.parametrize("kind", ["split", "bf16", "fp16"])
 def test_paired_weight_gradient_launch(M, tag, kind):
     """`gemm_tn_glds_pair` (csrc/gemm_tn2.hip) through `mfvit_linear_wgrad_pair`: dWqkv (+ d qkv.bias column sums) and dWproj of a timm
-    attention block in ONE launch - the default of the timed encoder backward at M >= 4096 - against float64 dY^T X on the rounded
+    attention block in ONE launch - the default of the timed encoder backward at M >= 2048 - against float64 dY^T X on the rounded
     operands for BOTH outputs and the bias sums, at the bench's M, a ragged M and a small one."""
     g = _gen(71)
     dqkv32, y132 = rn(g, M, 3 * D, sc=.1), rn(g, M, D)
@@ -155,7 +155,7 @@ def test_paired_weight_gradient_launch(M, tag, kind):
         ops.linear_wgrad_pair(dqkv[:1000], y1[:1000], gmid[:1000], attn[:1000], split=kind == "split")
 
 
-@pytest.mark.parametrize("M", [128 * 197, 64 * 197, 4096 + 40, 901])
+@pytest.mark.parametrize("M", [128 * 197, 64 * 197, 4096 + 40, 16 * 197, 2048 + 37, 901])
 def test_weight_gradient_with_partial_scratch(M):
     """The plain-store split-partial path (scratch given: `mfvit_linear_wgrad_ws`, MFVIT_TN_PART=1 inside the encoder) at row counts where the
     KR-rounded split chunks overshoot M: every split must write its partial tile (an empty split used to leave stale scratch in the sum)."""
@@ -215,3 +215,27 @@ def test_row_kernels_plain_16_bit_types(monkeypatch, M, tag, dt, mode):
         errs = dict(dx=rel(dx, dx64), dgamma=rel(dgm, (d64 * h).sum(0)), dbeta=rel(dbt, d64.sum(0)), dcol=rel(dcl, dx64.sum(0)))
         assert errs["dx"] < 3e-5 and rel(dxt, dx64) < tol_t and max(errs["dgamma"], errs["dbeta"], errs["dcol"]) < 2e-4, (tag, K, mode, errs)
 
+
+
+def test_stream_share_hint_changes_grids_not_results():
+    """mfvit_set_stream_share (include/mfvit.h; set to 2 by the two-stream CA model): at a small batch the row-complete GEMMs and the weight
+    gradients launch about half as many, longer workgroups.  Row outputs are bit-identical (every row's products and LayerNorm are computed in
+    the same order whatever the tile height); column sums and weight gradients agree at rounding level (different partial-sum order)."""
+    from mfvit import _lib
+    g = _gen(91)
+    M = 16 * 197
+    a, w, bias = sp(rn(g, M, 4 * D, sc=.3)), sp(rn(g, D, 4 * D, sc=.05)), rn(g, D).to(DEV)
+    res, gamma, beta = rn(g, M, D).to(DEV), (1 + 0.1 * rn(g, D)).to(DEV), rn(g, D, sc=.1).to(DEV)
+    dy, x = sp(rn(g, M, 3 * D, sc=.1)), sp(rn(g, M, D))
+    out = {}
+    try:
+        for share in (1, 2):
+            _lib.lib().mfvit_set_stream_share(share)
+            xo, y, mean, rstd = ops.linear_res_ln_fwd(a, w, bias, res, gamma, beta, 1e-6, split=True)
+            dw = ops.linear_wgrad(dy, x, split=True)
+            out[share] = (xo.clone(), y.clone(), mean.clone(), rstd.clone(), dw.clone())
+    finally:
+        _lib.lib().mfvit_set_stream_share(1)
+    for i in range(4):
+        assert torch.equal(out[1][i], out[2][i]), i
+    assert rel(out[2][4], out[1][4].double()) < 2e-6

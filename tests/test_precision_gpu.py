@@ -117,7 +117,7 @@ def test_linear_fwd(mode, M, N, K):
 
 @pytest.mark.parametrize("mode", MODES, ids=IDS)
 @pytest.mark.parametrize("M,N,K", [(777, 256, 384), (100, 384, 1536), (31, 128, 128), (197 * 64, 1152, 384), (197 * 33 + 5, 384, 1536),
-                                   (4099, 128, 128), (197 * 128, 1536, 384)])
+                                   (4099, 128, 128), (197 * 128, 1536, 384), (197 * 16, 1152, 384), (2048 + 37, 384, 1536)])
 def test_linear_wgrad(mode, M, N, K):
     from mfvit import ops
     dy, x = rnd((M, N), 4), rnd((M, K), 5)
