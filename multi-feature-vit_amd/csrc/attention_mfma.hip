@@ -1802,23 +1802,23 @@ int attn_cus() {   // CUs of the CURRENT device, a multiple of 8 (a persistent w
     return n >= 8 ? n : 8;
 }
 
-// parts of P / dS in the split-fp16 kernels (see the top of the file): forward 2 (hi + lo: f32-grade outputs), backward 1 (11 bits, like the
-// saved activation derivative of the MLP: gradients at 2^-11 relative); MFVIT_ATTN_PF / MFVIT_ATTN_PB = 1 / 2 override (A/B, tests)
-static int parts_fwd() { static int sw = INT_MIN; return env_switch("MFVIT_ATTN_PF", 2, sw) == 1 ? 1 : 2; }
+// parts of P / dS in the split-fp16 kernels (see the top of the file): forward 2 (hi + lo: f32-grade outputs - one part measured 2.2e-4 on the output
+// and 8e-5 ... 9e-5 on the logits of a 12-block encoder for 46 instead of 48 us, and was removed), backward 1 (11 bits, like the saved activation
+// derivative of the MLP: gradients at 2^-11 relative; worst parameter gradient of the encoder unchanged at 3.3e-4); MFVIT_ATTN_PB=2: two parts
+// in the backward too (dqkv at 5e-6 against float64, +14 % time)
 static int parts_bwd() { static int sw = INT_MIN; return env_switch("MFVIT_ATTN_PB", 1, sw) == 2 ? 2 : 1; }
 
 template <typename T, int NPX> int launch_fwd_t(const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st) {
     typedef typename Vec4<T>::elem E;
     typedef typename AttnT<T>::OE OE;
-    {   // persistent pair-synchronous kernel: enough pairs to fill every CU twice, 5 - 7 row tiles per pair (one per computing wave)
-        static int sw = INT_MIN;
+    if constexpr (is_split<T>::value) {
+        // persistent pair-synchronous kernel: enough pairs to fill every CU twice, 5 - 7 row tiles per pair (one per computing wave).  The split types
+        // only (53 vs 57 - 60 us at the bench shape in split bf16); the plain 16-bit types are faster on the per-pair kernel (27.5 vs 30 us: their steps
+        // are too short for the per-step overheads of the pipeline) and are no longer instantiated for it.
         const int cus = attn_cus();
         const int nt = (Tn + 31) >> 5;
         const int bytes = RingGeo<T>::lds_bytes(Tn);
-        // Default: the split types only (53 vs 57 - 60 us at the bench shape in split bf16); the plain 16-bit types are faster on the per-pair kernel
-        // (27.5 vs 30 us: their steps are too short for the per-step overheads of the pipeline) - MFVIT_ATTN_FWD_RING=2 forces the persistent kernel for them too.
-        const int want = env_switch("MFVIT_ATTN_FWD_RING", 1, sw);
-        if ((want == 2 || (want == 1 && is_split<T>::value)) && B * H >= 2 * cus && nt >= 5 && nt <= RingGeo<T>::NCW && bytes <= 160 * 1024) {
+        if (B * H >= 2 * cus && nt >= 5 && nt <= RingGeo<T>::NCW && bytes <= 160 * 1024) {
             static PerDeviceOnce attr_pp;
             if (attr_pp.first()) (void)hipFuncSetAttribute((const void*)attn_fwd_pp_kernel<T, NPX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             ProfScope ps(PROF_ATTN_FWD, 4.0 * B * H * (double)Tn * Tn * HD, 0, st);
@@ -1879,8 +1879,7 @@ template <typename T, int NPX> int launch_bwd_t(const void* qkv, const void* out
         ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
         // one persistent workgroup per CU (the LDS images allow no second one): a multiple of 8 so that a workgroup's pairs stay on its XCD
         const int cus = attn_cus();
-        static int swp = INT_MIN;                                      // MFVIT_ATTN_BWD_PERSIST=0: one workgroup per pair
-        const int grid = (B * H < cus || env_switch("MFVIT_ATTN_BWD_PERSIST", 1, swp) == 0) ? B * H : cus;
+        const int grid = B * H < cus ? B * H : cus;
         if (wide)
             MFVIT_LAUNCH((attn_bwd_mfma_kernel<T, RSB, NPX>), dim3(grid), dim3(512), bytes, st, (const E*)qkv, (const OE*)out, (const OE*)dout, lse,
                          (OE*)dqkv, Tn, H, 1.0f / sqrtf((float)HD), B * H);
@@ -1918,7 +1917,7 @@ int attn_fwd_mfma(int dtype, const void* qkv, void* out, float* lse, int B, int 
     if (dtype == MFVIT_BF16) return launch_fwd_t<bf16, 2>(qkv, out, lse, B, Tn, H, st);
     if (dtype == MFVIT_BF16X3) return launch_fwd_t<sbf16, 2>(qkv, out, lse, B, Tn, H, st);
     if (dtype == MFVIT_F16) return launch_fwd_t<f16, 2>(qkv, out, lse, B, Tn, H, st);
-    if (dtype == MFVIT_X3F16) return parts_fwd() == 1 ? launch_fwd_t<sf16, 1>(qkv, out, lse, B, Tn, H, st) : launch_fwd_t<sf16, 2>(qkv, out, lse, B, Tn, H, st);
+    if (dtype == MFVIT_X3F16) return launch_fwd_t<sf16, 2>(qkv, out, lse, B, Tn, H, st);
     return MFVIT_EINVAL;
 }
 int attn_bwd_mfma(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,

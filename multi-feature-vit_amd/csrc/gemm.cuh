@@ -508,16 +508,6 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN, int D, bool IL = 
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const char* ta = lds + cur * STAGE_BYTES;
-#ifdef MFVIT_ABLATE
-                const int ab = p.splits;
-                if (!(ab & 1)) issue(st[d], kt0 + d + D);
-                __builtin_amdgcn_sched_barrier(0);
-                if (!(ab & 16)) Base::compute(ta, ta + TA::BYTES, wm, wn, lane, acc);
-                if (!(ab & 1)) wait_set<NL*(D - 1)>(st[(d + 1) % D]);
-                if (!(ab & 2)) put(st[(d + 1) % D], lds + (cur ^ 1) * STAGE_BYTES);
-                if (!(ab & 4)) __syncthreads();
-                cur ^= 1;
-#else
                 if constexpr (IL && Base::SPLIT && !HALF && D == 2) {
                     // interleaved form: the loads of tile kt + 2 go out one behind each of the first MFMAs, then the wait for tile kt + 1
                     // (requested a whole iteration ago), then its LDS stores one behind each of the later MFMAs - instead of a burst of
@@ -550,7 +540,6 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN, int D, bool IL = 
                 __syncthreads();
                 cur ^= 1;
                 }
-#endif
             }
         }
         // the last D tiles (nk % D == 0: tile nk - D + d sits in set d): nothing left to issue, the counts run down
@@ -569,109 +558,6 @@ template <typename T, int BM, int BN, int BKB, int WM, int WN, int D, bool IL = 
         if constexpr (D > 1) tail(std::integral_constant<int, 1>());
         if constexpr (D > 2) tail(std::integral_constant<int, 2>());
         static_assert(D <= 3, "tail written out for D <= 3");
-    }
-};
-
-// ---------------------------------------------------------------------------------------------------
-// bf16 NT main loop with ASYNCHRONOUS global -> LDS copies (global_load_lds_dwordx4, "LDS-DMA"): no VGPR staging, no
-// ds_write pass, NS-deep LDS ring with a counted s_waitcnt vmcnt so that NS-2 K-tiles stay in flight across the single
-// barrier of each iteration.  The LDS destination of an LDS-DMA is lane-linear (base + 16 * lane), so the XOR swizzle of
-// the K-contiguous image (KTile<bf16, R, 64>) is applied on the per-lane SOURCE address instead (cdna_hip_programming.md
-// rule 21): LDS chunk position cpos of row r receives global chunk cpos ^ ((r >> 2) & 3).
-template <int BM, int BN, int WM, int WN, int NS> struct NtLoopGlds {
-    static constexpr int NT = WM * WN * 64;
-    static constexpr int BKB = 64, BK = 32;
-    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    typedef KTile<bf16, BM, BKB> TA;
-    typedef KTile<bf16, BN, BKB> TB;
-    static constexpr int STAGE_BYTES = TA::BYTES + TB::BYTES;
-    static constexpr int LDS_BYTES = NS * STAGE_BYTES;
-    static constexpr int LA = BM * 4 / NT, LB = BN * 4 / NT;   // LDS-DMA instructions per thread per stage
-    static constexpr int LPS = LA + LB;
-    static_assert(BM * 4 % NT == 0 && BN * 4 % NT == 0, "tile chunks must divide over the block");
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    typedef const __attribute__((address_space(1))) void* glb_ptr;
-
-    template <int N> static __device__ __forceinline__ void wait_vm() {
-        if constexpr (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if constexpr (N == LPS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-    }
-
-    static __device__ __forceinline__ void run(const GemmP& p, int m0, int n0, char* lds, f32x16 (&acc)[TM][TN]) {
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        const int wm = wave / WN, wn = wave % WN;
-        const bf16* srcA[LA];
-        const bf16* srcB[LB];
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int q = tid + i * NT, row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
-            int gr = m0 + row;
-            gr = gr < p.M ? gr : p.M - 1;
-            srcA[i] = (const bf16*)p.A + (long)gr * p.lda + c * 8;
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            const int q = tid + i * NT, row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
-            int gr = n0 + row;
-            gr = gr < p.N ? gr : p.N - 1;
-            srcB[i] = (const bf16*)p.W + (long)gr * p.ldw + c * 8;
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const int nk = p.K / BK;
-        // LDS byte offset of this wave's 1 KiB piece of every 4 KiB group (wave-uniform, in an SGPR)
-        const unsigned lbase = __builtin_amdgcn_readfirstlane(
-            (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds + (unsigned)wave * 1024u);
-        // inline asm on purpose: hipcc drains vmcnt(0) in front of the next ds_read when it SEES an LDS-DMA; hidden in asm the
-        // copies stay in flight and the counted waits below retire them (cdna_hip_programming.md 5.7: M0 = LDS destination base)
-        auto glds16 = [](const void* gsrc, unsigned lds_off) {
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep)
-                         : "v"(gsrc), "s"(lds_off)
-                         : "memory");
-        };
-        auto issue = [&](int kt, int slot) {
-            const unsigned sa = lbase + (unsigned)slot * STAGE_BYTES;
-            const unsigned sb = sa + TA::BYTES;
-#pragma unroll
-            for (int i = 0; i < LA; ++i) glds16(srcA[i] + kt * BK, sa + i * NT * 16);
-#pragma unroll
-            for (int i = 0; i < LB; ++i) glds16(srcB[i] + kt * BK, sb + i * NT * 16);
-        };
-#pragma unroll
-        for (int s = 0; s < NS - 1; ++s)
-            if (s < nk) issue(s, s);
-        for (int kt = 0; kt < nk; ++kt) {
-            // stage kt must have landed; up to NS-2 younger stages may stay in flight
-            const int younger = nk - 1 - kt < NS - 2 ? nk - 1 - kt : NS - 2;
-            if (younger >= 2) wait_vm<2 * LPS>();
-            else if (younger == 1) wait_vm<LPS>();
-            else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + NS - 1 < nk) issue(kt + NS - 1, (kt + NS - 1) % NS);
-            const char* ta = lds + (kt % NS) * STAGE_BYTES;
-            const char* tb = ta + TA::BYTES;
-#pragma unroll
-            for (int s = 0; s < TA::KSTEPS; ++s) {
-                bf16x8 a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = TA::frag(ta, (wm * TM + i) * 32, s, lane);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = TB::frag(tb, (wn * TN + j) * 32, s, lane);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = MmaTraits<bf16>::mma(a[i], b[j], acc[i][j]);
-            }
-        }
-        __syncthreads();
     }
 };
 

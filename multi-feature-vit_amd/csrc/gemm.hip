@@ -23,11 +23,12 @@ namespace mfvit {
 
 
 // ------------------------------------------------------------------------------------------ tile kernel
-// WIDE (round-5 experiment, MFVIT_NT_WIDE=1): an N-wide 128 x 256 tile of 8 waves (2 x 4, 64 x 64 per wave as before), ONE workgroup per CU - half
-// the A re-reads across the N tiles of a row block and 3/4 of the staged operand bytes per MFMA (VERDICT r4 task 2b)
-template <typename T, int EPI, int DEEP = 0, int WIDE = 0>     // DEEP: K tiles kept in flight by the main loop (0: NtLoop's one; 2: NtLoopDeep, 16-bit types)
-__global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 workgroups per CU (64 - 68 KB of LDS each): register budget 256 per wave
-    constexpr int BM = 128, BN = WIDE ? 256 : 128, BKB = 128, WM = 2, WN = WIDE ? 4 : 2, NTHR = WM * WN * 64;
+// (Round 5 tried an N-wide 128 x 256 tile of 8 waves, one workgroup per CU - half the A re-reads across the N tiles of a row block, 3/4 of the staged
+// operand bytes per MFMA: bit-identical, L2 requests - 17 %, and 4 - 9 % SLOWER (fc1 + GELU 130.0 -> 135.7 us, fc2 data gradient 112.9 -> 122.9 us);
+// like the M-tall 256 x 128 tile of round 4 it gives up the second independent workgroup per CU.  Removed; profiles/r05_tile_wide_ab.txt.)
+template <typename T, int EPI, int DEEP = 0>     // DEEP: K tiles kept in flight by the main loop (0: NtLoop's one; 2: NtLoopDeep, 16-bit types; 12: interleaved, split)
+__global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 workgroups per CU (64 - 68 KB of LDS each): register budget 256 per wave
+    constexpr int BM = 128, BN = 128, BKB = 128, WM = 2, WN = 2, NTHR = WM * WN * 64;
     typedef NtLoop<T, BM, BN, BKB, WM, WN> Loop;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     apply_batch<T>(p, sizeof(T));
@@ -40,26 +41,10 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_nt_tile_k
         NtLoopDeep<T, BM, BN, BKB, WM, WN, 2, true>::run(p, m0, n0, lds, acc);
     } else if constexpr (DEEP > 0) {
         NtLoopDeep<T, BM, BN, BKB, WM, WN, DEEP>::run(p, m0, n0, lds, acc);
-    } else if constexpr (std::is_same<T, bf16>::value) {
-        if (p.y_f32 == 99) NtLoopGlds<BM, BN, WM, WN, 4>::run(p, m0, n0, lds, acc);   // LDS-DMA main loop (bf16)
-        else Loop::run(p, m0, n0, lds, acc);
     } else {
         Loop::run(p, m0, n0, lds, acc);
     }
 
-#ifdef MFVIT_ABLATE
-    if (p.splits & 8) {          // no epilogue: one conditional store keeps the accumulators alive
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < Loop::TM; ++i)
-#pragma unroll
-            for (int j = 0; j < Loop::TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
-        if (sum == 12345.678f) ((float*)p.out0)[threadIdx.x] = sum;
-        return;
-    }
-#endif
     // ---- epilogue through LDS: per-element math in registers -> [128][128 + pad] tile in LDS -> 16-byte coalesced stores.
     // Rows >= M replicate row M-1 exactly (the A loads are clamped), so they are stored as identical duplicates: no branches.
     // The activation derivative (out0 of the GELU / ReLU epilogues, aux of EPI_GELU_BWD) is kept in AX: the tensor's own type for bf16 /
@@ -86,13 +71,7 @@ __global__ __launch_bounds__(WIDE ? 512 : 256, WIDE ? 1 : 2) void gemm_nt_tile_k
             u32x4* gp = (u32x4*)(g + (long)m * ld_bytes + col_bytes + 16 * c);
             u32x4* lp = (u32x4*)(tile + row * (RB + 16) + 16 * c);
             if constexpr (decltype(to_global_c)::value) {
-                if (p.rows_per_wg >= 2) {                                        // default (2): system-scope streaming stores - no write-allocate fetch (common.cuh)
-                    const u32x4 v = *lp;
-                    if (p.rows_per_wg == 2) store16_stream(gp, v);
-                    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(gp), "v"(v) : "memory");
-                } else
-                if (p.rows_per_wg == 1) __builtin_nontemporal_store(*lp, gp);   // (field unused by the tile kernel otherwise) nt only: MFVIT_NT_STORE=1
-                else *gp = *lp;                                                  // keeps the operand tiles in L2, see launch_tile
+                store16_stream(gp, *lp);                                         // system-scope streaming store: no write-allocate fetch (common.cuh)
             } else {
                 *lp = *gp;
             }
@@ -553,22 +532,11 @@ __global__ __launch_bounds__(WM * 256, (WM == 1 && sizeof(T) == 2) ? 2 : 1) void
     const int m0 = blockIdx.x * rpw;
     p.M = p.M < m0 + rpw ? p.M : m0 + rpw;   // everything below treats rows >= p.M as padding
     f32x16 acc[TM][TN];
-    if constexpr (std::is_same<T, bf16>::value && BKB == 128) {
-        // 128-row variant: the stage splits evenly over the 8 waves, so the LDS-DMA ring (BK 32, 4 slots in the same 128 KB, counted
-        // vmcnt: two stages in flight) applies - OPT-IN (MFVIT_ROW_GLDS=1): fc2 + LN 71 vs 75 us on a repeated launch whose operands sit
-        // in the Infinity Cache, but 84 vs 76 us inside the training step where they come from HBM.  (Measured and dropped for the 64-row variants: a 2-slot
-        // BK 64 DMA loop and a 4-slot loop with an uneven 3/4-instruction split per wave are both 5-10 % slower than register staging.)
-        if (BM == 128 && p.splits == 78) {
-            if constexpr (BM == 128) NtLoopGlds<BM, BN, WM, WN, 4>::run(p, m0, 0, lds, acc);
-        } else {
-            Loop::run(p, m0, 0, lds, acc);
-        }
-    } else {
-        // (NtLoopDeep, two K tiles in flight, measured on the two-workgroups-per-CU variant and not used: 2 - 4 % SLOWER (50.0 -> 52.5,
-        // 148.6 -> 154.2, 132.4 -> 136.5, 173.4 -> 176.3 us), and with the LayerNorm-backward epilogue at the register limit the
-        // allocator spills around the in-flight sets - wrong results.  The row tiles are LDS-read / MFMA paced, not latency paced.)
-        Loop::run(p, m0, 0, lds, acc);  // ends with a barrier: the staging LDS is free from here on
-    }
+    // (NtLoopDeep, two K tiles in flight, measured on the two-workgroups-per-CU variant and not used: 2 - 4 % SLOWER (50.0 -> 52.5,
+    // 148.6 -> 154.2, 132.4 -> 136.5, 173.4 -> 176.3 us), and with the LayerNorm-backward epilogue at the register limit the
+    // allocator spills around the in-flight sets - wrong results.  The row tiles are LDS-read / MFMA paced, not latency paced.  An LDS-DMA
+    // ring for the 128-row bf16 variant (round 2, opt-in until round 5): 71 vs 75 us on operands in the Infinity Cache, 84 vs 76 us inside the step.)
+    Loop::run(p, m0, 0, lds, acc);  // ends with a barrier: the staging LDS is free from here on
 
     constexpr bool LEAN = WM == 1 && sizeof(T) == 2 && BM == 64;      // the two-workgroups-per-CU variant: 256 registers
     if constexpr (LEAN) {
@@ -967,13 +935,7 @@ template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStrea
     GemmP p = pin;
     constexpr int EP = elems_per<T>::value;
     if (p.N % 128 || p.K * EP % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
-    static const int use_glds = [] { const char* e = getenv("MFVIT_GLDS"); return e ? atoi(e) : 0; }();
-    if (std::is_same<T, bf16>::value && use_glds) p.y_f32 = 99;
-    // Output tile stores marked non-temporal: the 58 - 310 MB a launch writes otherwise evict the A / W tiles the other N tiles of the
-    // same rows are about to re-read (L2 hit rate of the operand reads 77 %).  Isolated qkv 80.7 -> 77.1 us, fc1 + GELU 157.5 -> 151.4 us.
-    static int nt_sw = INT_MIN;
-    const int nt_store = env_switch("MFVIT_NT_STORE", 2, nt_sw);      // A/B switch (0: plain stores, 1: nt, 2: sc0 sc1 nt (default), 3: sc1)
-    p.rows_per_wg = nt_store;
+    // (output tiles leave through common.cuh::store16_stream: system-scope streaming stores)
     const int nwg = (p.N / 128) * ((p.M + 127) / 128);
     constexpr int epi_bytes = 128 * (128 * (int)sizeof(T) * EP + 16);
     constexpr int lds_bytes = Loop::LDS_BYTES > epi_bytes ? Loop::LDS_BYTES : epi_bytes;
@@ -986,18 +948,13 @@ template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStrea
     ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
     if constexpr (sizeof(T) == 2) {
         // two K tiles in flight per workgroup (NtLoopDeep): needs an even number of K tiles and 32-bit byte offsets inside both operands
-        static const int deep = [] { const char* e = getenv("MFVIT_NT_DEEP"); return e ? atoi(e) : 2; }();      // 0: the one-tile loop (A/B switch)
         const bool fits = (unsigned long long)(p.M - 1) * p.lda * 2 + 256 < (1ull << 32) && (unsigned long long)(p.N - 1) * p.ldw * 2 + 256 < (1ull << 32);
-#ifdef MFVIT_ABLATE
-        { const char* e = getenv("MFVIT_ABLATE_BITS"); p.splits = e ? atoi(e) : 0; }
-#endif
-        const bool deep_ok = deep == 2 && p.y_f32 != 99 && p.K * EP / Loop::BK >= 2 && (p.K * EP / Loop::BK) % 2 == 0 && fits;
+        const bool deep_ok = p.K * EP / Loop::BK >= 2 && (p.K * EP / Loop::BK) % 2 == 0 && fits;
         if constexpr (is_split<T>::value) {
-            // interleaved loads / LDS stores (default; MFVIT_NT_IL=0: the burst form; read at every launch for A/B runs in one process).
+            // interleaved loads / LDS stores (round 3; the burst form stays for the plain 16-bit types).
             // Measured inside the step (rocprofv3, serialized streams): fc1 + GELU 138.3 -> 133.1 us, fc2-dgrad 122.7 -> 114.7, qkv 84.0 -> 79.6,
             // proj-dgrad 35.0 -> 32.2; results bit-identical (same MFMA order).
-            static int sw_il = INT_MIN;
-            if (deep_ok && env_switch("MFVIT_NT_IL", 1, sw_il) != 0) {
+            if (deep_ok) {
                 static PerDeviceOnce a12;
                 if (a12.first())
                     (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -1016,51 +973,13 @@ template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStrea
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
-// the N-wide experiment form of the split-bf16 tile kernel (see the kernel): N % 256 == 0, an even number of K tiles, 32-bit operand offsets
-template <int EPI> static int launch_tile_wide(const GemmP& pin, hipStream_t st) {
-    typedef sbf16 T;
-    typedef NtLoop<T, 128, 256, 128, 2, 4> Loop;
-    GemmP p = pin;
-    p.rows_per_wg = 2;
-    const int nk = p.K * 2 / Loop::BK;
-    const bool fits = (unsigned long long)(p.M - 1) * p.lda * 2 + 256 < (1ull << 32) && (unsigned long long)(p.N - 1) * p.ldw * 2 + 256 < (1ull << 32);
-    if (p.N % 256 || p.K * 2 % Loop::BK || nk < 2 || nk % 2 || !fits || p.M <= 0) return MFVIT_ENOSYS;
-    const int nwg = (p.N / 256) * ((p.M + 127) / 128);
-    constexpr int epi_bytes = 128 * (256 * 4 + 16);
-    constexpr int lds_bytes = Loop::LDS_BYTES > epi_bytes ? Loop::LDS_BYTES : epi_bytes;
-    static PerDeviceOnce attr_set;
-    if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_nt_tile_kernel<T, EPI, 12, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
-    MFVIT_LAUNCH((gemm_nt_tile_kernel<T, EPI, 12, 1>), dim3(nwg, 1, p.nb > 1 ? p.nb : 1), dim3(512), lds_bytes, st, p);
-    MFVIT_CHECK_LAUNCH();
-    return MFVIT_OK;
-}
-static int row_variant() {   // MFVIT_ROW_VARIANT: 0 = 4 waves (1x4), BK 64 B rows | 1 = 4 waves, 128 B rows | 2 = 8 waves (2x4), 128 B rows
-    static const int v = [] { const char* e = getenv("MFVIT_ROW_VARIANT"); return e ? atoi(e) : 2; }();
-    return v;
-}
 static int row_grid(const GemmP& p, int BM) {
     const int rpw = p.rows_per_wg > 0 ? p.rows_per_wg : BM;
     return (p.M + rpw - 1) / rpw;
 }
-// rows per workgroup that fill the chip evenly: the smallest whole number of rounds of 256 workgroups (one per CU) that covers M
-// with tiles of BM rows, then the rows spread evenly over rounds * 256 workgroups.  OPT-IN (MFVIT_ROW_BALANCE=1): measured on
-// MI355X it is 6-15 % SLOWER than full tiles (fc2+LN 80.8 vs 75.9 us, qkv-dgrad+LN-backward 93 vs 80 us) - every workgroup streams
-// the whole W[384][K] from L2, so 505 workgroups of 50 rows move more operand bytes than 394 of 64, and that traffic, not the
-// 77 % grid fill, is what bounds these kernels.
-static int balanced_rows(int M, int BM) {
-    static const bool on = [] { const char* e = getenv("MFVIT_ROW_BALANCE"); return e && e[0] == '1'; }();
-    if (!on || M < 256 * 32) return 0;
-    const int rounds = (M + 256 * BM - 1) / (256 * BM);
-    int rpw = (M + 256 * rounds - 1) / (256 * rounds);
-    if (rpw < 32) rpw = 32;
-    return rpw >= BM ? 0 : rpw;
-}
 template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v(const GemmP& pin, hipStream_t st) {
     GemmP p = pin;
-    p.rows_per_wg = balanced_rows(p.M, BM);
-    static const int row_glds = [] { const char* e = getenv("MFVIT_ROW_GLDS"); return e ? atoi(e) : 0; }();   // opt-in, see the kernel
-    p.splits = (row_glds && std::is_same<T, bf16>::value && BKB == 128 && BM == 128) ? 78 : 0;      // field unused by the row kernels otherwise
+    p.rows_per_wg = 0;      // full tiles (rows spread evenly over one workgroup per CU measured 6 - 15 % slower in round 2: every workgroup streams the whole W)
     typedef NtLoop<T, BM, ROW_BN, BKB, WM, 4> Loop;
     if (p.N != ROW_BN || p.K * elems_per<T>::value % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
     constexpr int need = BM * ROW_RS * 4 + BM * 4;
@@ -1078,28 +997,17 @@ template <typename T, int REPI, int WM, int BKB, int BM> static int launch_row_v
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
+// gemm_nt_row serves what gemm_rowp.hip does not take: the patch embedding (row remap), f32, K not a multiple of a tile.  Variants (rounds 2 - 3):
+// 16-bit types above 16,384 rows: two co-resident 4-wave workgroups per CU on 64-byte K tiles; otherwise 8 waves (2 x 4) on 128-byte K tiles, 128
+// rows per workgroup for the forward at K >= 768 and M >= 16,384 (half the W traffic per row).
 template <typename T, int REPI> static int launch_row(const GemmP& p, hipStream_t st) {
-    const int v = row_variant();
     if constexpr (sizeof(T) == 2) {
-        // two co-resident 4-wave workgroups per CU (64-byte K tiles; split tensors: half a k group per tile): each hides the other's
-        // HBM latency, barriers and row-statistics epilogue.  Measured (split bf16, M = 25,216, isolated launches): proj + LN 65 -> 50 us,
-        // fc2 + LN 179 -> 156, qkv-dgrad + LN-backward 146 -> 132, fc1-dgrad + LN-backward 194 -> 172.  Only once M gives more than one
-        // workgroup per CU: at M = 12,608 (197 workgroups) a CU would hold 4 waves instead of 8 and the step is 5-7 % slower.
-        static const int lean = [] { const char* e = getenv("MFVIT_ROW_LEAN"); return e ? atoi(e) : 1; }();    // A/B switch
-        if (v == 0 || (v == 2 && lean && p.M > 256 * 64) || p.K * elems_per<T>::value % (128 / (int)sizeof(T)))
-            return launch_row_v<T, REPI, 1, 64, 64>(p, st);
+        if (p.M > 256 * 64 || p.K * elems_per<T>::value % (128 / (int)sizeof(T))) return launch_row_v<T, REPI, 1, 64, 64>(p, st);
     } else {
-        if (v == 0 || p.K % (128 / (int)sizeof(T))) return launch_row_v<T, REPI, 1, 64, 64>(p, st);
+        if (p.K % (128 / (int)sizeof(T))) return launch_row_v<T, REPI, 1, 64, 64>(p, st);
     }
-    if constexpr (!is_split<T>::value) {
-        if (v == 3) return launch_row_v<T, REPI, 2, 64, 64>(p, st);
-    }
-    if (v == 1) return launch_row_v<T, REPI, 1, 128, 64>(p, st);
     if constexpr (REPI == REPI_RES_LN) {
-        // 128-row variant: every workgroup streams the whole W[384][K] from L2, so doubling the rows per workgroup halves that
-        // traffic (the row kernels' main loop is bound by it); worth it once K is large enough to amortise the 77 % grid fill
-        static const int bm128 = [] { const char* e = getenv("MFVIT_ROW_BM128"); return e ? atoi(e) : 1; }();   // 0: 64-row tiles everywhere (A/B switch)
-        if (v == 4 || (v == 2 && bm128 && p.K >= 768 && p.M >= 128 * 128)) return launch_row_v<T, REPI, 2, 128, 128>(p, st);
+        if (p.K >= 768 && p.M >= 128 * 128) return launch_row_v<T, REPI, 2, 128, 128>(p, st);
     }
     return launch_row_v<T, REPI, 2, 128, 64>(p, st);
 }
@@ -1109,7 +1017,7 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
     constexpr int KR = 128 / (int)sizeof(T);
     const int tiles = (p.N * EP / 128) * (p.K * EP / 128);
     if (p.splits <= 0) {
-        static const int target = [] { const char* e = getenv("MFVIT_TN_TARGET"); return e ? atoi(e) : 384; }();
+        constexpr int target = 384;
         // Fill the chip evenly: two workgroups fit a CU (2 x 80 KB of LDS), so aim just BELOW a multiple of 256 blocks - 288
         // blocks on 256 CUs leave 224 CUs idle while 32 run two (the makespan is the slowest CU's).
         int s = (tiles >= 16 ? target : (target * 2) / 3) / tiles;
@@ -1245,25 +1153,12 @@ template <int REPI> static int row_by_dtype(int dtype, const GemmP& p, hipStream
 static int tn_by_dtype(int dtype, const GemmP& p, hipStream_t st) { MFVIT_BY_DTYPE(dtype, (launch_tn<TT>(p, st))) }
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
-    static int sw_wide = INT_MIN;      // round-5 experiment: the N-wide tile (MFVIT_NT_WIDE=1), see gemm_nt_tile_kernel
-    const bool wide = dtype == MFVIT_BF16X3 && env_switch("MFVIT_NT_WIDE", 0, sw_wide) != 0;
     if (epi == EPI_GELU_BWD && p.cpart && p.cs0) {
-        int rc = wide ? launch_tile_wide<EPI_GELU_BWD>(p, st) : MFVIT_ENOSYS;
-        if (rc == MFVIT_ENOSYS) rc = tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
+        const int rc = tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
         if (rc != MFVIT_OK) return rc;
         return colpart_reduce(p.cpart, (p.M + 127) / 128, p.N, 1, p.cs0, nullptr, nullptr, st);
     }
     if (gemm_nt_small_supported(dtype, epi, p)) return gemm_nt_small(epi, p, st);   // gemm_small.hip: f32, M <= 512
-    {   // the N-wide tile for the split-bf16 linears with N % 256 == 0 (falls through when it does not apply)
-        if (wide) {
-            int rc = MFVIT_ENOSYS;
-            if (epi == EPI_BIAS) rc = launch_tile_wide<EPI_BIAS>(p, st);
-            else if (epi == EPI_BIAS_GELU) rc = launch_tile_wide<EPI_BIAS_GELU>(p, st);
-            else if (epi == EPI_GELU_BWD) rc = launch_tile_wide<EPI_GELU_BWD>(p, st);
-            else if (epi == EPI_BIAS_X3F16) rc = launch_tile_wide<EPI_BIAS_X3F16>(p, st);
-            if (rc != MFVIT_ENOSYS) return rc;
-        }
-    }
     switch (epi) {
         case EPI_BIAS: return tile_by_dtype<EPI_BIAS>(dtype, p, st);
         case EPI_BIAS_GELU: return tile_by_dtype<EPI_BIAS_GELU>(dtype, p, st);
@@ -1281,7 +1176,7 @@ int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
         const int rc = row_by_dtype<REPI_LNBWD_RES>(dtype, p, st);
         if (rc != MFVIT_OK || !p.cpart) return rc;
         GemmP q = p;
-        q.rows_per_wg = balanced_rows(p.M, 64);     // the LN-backward variants all use 64-row tiles (see launch_row)
+        q.rows_per_wg = 0;                          // the LN-backward variants all use full 64-row tiles (see launch_row)
         return colpart_reduce(p.cpart, row_grid(q, 64), ROW_BN, 3, p.cs0, p.cs1, p.cs2, st);
     }
     return MFVIT_EINVAL;

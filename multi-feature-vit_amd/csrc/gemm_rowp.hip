@@ -353,9 +353,6 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                   // the ring is free: epilogue scratch
-#ifdef MFVIT_ABLATE
-    if (p.rows_per_wg == 78) return;                                   // (timing experiment MFVIT_ROWP_NOEPI=1 of an MFVIT_ABLATE build: main loop only, nothing stored)
-#endif
 
     // ------------------------------------------------------------------------------------------------ epilogues
     // acc[i][j][r] = out[m0 + 16 i + fr][48 wave + 16 j + 4 fq + r]; rows past `rows` replicate the tile's last valid row exactly (clamped
@@ -750,19 +747,14 @@ template <int MODE, typename T> int launch_rowp(const GemmP& p, hipStream_t st) 
     ProfScope ps(MODE == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
     GemmP q = p;
     q.rows_per_wg = 0;
-#ifdef MFVIT_ABLATE
-    { const char* e = getenv("MFVIT_ROWP_NOEPI"); q.rows_per_wg = (e && atoi(e)) ? 78 : 0; }
-#endif
-    static int sw_mf = INT_MIN, sw_mix = INT_MIN;                        // MFVIT_ROWP_MF=7: every tile on the 7-fragment kernel (the round-3 behaviour)
-    const int mf = env_switch("MFVIT_ROWP_MF", 0, sw_mf) == 7 ? 7 : (rpt + 15) / 16;
-    if (mf >= 2 && grid > 1 && rpt % 16 && env_switch("MFVIT_ROWP_MIX", 1, sw_mix) != 0 && env_switch("MFVIT_ROWP_MF", 0, sw_mf) != 7) {
+    const int mf = (rpt + 15) / 16;
+    if (mf >= 2 && grid > 1 && rpt % 16) {
         // mixed heights: n_lo tiles of 16 (mf - 1) rows, the rest as many rows as it takes, at most 16 mf and the mode's cap
         // rows of the tall tiles at most.  Their epilogue is the launch's critical path, so in the SERIALIZED pass the forward launch is shortest with
         // short tall tiles (74.9 us at 100 rows, 77.2 at 112) - but the timed step, at the power cap, follows the MFMA count: 26.85 ms uniform,
         // 26.63 / 26.55 / 26.56 / 26.52 ms at 100 / 104 / 108 / 112 rows (profiles/r04_kernel_experiments.txt)
-        static int sw_cap = INT_MIN;
         const int lo = 16 * (mf - 1);
-        int cap = env_switch("MFVIT_ROWP_MIXCAP", RP_TH, sw_cap);
+        int cap = RP_TH;
         cap = cap > rp_cap<MODE>() ? rp_cap<MODE>() : cap;
         cap = cap > 16 * mf ? 16 * mf : (cap < lo + 1 ? lo + 1 : cap);
         int n_lo = (cap * grid - p.M) / (cap - lo);                      // the most short tiles that leave <= cap rows for each of the others
@@ -799,27 +791,16 @@ template <int MODE, typename T> int launch_rowp(const GemmP& p, hipStream_t st) 
     }
 }
 
-// MFVIT_ROWP: 0 off, 1 the forward epilogue only (+ bias + residual -> LayerNorm), 2 (default) the LayerNorm-backward epilogue as well.  Read
-// once (at every launch under MFVIT_AB_LIVE=1: A/B runs in one process).  Measured inside the training step (serialized pass, M = 25,216): forward proj + LN 56 -> 54 us,
-// fc2 + LN 140 -> 105 us; backward class average (fc1-dgrad + qkv-dgrad) 125 -> 95 us once the epilogue fetched x by LDS-DMA (before that
-// 137 / 119 us against 139 / 112 us of gemm_nt_row); whole step 33.85 -> 32.21 ms (profiles/r03_rowp_ab.txt).
-int rowp_mode() {
-    static int sw = INT_MIN;
-    return env_switch("MFVIT_ROWP", 2, sw);
-}
-
 }  // namespace
 
 bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
-    if ((dtype != MFVIT_BF16X3 && dtype != MFVIT_BF16 && dtype != MFVIT_F16) || rowp_mode() == 0) return false;
+    // (the tall-tile kernel is the default for N = 384 in the three 16-bit types since round 4; its measurements against gemm_nt_row: DESIGN.md 5.
+    // MFVIT_ROWP=0 keeps gemm_nt_row reachable for its own parity tests - it still serves the patch embedding and f32.)
+    static int sw_on = INT_MIN;
+    if ((dtype != MFVIT_BF16X3 && dtype != MFVIT_BF16 && dtype != MFVIT_F16) || env_switch("MFVIT_ROWP", 1, sw_on) == 0) return false;
     const bool split = dtype == MFVIT_BF16X3;
-    static int sw_plain = INT_MIN;                                       // MFVIT_ROWP_PLAIN=0: the plain 16-bit types stay on gemm_nt_row (A/B)
-    if (!split && env_switch("MFVIT_ROWP_PLAIN", 1, sw_plain) == 0) return false;
     if (repi != REPI_RES_LN && repi != REPI_LNBWD_RES) return false;
-    if (repi == REPI_LNBWD_RES && rowp_mode() < 2) return false;
-    static int sw_minm = INT_MIN;                                        // smallest M that takes this kernel (A/B: MFVIT_ROWP_MINM >= 0)
-    const int minm_env = env_switch("MFVIT_ROWP_MINM", -1, sw_minm);
-    const int minm = minm_env >= 0 ? minm_env : (repi == REPI_RES_LN ? RP_MINM_FWD : RP_MINM_BWD);
+    const int minm = repi == REPI_RES_LN ? RP_MINM_FWD : RP_MINM_BWD;
     // an even number of stages (128-byte k groups: 32 logical columns split, 64 plain), at least 4
     if (p.N != RP_N || p.K % (split ? 64 : 128) || p.K < (split ? 128 : 256) || p.M < minm || p.nb > 1) return false;
     if (!split && p.res_t) return false;                                 // (the operand-type residual-gradient copy is a split-bf16 path)

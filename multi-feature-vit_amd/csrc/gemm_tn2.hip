@@ -383,12 +383,6 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
                     for (int r = 0; r < 16; ++r) {
                         const int n = nw + i * 32 + acc_row(r, lane);
                         const int k = kw + j * 32 + (lane & 31);
-#ifdef MFVIT_ABLATE
-                        if (p.rows_per_wg >= 2) {          // (timing experiment MFVIT_TN2_ATOMX=2 / 3 of an MFVIT_ABLATE build: the same sum in 2 / 3 atomics per element)
-                            const float v = acc[i][j][r] / (float)p.rows_per_wg;
-                            for (int q = 0; q < p.rows_per_wg; ++q) atomicAdd(out + (long)n * ldo_ + k, v);
-                        } else
-#endif
                         atomicAdd(out + (long)n * ldo_ + k, acc[i][j][r]);
                     }
         }
@@ -406,15 +400,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
 }  // namespace
 
 bool gemm_tn_glds_supported(int dtype, const GemmP& p) {
-    static const int on = [] { const char* e = getenv("MFVIT_TN_GLDS"); return e ? atoi(e) : 1; }();
-    if (!on || (dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || p.nb > 1) return false;
-    if (p.orow_in) {                                            // remapped A rows: the default split-bf16 form without bias sums only
-        static int sw8r = INT_MIN, swilr = INT_MIN;
-        if (dtype != MFVIT_BF16X3 || p.cs0 || p.res_mod || env_switch("MFVIT_TN2_W8", 1, sw8r) == 0 || env_switch("MFVIT_TN2_IL", 1, swilr) == 0) return false;
-    }
-    static int sw_minm = INT_MIN;
+    static int sw_on = INT_MIN;                                 // MFVIT_TN_GLDS=0 keeps gemm_tn (gemm.hip: f32, small M, odd shapes) reachable at every M for its parity tests
+    if (env_switch("MFVIT_TN_GLDS", 1, sw_on) == 0 || (dtype != MFVIT_BF16 && dtype != MFVIT_BF16X3 && dtype != MFVIT_F16) || p.nb > 1) return false;
+    if (p.orow_in && (dtype != MFVIT_BF16X3 || p.cs0 || p.res_mod)) return false;    // remapped A rows: the split-bf16 form without bias sums only
     // (M >= 2,048 since round 5: at B = 16 (M = 3,152) the LDS-DMA kernel with the paired dWqkv + dWproj launch is ~3 % of the step ahead of gemm_tn)
-    if (p.N % 128 || p.K % 128 || p.M < env_switch("MFVIT_TN2_MINM", 2048, sw_minm)) return false;     // 128 x 128 LOGICAL tiles in every mode
+    if (p.N % 128 || p.K % 128 || p.M < 2048) return false;     // 128 x 128 LOGICAL tiles in every mode
     if (p.lda % 8 || p.ldw % 8) return false;
     return true;
 }
@@ -451,14 +441,11 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     if (p.splits < 2 || p.ldo0 % 4 || (long)tiles * p.splits > 384) p.cpart = nullptr;
     constexpr int bytes = (is_split<T>::value ? T2_NSP : T2_NS) * T2_STAGE;   // (the pipelined form's ring; the other split forms use three of the four slots)
     p.rows_per_wg = 0;
-#ifdef MFVIT_ABLATE
-    { const char* ex = getenv("MFVIT_TN2_ATOMX"); p.rows_per_wg = ex ? atoi(ex) : 0; }   // (timing experiment: changes the rounding of dW)
-#endif
-    static int sw8 = INT_MIN, swil = INT_MIN;                // read once, or at every launch under MFVIT_AB_LIVE=1 (A/B runs in one process)
-    const bool w8 = env_switch("MFVIT_TN2_W8", 1, sw8) != 0, il = env_switch("MFVIT_TN2_IL", 1, swil) != 0;
+    // (eight waves per workgroup and the LDS-DMA issue interleaved with the MFMAs - the W8 / IL template flags of the kernel - are the only forms
+    // launched since round 5; their four-wave / burst-issue alternatives and measurements: DESIGN.md 5, round 3)
     ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * (p.N + p.res_mod) * p.K, 0, st);
     static int sw2 = INT_MIN;
-    const bool two = is_split<T>::value && w8 && il && !p.orow_in && env_switch("MFVIT_WGRAD_TERMS", 3, sw2) == 2;
+    const bool two = is_split<T>::value && !p.orow_in && env_switch("MFVIT_WGRAD_TERMS", 3, sw2) == 2;
     auto go = [&](auto cs, auto w, auto i) {
         constexpr bool CS = decltype(cs)::value, W8 = decltype(w)::value, IL = decltype(i)::value;
         if constexpr (is_split<T>::value && W8 && IL) {
@@ -476,14 +463,7 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
         }
         MFVIT_LAUNCH((gemm_tn_glds_kernel<T, CS, W8, IL>), dim3(tiles * p.splits), dim3(W8 ? 512 : 256), bytes, st, p);
     };
-    auto go2 = [&](auto cs, auto w) {
-        if (il) go(cs, w, std::true_type{});
-        else go(cs, w, std::false_type{});
-    };
-    auto go1 = [&](auto cs) {
-        if (w8) go2(cs, std::true_type{});
-        else go2(cs, std::false_type{});
-    };
+    auto go1 = [&](auto cs) { go(cs, std::true_type{}, std::true_type{}); };
     if (p.orow_in) {
         if constexpr (is_split<T>::value) {
             static PerDeviceOnce attr_rm;

@@ -17,14 +17,11 @@ int stream_share() { return g_stream_share.load(std::memory_order_relaxed); }
 
 namespace {
 
-// MFVIT_FC1B_TILE (default 1, round 4): the fc1 bias gradient comes from the accumulators of the fc2-dgrad tile epilogue (float atomics on 1536 addresses)
+// Round 4: the fc1 bias gradient comes from the accumulators of the fc2-dgrad tile epilogue (float atomics on 1536 addresses)
 // instead of the ones-fragment MFMAs of the fc1 weight gradient - those cost that launch 8 % (98.9 vs 91.5 us for the same flops without them: a third
 // more MFMAs on half the waves of a third of its workgroups).  Same box, 0 / 1 / 0 / 1: weight-gradient class 97.8 / 94.3 / 97.4 / 94.8 us per launch, tile
 // class unchanged (93.2 / 93.3 / 93.4 / 93.6), step 27.23 / 27.16 / 27.26 / 27.19 ms.
-bool fc1b_in_tile() {
-    static int sw = INT_MIN;
-    return env_switch("MFVIT_FC1B_TILE", 1, sw) != 0;
-}
+constexpr bool fc1b_in_tile() { return true; }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -188,7 +185,10 @@ WsLayout ws_layout(const Dims& d) {
         W.dattn = o; o += align256(M * D * es);
         W.colscratch = o; o += align256(2 * D * 4);
         {   // per-workgroup column-sum partials: max over the kernels that use them
-            size_t a = ((M + 63) / 64 + 256) * 3 * D, b2 = ((M + 127) / 128) * F, c2 = 256 * 3 * D;   // row kernels: <= M/64 + 256 blocks (balanced rows)
+            // row kernels: one partial row set [3][D] per workgroup - gemm_rowp launches at most one tile per CU and round (<= max(#CUs, M / 16) tiles),
+            // gemm_nt_row full 64-row tiles (the former M / 64 + 256 bound belonged to the removed balanced-rows option)
+            const size_t tiles_row = (M + 63) / 64 > 256 ? (M + 63) / 64 : 256;
+            size_t a = tiles_row * 3 * D, b2 = ((M + 127) / 128) * F, c2 = 256 * 3 * D;
             size_t n = a > b2 ? a : b2;
             n = n > c2 ? n : c2;
             W.colpart = o; o += (2 * nl + 2) * align256(n * 4);          // one partial buffer per row-kernel launch of a backward call (batched reduce)
@@ -610,9 +610,8 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.out0 = gb + L.proj_w; p.ldo0 = D;
                 p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
                 // held back by default when the weight gradients run on the caller's stream (nothing to overlap: one launch less is a pure gain,
-                // 30.81 -> 30.68 ms per step); MFVIT_TN_PAIR=0 / 1 forces it off / on
-                static const int pair_mode = [] { const char* e = getenv("MFVIT_TN_PAIR"); return e ? atoi(e) : -1; }();
-                if (!rdrop && !tnpart && (pair_mode == 1 || (pair_mode < 0 && !use_side))) {
+                // 30.81 -> 30.68 ms per step)
+                if (!rdrop && !tnpart && !use_side) {
                     pend_proj = p;
                     have_pend = true;
                 } else {

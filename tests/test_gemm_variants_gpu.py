@@ -1,10 +1,10 @@
-"""Every GEMM kernel variant of the split-bf16 (bf16x3) path, selected by its run-time switch and called through the C ABI, against float64
-math on the ROUNDED operands (hi + lo), at the bench's row count (M = 128 x 197 = 25,216), a ragged M and a small one:
+"""The GEMM kernels of the split-bf16 (bf16x3) path that share a job, each selected by the one run-time switch that is left for it (round 5 removed
+the variant switches whose A/B had been decided: DESIGN.md 5) and called through the C ABI, against float64 math on the ROUNDED operands (hi + lo),
+at the bench's row count (M = 128 x 197 = 25,216), a ragged M and small ones:
 
-  row-complete kernels   csrc/gemm_rowp.hip (MFVIT_ROWP=2, default: one tall tile per CU, LayerNorm epilogues; LayerNorm-backward epilogue with
-                         x staged by LDS-DMA) vs csrc/gemm.hip gemm_nt_row (MFVIT_ROWP=0)
-  weight gradient        csrc/gemm_tn2.hip: 4 / 8 waves x burst / interleaved LDS-DMA issue (MFVIT_TN2_W8, MFVIT_TN2_IL; default 1, 1 = the
-                         pipelined 8-wave form with a 4-slot ring)
+  row-complete kernels   csrc/gemm_rowp.hip (default: one tall tile per CU, mixed tile heights, LayerNorm epilogues; LayerNorm-backward epilogue
+                         with x staged by LDS-DMA) and csrc/gemm.hip gemm_nt_row (MFVIT_ROWP=0: what the patch embedding and f32 run)
+  weight gradient        csrc/gemm_tn2.hip (default from M = 2,048: LDS-DMA ring, 8 waves) and csrc/gemm.hip gemm_tn (MFVIT_TN_GLDS=0)
 
 The switches are read by the library at every launch, so one process covers all of them.  Tolerances: 3e-5 of the largest output element for
 the GEMM outputs (f32 accumulation of 384 - 25,216 products of 16-bit-exact hi / lo parts), 2e-4 for the column sums over 25,216 rows."""
@@ -42,14 +42,10 @@ def rn(g, *shape, sc=1.0):
 
 @pytest.mark.parametrize("M,tag", ROW_SHAPES)
 @pytest.mark.parametrize("K", [D, F])
-@pytest.mark.parametrize("mode", ["0", "2", "2-uniform"])
+@pytest.mark.parametrize("mode", ["0", "1"])
 def test_row_kernel_forward_residual_layernorm(monkeypatch, M, tag, K, mode):
-    """x = a @ w.T + bias + res ; y = LayerNorm(x)  (proj / fc2 of timm's Block + the following norm): both row kernels (the tall-tile one with
-    mixed tile heights - the default - and with uniform ones: MFVIT_ROWP_MIX=0), split and f32 y."""
-    monkeypatch.setenv("MFVIT_ROWP_MIX", "0" if mode.endswith("uniform") else "1")
-    mode = mode[0]
+    """x = a @ w.T + bias + res ; y = LayerNorm(x)  (proj / fc2 of timm's Block + the following norm): both row kernels, split and f32 y."""
     monkeypatch.setenv("MFVIT_ROWP", mode)
-    monkeypatch.setenv("MFVIT_ROWP_MINM", "1")                              # mode 2: the tall-tile kernel at every M, whatever the default gate
     g = _gen(11 + K)
     a, w = sp(rn(g, M, K)), sp(rn(g, D, K, sc=.05))
     b, res = rn(g, D), rn(g, M, D)
@@ -67,13 +63,10 @@ def test_row_kernel_forward_residual_layernorm(monkeypatch, M, tag, K, mode):
 
 @pytest.mark.parametrize("M,tag", ROW_SHAPES)
 @pytest.mark.parametrize("K", [3 * D, F])
-@pytest.mark.parametrize("mode", ["0", "2", "2-uniform"])
+@pytest.mark.parametrize("mode", ["0", "1"])
 def test_row_kernel_dgrad_layernorm_backward(monkeypatch, M, tag, K, mode):
     """dx = LayerNorm-backward(dy @ wt.T; x) + dres, dgamma, dbeta, column sums of dx  (qkv / fc1 data gradients + norm1 / norm2 backward)."""
-    monkeypatch.setenv("MFVIT_ROWP_MIX", "0" if mode.endswith("uniform") else "1")
-    mode = mode[0]
     monkeypatch.setenv("MFVIT_ROWP", mode)
-    monkeypatch.setenv("MFVIT_ROWP_MINM", "1")                              # mode 2: the tall-tile kernel at every M, whatever the default gate
     g = _gen(23 + K)
     dy, wt = sp(rn(g, M, K, sc=.1)), sp(rn(g, D, K, sc=.05))
     x = rn(g, M, D, sc=1.5) + .3
@@ -91,11 +84,11 @@ def test_row_kernel_dgrad_layernorm_backward(monkeypatch, M, tag, K, mode):
 
 
 @pytest.mark.parametrize("M,tag", SHAPES)
-@pytest.mark.parametrize("w8,il", [("0", "0"), ("0", "1"), ("1", "0"), ("1", "1")])
-def test_weight_gradient_variants(monkeypatch, M, tag, w8, il):
-    """dW = dy.T @ x for the four linears of a block, split bf16 and plain bf16, every wave-count / issue-order variant of gemm_tn2.hip."""
-    monkeypatch.setenv("MFVIT_TN2_W8", w8)
-    monkeypatch.setenv("MFVIT_TN2_IL", il)
+@pytest.mark.parametrize("glds", ["1", "0"])
+def test_weight_gradient_variants(monkeypatch, M, tag, glds):
+    """dW = dy.T @ x for the four linears of a block, split bf16 and plain bf16, on the LDS-DMA kernel of gemm_tn2.hip and on gemm_tn."""
+    monkeypatch.setenv("MFVIT_TN_GLDS", glds)
+    w8 = il = glds
     g = _gen(37)
     for name, n, k in (("qkv", 3 * D, D), ("fc1", F, D), ("fc2", D, F), ("proj", D, D)):
         a32, b32 = rn(g, M, n, sc=.1), rn(g, M, k)
@@ -179,14 +172,13 @@ def test_weight_gradient_with_partial_scratch(M):
 
 @pytest.mark.parametrize("M,tag", [(128 * 197, "full"), (128 * 197 - 57, "ragged"), (16 * 197, "B16: 1 fragment"), (48 * 197, "B48: 3"), (197, "one row per tile")])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("mode", ["0", "2"])
+@pytest.mark.parametrize("mode", ["0", "1"])
 def test_row_kernels_plain_16_bit_types(monkeypatch, M, tag, dt, mode):
     """The tall-tile row kernels in the plain 16-bit types (round 4: gemm_rowp instantiated for bf16 / f16 - a 128-byte row is two k steps of one MFMA
     each instead of one split k group of three) against float64 on the rounded operands, forward (K = 384, 1536) and LayerNorm backward (K = 1152, 1536);
     mode 0 = gemm_nt_row, the kernel they replace.  Tolerances: the output's own rounding (2^-9 bf16, 2^-12 fp16) for the operand-type tensors, 3e-5 / 2e-4
     for the f32 outputs and the column sums."""
     monkeypatch.setenv("MFVIT_ROWP", mode)
-    monkeypatch.setenv("MFVIT_ROWP_MINM", "1")
     tol_t = 6e-3 if dt == torch.bfloat16 else 8e-4
     g = _gen(71)
     for K in (D, F):

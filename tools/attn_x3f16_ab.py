@@ -46,8 +46,9 @@ def f16_rounded(x):
 
 
 refs = {"bf16": ref(ops.split_unpack(q_b.cpu().view(-1, 6 * D)).view(B, T, 3 * D)), "f16": ref(f16_rounded(x))}
+# (MFVIT_ATTN_PF, the one-part forward, existed until the end of round 5: 2.2e-4 on the output for 46 instead of 48 us - profiles/r05_attention_x3f16_ab.txt)
 variants = [("split bf16 qkv (round 4)", q_b, "bf16", None, None), ("split fp16, P 2 parts / dS 2 parts", q_h, "f16", "2", "2"),
-            ("split fp16, P 2 parts / dS 1 part", q_h, "f16", "2", "1"), ("split fp16, P 1 part / dS 1 part", q_h, "f16", "1", "1")]
+            ("split fp16, P 2 parts / dS 1 part", q_h, "f16", "2", "1")]
 outs = {}
 for name, qkv, rk, pf, pb in variants:
     if pf:

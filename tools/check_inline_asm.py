@@ -3,12 +3,17 @@
     s_cselect does not, s_mov does not) need an "scc" clobber - better: not be there (with the clobber the compiler turned the scalar selects around
     the statement into vector code; DESIGN.md 5, round 4: v_cmpx instead of v_cmp + s_and_b64 exec);
   * vcc written (v_cmp / v_cmpx e32 forms, v_add_co ...) needs a "vcc" clobber;
-  * m0 and exec, when written, must be restored from a saved copy inside the same statement.
+  * m0 and exec, when written, must be restored from a saved copy inside the same statement;
+  * a vector-memory STORE of more than 64 bits (global_store_dwordx3 / x4, buffer_store_dwordx3 / x4) must be followed by wait states (s_nop) inside
+    the statement: the hardware reads its data registers late, the next write of those registers needs >= 1 wait state (2 with an SGPR offset), and the
+    compiler - which inserts them for the stores it knows - cannot see into the template.  Round 5: without them the second phase of the fc1 epilogue
+    overwrote ~8,000 gelu' values per launch that were still waiting to be read (tests/test_precision_gpu.py::test_linear_fwd caught it).
 usage: check_inline_asm.py file.hip [...]   (exit code 1 on a finding)"""
 import re, sys
 
 SCC_WRITERS = re.compile(r"\b(s_and|s_or|s_xor|s_nand|s_nor|s_xnor|s_andn2|s_orn2|s_add|s_addc|s_sub|s_subb|s_cmp|s_cmpk|s_lshl|s_lshr|s_ashr|s_bfe|s_bfm|s_min|s_max|s_abs|"
                          r"s_not|s_wqm|s_quadmask|s_bitcmp|s_absdiff|s_and_saveexec|s_or_saveexec)\w*\b")
+WIDE_STORE = re.compile(r"\b(global|buffer|flat|scratch)_store_dwordx[34]\b[^\n]*(?:\n\s*([^\n]*))?")
 VCC_WRITERS = re.compile(r"\b(v_cmp\w*|v_cmpx\w*|v_add_co\w*|v_sub_co\w*|v_div_scale\w*)\s+vcc\b")
 
 
@@ -36,6 +41,9 @@ def check(path):
             continue
         if SCC_WRITERS.search(tmpl) and '"scc"' not in clob:
             bad.append((line, "writes SCC without an \"scc\" clobber: " + SCC_WRITERS.search(tmpl).group(0)))
+        for m in WIDE_STORE.finditer(tmpl):
+            if not (m.group(2) or "").strip().startswith("s_nop"):
+                bad.append((line, "vector-memory store of more than 64 bits without an s_nop behind it (late read of the data registers)"))
         if VCC_WRITERS.search(tmpl) and '"vcc"' not in clob:
             bad.append((line, "writes vcc without a \"vcc\" clobber"))
         for reg, save in (("m0", r"s_mov_b32\s+%\d+,\s*m0"), ("exec", r"s_mov_b64\s+%\d+,\s*exec")):

@@ -3,7 +3,8 @@ assembly.  hipcc cannot count loads issued from inline asm, so wherever IT needs
 issued, a spill reload) it waits for the whole queue - every LDS-DMA in flight included - and the prefetch distance of the loop is gone
 (DESIGN.md 5, round 4).
 usage: scan_loop_waits.py file.s [...]                         list every finding
-       scan_loop_waits.py --fail <kernel-name regex> file.s    exit code 1 if a matching kernel has one (used by __graft_entry__.build())"""
+       scan_loop_waits.py --fail <kernel-name regex> file.s    exit code 1 if a matching kernel has one, 2 if NO kernel matches the regex
+                                                               (used by __graft_entry__.build())"""
 import re, sys
 
 
@@ -35,12 +36,19 @@ def scan(path, name_rx=None, min_mfma=12):
     return found
 
 
+def matching_kernels(path, name_rx):
+    return [m.group(1) for m in re.finditer(r"^(_Z\w+):", open(path).read(), re.M) if re.search(name_rx, m.group(1))]
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     rx = None
     if args and args[0] == "--fail":
         rx, args = args[1], args[2:]
     rc = 0
+    if rx and not any(matching_kernels(p, rx) for p in args):      # exit code 2: the pattern matches nothing (stale after a rename / template change)
+        print(f"no kernel matches /{rx}/ in {args}")
+        sys.exit(2)
     for p in args:
         for name, line, mf, text in scan(p, rx):
             print(f"{p}:{line}: {name[:100]}: innermost loop with {mf} MFMAs: {text}")
