@@ -156,6 +156,33 @@ def cpu_baseline(args, model, backs, x, xe, target):
                                  f"iterations after 3 warm-up, {ncpu} threads")), out
 
 
+def attribution_pass(step, lib, precision, nsteps=3):
+    """The per-class table of a workload: `nsteps` steps with every kernel class timed by HIP events on its launch stream (mfvit_prof_*; the caller
+    has serialised whatever streams the workload uses).  Returns (ms per step, {class: launches, avg us, ms per step, TFLOP/s or GB/s, fraction})."""
+    solo = (ctypes.c_double * (NCLS * 4))()
+    step()
+    torch.cuda.synchronize()
+    lib.mfvit_prof_enable((1 << NCLS) - 1)
+    t1 = time.perf_counter()
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t1) / nsteps
+    lib.mfvit_prof_collect(solo, NCLS)
+    lib.mfvit_prof_enable(0)
+    peak_t, per = PEAK_TFLOPS[precision], {}
+    for c in range(NCLS):
+        n, ms_c, fl, by = (solo[c * 4 + i] for i in range(4))
+        if n > 0:
+            e = dict(launches_per_step=n / nsteps, avg_us=round(1e3 * ms_c / n, 2), ms_per_step=round(ms_c / nsteps, 3))
+            if fl > 0:
+                e.update(tflops=round(fl / (ms_c * 1e-3) / 1e12, 1), frac_of_mfma_peak=round(fl / (ms_c * 1e-3) / 1e12 / peak_t, 4))
+            elif by > 0:
+                e.update(gbs=round(by / (ms_c * 1e-3) / 1e9, 1), frac_of_hbm_peak=round(by / (ms_c * 1e-3) / 1e9 / PEAK_HBM_GBS, 4))
+            per[lib.mfvit_prof_class_name(c).decode()] = e
+    return ms, per
+
+
 def other_workloads(args, world, rank, dev, lib):
     """configs[1] (single-stream fwd/bwd, B=64) and configs[3] (MoCo pretrain step, 128 samples / GPU): same timing contract,
     reported with their own metric names (they are NOT the headline metric)."""
@@ -232,13 +259,16 @@ def other_workloads(args, world, rank, dev, lib):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
+    ser_ms, per = attribution_pass(step, lib, args.precision)     # one stream by construction in these workloads
     if rank == 0:
         print(json.dumps(dict(metric=name, value=B * world * args.steps / dt, unit="images/sec", n_gpus=world, steps=args.steps,
                               warmup=args.warmup, ms_per_step=1e3 * dt / args.steps, higher_is_better=True, scaling="weak",
                               vs_baseline=None, dtype=ARITH[args.precision], data="synthetic",
                               config=dict(workload=args.workload, precision=args.precision, per_gpu_batch=B, global_batch=B * world, parallelism=f"dp{world}"),
                               model_tflops=gflop * B * world * args.steps / dt / 1e3 if args.img == 224 else None,
-                              loss=float(loss.detach()))), flush=True)
+                              loss=float(loss.detach()),
+                              serialized_pass=dict(note="3-step attribution pass after the timed region (HIP events per kernel class, mfvit_prof_*)",
+                                                   ms_per_step=round(ser_ms, 3), peak_tflops=PEAK_TFLOPS[args.precision], per_class=per))), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -910,8 +910,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
     }
 }
 
-// out[n][k] += sum_s part[s][n][k]   (K % 4 == 0; one float4 per thread)
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int splits, int N, int K, float* __restrict__ out,
+// out[n][k] += sum_s part[s * stride + n * K + k]   (K % 4 == 0; one float4 per thread; the splits in a FIXED order: run-to-run identical sums)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int splits, long stride, int N, int K, float* __restrict__ out,
                                                         long ldo) {
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     const long total4 = (long)N * K / 4;
@@ -919,11 +919,33 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     const long e = q * 4;
     float4 s = *(const float4*)(part + e);
     for (int t = 1; t < splits; ++t) {
-        const float4 v = *(const float4*)(part + (long)t * N * K + e);
+        const float4 v = *(const float4*)(part + (long)t * stride + e);
         s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
     }
     const int n = (int)(e / K), k = (int)(e % K);
     float4* o = (float4*)(out + (long)n * ldo + k);
+    float4 c = *o;
+    c.x += s.x, c.y += s.y, c.z += s.z, c.w += s.w;
+    *o = c;
+}
+// the same for every job of a batch in one launch (job of a float4 index: binary search over the prefix counts)
+__global__ __launch_bounds__(256) void tn_reduce_batch_kernel(TnPartBatch b) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= b.total4) return;
+    int lo = 0, hi = b.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.job[mid].first4 <= q) lo = mid; else hi = mid - 1;
+    }
+    const TnPartJob& j = b.job[lo];
+    const long e = (q - j.first4) * 4;
+    float4 s = *(const float4*)(j.part + e);
+    for (int t = 1; t < j.splits; ++t) {
+        const float4 v = *(const float4*)(j.part + (long)t * j.stride + e);
+        s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    const int n = (int)(e / j.K), k = (int)(e % j.K);
+    float4* o = (float4*)(j.out + (long)n * j.ldo + k);
     float4 c = *o;
     c.x += s.x, c.y += s.y, c.z += s.z, c.w += s.w;
     *o = c;
@@ -1048,18 +1070,41 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
         MFVIT_LAUNCH((gemm_tn_kernel<T, false>), grid, dim3(256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     if (p.cpart) {
-        const long total4 = (long)p.N * p.K / 4;
-        MFVIT_LAUNCH(tn_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, p.cpart, p.splits, p.N, p.K, (float*)p.out0,
-                     p.ldo0);
-        MFVIT_CHECK_LAUNCH();
+        return tn_partial_reduce(p.cpart, p.splits, (long)p.N * p.K, p.N, p.K, (float*)p.out0, p.ldo0, st);
     }
     return MFVIT_OK;
 }
 
 // out[n][k] += sum over `splits` partial matrices [N][K] (the weight-gradient kernels' plain-store path)
-int tn_partial_reduce(const float* part, int splits, int N, int K, float* out, long ldo, hipStream_t st) {
+static thread_local TnPartBatch* g_tnpart_batch = nullptr;
+TnPartBatch* tnpart_batch_begin(TnPartBatch* b) {
+    TnPartBatch* prev = g_tnpart_batch;
+    if (b) { b->n = 0; b->total4 = 0; }
+    g_tnpart_batch = b;
+    return prev;
+}
+int tnpart_batch_flush(hipStream_t st) {
+    TnPartBatch* b = g_tnpart_batch;
+    if (!b || b->n == 0) return MFVIT_OK;
+    MFVIT_LAUNCH(tn_reduce_batch_kernel, dim3((unsigned)((b->total4 + 255) / 256)), dim3(256), 0, st, *b);
+    b->n = 0;
+    b->total4 = 0;
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+int tn_partial_reduce(const float* part, int splits, long stride, int N, int K, float* out, long ldo, hipStream_t st) {
+    if (TnPartBatch* b = g_tnpart_batch) {                    // deferred (every job has its OWN partial buffer until the flush)
+        if (b->n == TnPartBatch::MAXJ) {
+            const int rc = tnpart_batch_flush(st);
+            if (rc != MFVIT_OK) return rc;
+        }
+        TnPartJob& j = b->job[b->n++];
+        j.part = part; j.out = out; j.stride = stride; j.ldo = ldo; j.splits = splits; j.N = N; j.K = K; j.first4 = b->total4;
+        b->total4 += (long)N * K / 4;
+        return MFVIT_OK;
+    }
     const long total4 = (long)N * K / 4;
-    MFVIT_LAUNCH(tn_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, part, splits, N, K, out, ldo);
+    MFVIT_LAUNCH(tn_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, part, splits, stride, N, K, out, ldo);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

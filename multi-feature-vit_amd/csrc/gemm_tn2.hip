@@ -363,7 +363,8 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
             // split partials as PLAIN stores into scratch [split][N][K] (a register of a 32 x 32 accumulator = two 128-byte row segments: full store
             // rate), summed into out0 by tn_reduce_kernel: the float atomics of this tile (64 KB per workgroup, 16.5 MB per launch at the
             // ~1.3 TB/s atomics run at) were 10 - 13 us at the end of every launch, with nothing left to overlap them
-            float* part = p.cpart + (long)split * p.N * p.K;
+            // (paired launch: a split's region holds the first gradient's [N][K] tile rows, then the second's [N2][K])
+            float* part = p.cpart + (long)split * (p.N + p.res_mod) * p.K + (second ? (long)p.N * p.K : 0);
 #pragma unroll
             for (int i = 0; i < NL; ++i)
 #pragma unroll
@@ -415,14 +416,13 @@ bool gemm_tn_pair_supported(int dtype, const GemmP& a, const GemmP& b) {
     // step in the serialized pass, as the saved atomics predict; with the weight gradients on a side stream the TIMED step loses 0.1 ms - dWproj alone was a short
     // kernel that filled gaps beside the data-gradient chain - on the caller's stream it gains 0.13 ms.)
     if (!gemm_tn_glds_supported(dtype, a) || !gemm_tn_glds_supported(dtype, b)) return false;
-    if (a.M != b.M || a.K != b.K || b.cs0 || a.cpart || b.cpart || a.splits > 0 || b.splits > 0 || a.res_mod || b.res_mod) return false;
+    if (a.M != b.M || a.K != b.K || b.cs0 || b.cpart || a.splits > 0 || b.splits > 0 || a.res_mod || b.res_mod) return false;
     return true;
 }
 
 template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     typedef T2Geo<T> G;
     const int tiles = ((p.N + p.res_mod) / 128) * (p.K / 128);          // res_mod = N of the paired second GEMM (0: none)
-    if (p.res_mod) p.cpart = nullptr;                                   // (the plain-store partial path is single-GEMM)
     if (p.splits <= 0) {
         static const int target_env = [] { const char* e = getenv("MFVIT_TN2_TARGET"); return e ? atoi(e) : 0; }();
         // one workgroup per CU (96 KB of LDS): tiles x splits <= 256; with a second kernel stream beside this one (stream_share(), common.cuh) and a
@@ -438,7 +438,7 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
         p.splits = (p.M + chunk - 1) / chunk;
     }
     // p.cpart (optional scratch of >= 384 tiles of 128 x 128 floats): split partials as plain stores + one reduce pass
-    if (p.splits < 2 || p.ldo0 % 4 || (long)tiles * p.splits > 384) p.cpart = nullptr;
+    if (p.splits < 2 || p.ldo0 % 4 || (p.res_mod && p.ldo1 % 4) || (long)tiles * p.splits > 384) p.cpart = nullptr;
     constexpr int bytes = (is_split<T>::value ? T2_NSP : T2_NS) * T2_STAGE;   // (the pipelined form's ring; the other split forms use three of the four slots)
     p.rows_per_wg = 0;
     // (eight waves per workgroup and the LDS-DMA issue interleaved with the MFMAs - the W8 / IL template flags of the kernel - are the only forms
@@ -469,7 +469,6 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
             static PerDeviceOnce attr_rm;
             if (attr_rm.first())
                 (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<T, false, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            p.cpart = nullptr;
             MFVIT_LAUNCH((gemm_tn_glds_kernel<T, false, true, true, true>), dim3(tiles * p.splits), dim3(512), bytes, st, p);
         } else {
             return MFVIT_EINVAL;
@@ -477,7 +476,12 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     } else if (p.cs0) go1(std::true_type{});
     else go1(std::false_type{});
     MFVIT_CHECK_LAUNCH();
-    if (p.cpart) return tn_partial_reduce(p.cpart, p.splits, p.N, p.K, (float*)p.out0, p.ldo0, st);
+    if (p.cpart) {
+        const long stride = (long)(p.N + p.res_mod) * p.K;
+        const int rc = tn_partial_reduce(p.cpart, p.splits, stride, p.N, p.K, (float*)p.out0, p.ldo0, st);
+        if (rc != MFVIT_OK || !p.res_mod) return rc;
+        return tn_partial_reduce(p.cpart + (long)p.N * p.K, p.splits, stride, p.res_mod, p.K, (float*)p.out1, p.ldo1, st);
+    }
     return MFVIT_OK;
 }
 

@@ -32,7 +32,14 @@ ColpartBatch* colpart_batch_begin(ColpartBatch* b);
 int colpart_batch_flush(hipStream_t st);
 bool gemm_tn_pair_supported(int dtype, const GemmP& a, const GemmP& b);   // gemm_tn2.hip: two weight gradients in one launch
 int gemm_tn_glds_pair(int dtype, GemmP a, const GemmP& b, hipStream_t st);
-int tn_partial_reduce(const float* part, int splits, int N, int K, float* out, long ldo, hipStream_t st);   // out += sum of the split partials [splits][N][K]
+// out[n][k] += sum over the splits of part[s * stride + n * K + k]  (fixed order: deterministic).  Between tnpart_batch_begin(&batch) and
+// tnpart_batch_begin(previous) every call of this thread is queued (its partial buffer must stay untouched until the flush) and
+// tnpart_batch_flush reduces all queued jobs in ONE launch - the weight gradients of a whole encoder-backward call (round 5).
+int tn_partial_reduce(const float* part, int splits, long stride, int N, int K, float* out, long ldo, hipStream_t st);
+struct TnPartJob { const float* part; float* out; long stride, ldo; int splits, N, K; long first4; };   // first4: prefix of float4 counts
+struct TnPartBatch { static constexpr int MAXJ = 56; int n; long total4; TnPartJob job[MAXJ]; };
+TnPartBatch* tnpart_batch_begin(TnPartBatch* b);
+int tnpart_batch_flush(hipStream_t st);
 
 int attn_fwd_exact(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HD, hipStream_t st);
 int attn_bwd_exact(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,

@@ -139,6 +139,7 @@ ShadowLayout shadow_layout(const Dims& d) {
 }
 
 // ------------------------------------------------------------------ workspace layout (bytes)
+constexpr int TN_SLOTS = 5;
 struct WsLayout {
     size_t patches;
     size_t x0, x_stride;        // f32 [M][D], depth+1 (save) or 1 copies
@@ -146,7 +147,7 @@ struct WsLayout {
     size_t blk0, blk_stride;    // per block (depth or 1 copies):
     size_t y1, qkv, attn, lse, xmid, st2, y2, hpre, hact;
     // backward scratch
-    size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart, colpart_stride = 0, tnpart;
+    size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart, colpart_stride = 0, tnpart, tnpart_stride = 0;
     size_t dtmp;                // token-input mode with residual dropout: [M][D] of the operand type (branch output before the dropout; masked dY)
     size_t pp_stride;           // distance between the two ping-pong copies of gxT / gmidT / dhpre / dqkv (0 = none)
     size_t total;
@@ -194,9 +195,10 @@ WsLayout ws_layout(const Dims& d) {
             W.colpart = o; o += (2 * nl + 2) * align256(n * 4);          // one partial buffer per row-kernel launch of a backward call (batched reduce)
             W.colpart_stride = align256(n * 4);
         }
-        // split partials of the weight-gradient GEMMs (side stream, one GEMM at a time): splits * N * K floats, and
-        // tiles * splits <= 384 blocks of 128 x 128  =>  at most 384 * 16384 floats
-        W.tnpart = o; o += align256((size_t)384 * 128 * 128 * 4);
+        // split partials of the weight-gradient GEMMs: one slot per launch of a BLOCK (at most 4) + 1 for the patch embedding, each tiles * splits <= 384
+        // blocks of 128 x 128 floats; reduced by one batched launch per block, in a fixed order (deterministic sums, round 5), then reused
+        W.tnpart_stride = align256((size_t)384 * 128 * 128 * 4);
+        W.tnpart = o; o += (size_t)TN_SLOTS * W.tnpart_stride;
     } else {
         W.gx = W.gmid = W.gxT = W.gmidT = W.dhpre = W.dattn = W.dqkv = W.colscratch = W.colpart = W.tnpart = o;
         W.pp_stride = 0;
@@ -499,18 +501,31 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
         BatchScope(ColpartBatch* b, bool on_) : on(on_) { if (on) prev = colpart_batch_begin(b); }
         ~BatchScope() { if (on) colpart_batch_begin(prev); }
     } batch_scope(&cbatch, !(d.p_resid > 0.f));
-    // split partials of the wgrad GEMMs through scratch (plain stores + one reduce launch) instead of float atomics: opt-in (MFVIT_TN_PART=1;
-    // what it buys is a deterministic dW).  Measured inside the step, round 3, with the store path in the LDS-DMA wgrad kernel itself: class
-    // average 77.2 -> 80.8 us including the reduce launch, step 30.85 -> 31.0 ms (profiles/r03_wgrad_ab.txt) - the atomics of a launch (16.5 MB)
-    // are fire-and-forget and overlap the tail of the kernel and the head of the next one.
-    static const bool tn_part = [] { const char* e = getenv("MFVIT_TN_PART"); return e && e[0] == '1'; }();
-    float* tnpart = tn_part ? (float*)(ws + W.tnpart) : nullptr;
+    // split partials of the weight-gradient GEMMs through scratch - plain stores, every launch into its OWN slot - and ONE batched reduce launch at
+    // the end of every BLOCK that adds the splits in a fixed order: dW is the same bits on every run (the float atomics it replaces add in whatever
+    // order the workgroups finish).  Round 3 measured the same idea with a reduce launch behind EVERY gradient as a loss (77.2 -> 80.8 us per
+    // launch); batched it costs 0.4 - 0.6 % of the step (round 5, profiles/r05_wgrad_partials_ab.txt: weight-gradient class 95.6 -> 90.8 us per launch,
+    // the reduce launches take most of it back; per block - partials still in the Infinity Cache - beats per call by 0.07 ms).  MFVIT_TN_PART=0: float
+    // atomics.  (With the opt-in weight-gradient side stream the partial path is off: its launches are not ordered with the reduce on this stream.)
+    static const bool tn_part_env = [] { const char* e = getenv("MFVIT_TN_PART"); return !(e && e[0] == '0'); }();
+    int tn_used = 0;
+    bool tn_part = tn_part_env;                // (decided below, once use_side is known)
+    auto next_tnpart = [&]() -> float* {       // (more launches than slots between two flushes: float atomics for the rest - never a slot still in use)
+        return tn_part && tn_used < TN_SLOTS ? (float*)(ws + W.tnpart + (size_t)(tn_used++) * W.tnpart_stride) : nullptr;
+    };
+    TnPartBatch tbatch;
+    struct TnScope {
+        TnPartBatch* prev; bool on;
+        TnScope(TnPartBatch* b, bool on_) : on(on_) { if (on) prev = tnpart_batch_begin(b); }
+        ~TnScope() { if (on) tnpart_batch_begin(prev); }
+    } tn_scope(&tbatch, tn_part_env);
     // dY buffers by layer parity (the embed stage counts as layer -1 -> parity 1)
     auto pp = [&](size_t off, int l) { return (void*)(ws + off + (size_t)(l & 1) * W.pp_stride); };
     SideStream& ss = side_stream(st);
     // (residual dropout: the masked dY copies live in ONE scratch buffer - everything stays on the caller's stream)
     const bool use_side = ss.ok && W.pp_stride != 0 && g_wgrad_stream.load(std::memory_order_relaxed) != 0 && !(d.p_resid > 0.f);
     hipStream_t wst = use_side ? ss.s : st;                       // stream of the weight-gradient GEMMs
+    tn_part = tn_part_env && !use_side;
     // the side stream may only start after everything already queued on the caller's stream (activations, zeroed gradients)
     auto fork = [&]() -> int {                                    // main -> side dependency at this point of the main stream
         if (!use_side) return MFVIT_OK;
@@ -557,7 +572,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.M = d.M; p.N = d.D; p.K = d.F;
                 if (rdrop) p.cs0 = gb + L.fc2_b;
                 p.out0 = gb + L.fc2_w; p.ldo0 = F;
-                p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
+                p.cpart = next_tnpart();                          // split partials: plain stores, reduced in a fixed order at the end of the call
                 MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
             {   // dhpre = (gx W2) * gelu'(hpre)
@@ -576,7 +591,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.M = d.M; p.N = d.F; p.K = d.D;
                 if (!fc1b_in_tile()) p.cs0 = gb + L.fc1_b;        // d fc1_b += column sums of dhpre (ones-fragment MFMA in the wgrad kernel)
                 p.out0 = gb + L.fc1_w; p.ldo0 = D;
-                p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
+                p.cpart = next_tnpart();                          // split partials: plain stores, reduced in a fixed order at the end of the call
                 MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
             {   // gmid = LN2bwd(dhpre W1) + gx ; d ln2_w, d ln2_b, d proj_b
@@ -608,10 +623,10 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.M = d.M; p.N = d.D; p.K = d.D;
                 if (rdrop) p.cs0 = gb + L.proj_b;
                 p.out0 = gb + L.proj_w; p.ldo0 = D;
-                p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
+                p.cpart = next_tnpart();                          // split partials: plain stores, reduced in a fixed order at the end of the call
                 // held back by default when the weight gradients run on the caller's stream (nothing to overlap: one launch less is a pure gain,
                 // 30.81 -> 30.68 ms per step)
-                if (!rdrop && !tnpart && !use_side) {
+                if (!rdrop && !use_side) {
                     pend_proj = p;
                     have_pend = true;
                 } else {
@@ -638,15 +653,21 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.M = d.M; p.N = 3 * d.D; p.K = d.D;
                 p.cs0 = gb + L.qkv_b;
                 p.out0 = gb + L.qkv_w; p.ldo0 = D;
-                p.cpart = tnpart;                                 // split partials: plain stores + one reduce pass instead of float atomics
+                p.cpart = next_tnpart();                          // split partials: plain stores, reduced in a fixed order at the end of the call
                 // dWproj rides along when the LDS-DMA kernel takes both (same rows, same K = 384: 27 + 9 tiles x 7 splits = 252 workgroups): the
                 // float atomics of one launch (16.5 MB, 12.5 us) and one prologue less per block
-                if (have_pend && gemm_tn_pair_supported(d.dtype, p, pend_proj)) {
-                    MFVIT_TRY(gemm_tn_glds_pair(d.dtype, p, pend_proj, wst));
+                GemmP pend_nc = pend_proj;
+                pend_nc.cpart = nullptr;                          // (in the paired launch both gradients' partials go to dWqkv's slot)
+                if (have_pend && gemm_tn_pair_supported(d.dtype, p, pend_nc)) {
+                    MFVIT_TRY(gemm_tn_glds_pair(d.dtype, p, pend_nc, wst));
                 } else {
                     if (have_pend) MFVIT_TRY(gemm_tn(d.dtype, pend_proj, wst));
                     MFVIT_TRY(gemm_tn(d.dtype, p, wst));
                 }
+            }
+            if (tn_part) {                                        // dW += this block's split partials, splits in a fixed order; the slots are free again
+                MFVIT_TRY(tnpart_batch_flush(wst));
+                tn_used = 0;
             }
             if (use_side && hipEventRecord(ss.done[l & 63], ss.s) != hipSuccess) return MFVIT_ELAUNCH;
             MFVIT_TRY(wait_layer(l + 1));                         // fc2-wgrad of layer l+1 reads the gxT copy written next
@@ -687,6 +708,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.M = d.Mp; p.N = d.D; p.K = 768;
                 p.orow_in = d.np; p.orow_out = d.T; p.orow_off = 1;
                 p.out0 = dparams + L.pe_w; p.ldo0 = 768;
+                p.cpart = next_tnpart();
                 MFVIT_TRY(gemm_tn(d.dtype, p, st));
             }
         }
@@ -695,6 +717,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     if (use_side) {   // join: everything the side stream did is ordered before whatever the caller queues next
         if (hipEventRecord(ss.end, ss.s) != hipSuccess || hipStreamWaitEvent(st, ss.end, 0) != hipSuccess) return MFVIT_ELAUNCH;
     }
+    MFVIT_TRY(tnpart_batch_flush(st));      // dW += the split partials of every weight gradient of this call, splits in a fixed order
     return MFVIT_OK;
 }
 

@@ -229,3 +229,32 @@ def test_default_1000_class_head_runs_on_the_hip_head_kernels():
     (logits * r.to("cuda:0")).sum().backward()
     (ref * r.double()).sum().backward()
     assert scale_err(m.head.weight.grad, pd["head.weight"].grad) < 1e-3 and scale_err(m.head.bias.grad, pd["head.bias"].grad) < 1e-3
+
+
+@pytest.mark.parametrize("B", [16, 3])
+def test_weight_gradients_are_bit_identical_from_run_to_run(B):
+    """The weight-gradient GEMMs leave their split partials as plain stores and a batched reduce adds them in a FIXED order (round 5; VERDICT r4 task 5:
+    the float atomics they replace add in whatever order the workgroups finish): two backward passes over the same forward give the SAME BITS for every
+    2-D weight gradient - qkv / proj / fc1 / fc2 of every block and the patch embedding - at B = 16 (M = 3,152: the LDS-DMA kernel, paired dWqkv + dWproj
+    launch) and at B = 3 (M = 591: gemm_tn).  That is 99.9 % of the parameters.  The 1-D gradients - LayerNorm weights / biases and the proj / fc2
+    biases (column partials whose second-stage reduce still uses float atomics over groups of 32 tiles), the qkv / fc1 biases (ones-fragment sums in
+    the weight-gradient kernel, tile-epilogue atomics), cls_token - are still order-dependent: equal to rounding, asserted as such."""
+    import vits
+    depth = 2
+    m = vits.vit_small(num_classes=0, depth=depth, precision="bf16x3")
+    m.load_state_dict(ref_vit.seeded_params(611, num_classes=0, depth=depth), strict=False)
+    m = m.to("cuda:0")
+    x = rng_tensor(612, (B, 3, 224, 224)).to("cuda:0")
+    w = rng_tensor(613, (B, 197, 384)).to("cuda:0")
+    runs = []
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        (m.features3D(x) * w).sum().backward()
+        torch.cuda.synchronize()
+        runs.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    two_d = [n for n, g in runs[0].items() if g.ndim >= 2 and n != "cls_token"]
+    assert len(two_d) == 4 * depth + 1, two_d
+    for n in two_d:
+        assert torch.equal(runs[0][n], runs[1][n]) and torch.equal(runs[0][n], runs[2][n]), n
+    for n, g in runs[0].items():
+        assert float((g - runs[1][n]).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-12, n
