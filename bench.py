@@ -501,11 +501,11 @@ def main():
                             "are under profiles/")
         # HBM bytes per launch from the committed PMC passes: only when they were measured on THESE kernel sources at this precision
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r04_hbm_traffic_by_class.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r05_hbm_traffic_by_class.json")))
             if (tj.get("source_hash") == _lib.source_hash() and tj.get("precision") == args.precision and args.batch == 128
                     and args.img == 224 and name in tj["per_class"]):
                 roof["traffic"] = tj["per_class"][name]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = ("profiles/r04_hbm_traffic_by_class.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                roof["traffic_source"] = ("profiles/r05_hbm_traffic_by_class.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                                           f"kernel sources {tj['source_hash'][:12]})")
             else:
                 roof["traffic_note"] = "committed PMC traffic was measured on other kernel sources / another precision: not reported"
