@@ -47,19 +47,31 @@ class FusionFn(torch.autograd.Function):
         arena, cfg = ctx.arena, ctx.cfg
         flat = arena.ensure()
         need_df = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        gflat = torch.zeros_like(flat)
+        # ONE zeroed buffer for every accumulated gradient of this node (the fusion arena + the four head tensors): one fill launch per step
+        # instead of five; every view starts 16-byte aligned
+        sizes = [flat.numel()]
+        want = [False] * 4
+        if ctx.have_heads:
+            want = [bool(ctx.needs_input_grad[i]) for i in (3, 4, 5, 6)]
+            sizes += [hw_c.numel() if want[0] else 0, hw_c.shape[0] if want[1] else 0, hw_e.numel() if want[2] else 0, hw_e.shape[0] if want[3] else 0]
+        offs, tot = [], 0
+        for n in sizes:
+            offs.append(tot)
+            tot += (n + 3) // 4 * 4
+        zbuf = torch.zeros(tot, device=flat.device, dtype=torch.float32)
+        gflat = zbuf[:flat.numel()]
         df_c = torch.empty_like(f_cxr) if need_df else None
         df_e = torch.empty_like(f_enh) if need_df else None
         dhw_c = dhb_c = dhw_e = dhb_e = None
         if ctx.have_heads:
-            if ctx.needs_input_grad[3]:
-                dhw_c = torch.zeros_like(hw_c)
-            if ctx.needs_input_grad[4]:
-                dhb_c = torch.zeros(hw_c.shape[0], device=hw_c.device, dtype=torch.float32)
-            if ctx.needs_input_grad[5]:
-                dhw_e = torch.zeros_like(hw_e)
-            if ctx.needs_input_grad[6]:
-                dhb_e = torch.zeros(hw_e.shape[0], device=hw_e.device, dtype=torch.float32)
+            if want[0]:
+                dhw_c = zbuf[offs[1]:offs[1] + hw_c.numel()].view_as(hw_c)
+            if want[1]:
+                dhb_c = zbuf[offs[2]:offs[2] + hw_c.shape[0]]
+            if want[2]:
+                dhw_e = zbuf[offs[3]:offs[3] + hw_e.numel()].view_as(hw_e)
+            if want[3]:
+                dhb_e = zbuf[offs[4]:offs[4] + hw_e.shape[0]]
         dfused = dfused.contiguous().float()
         dx_c = dx_c.contiguous().float() if ctx.have_heads else None
         dx_e = dx_e.contiguous().float() if ctx.have_heads else None
