@@ -131,6 +131,78 @@ int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long
     return MFVIT_OK;
 }
 
+// ------------------------------------------------------------------------------------- GEMM output + residual -> LayerNorm rows (unfused path)
+// What the row-complete GEMM kernels fuse (gemm_rowp.hip / gemm_nt_row: N = 384 only), as a separate row pass behind a plain tile GEMM - the path of
+// every embed dim the row kernels are not built for (vit_base: 768) and an A/B partner at small M:
+//   v = tin[g] (operand type T: the GEMM's output incl. bias) (+ pos[(go % pmod)] f32) (+ res[go] f32);  x[go] = v;  y[go] = LN(v);  mean, rstd [go]
+// with the output row go = (g / rin) * rout + roff + g % rin  (rin = 0: go = g) - the patch embedding writes the np patch rows of image b behind
+// its cls row (rin = np, rout = T, roff = 1; pos = pos_embed, pmod = T).  One wave per row.
+template <typename T, int NPL>
+__global__ __launch_bounds__(256) void add_ln_rows_kernel(const T* __restrict__ tin, long ldt, const float* __restrict__ pos, long ldp, int pmod,
+                                                          const float* __restrict__ res, long ldres, int rin, int rout, int roff,
+                                                          float* __restrict__ xout, long ldx, void* __restrict__ y, long ldy, int y_f32,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int rows) {
+    constexpr int N = NPL * 64;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= rows) return;
+    const long go = rin ? (long)(g / rin) * rout + roff + g % rin : g;
+    float v[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int n = lane + 64 * i;
+        float t = load_elem<T>(tin + (long)g * ldt, n);
+        if (pos) t += pos[(pmod ? go % pmod : go) * ldp + n];
+        v[i] = res ? res[go * ldres + n] + t : t;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) s += v[i];
+    const float mu = wave_sum(s) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { const float dd = v[i] - mu; q += dd * dd; }
+    const float rs = rsqrtf(wave_sum(q) * (1.0f / N) + eps);
+    if (lane == 0) {
+        if (mean) mean[go] = mu;
+        if (rstd) rstd[go] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int n = lane + 64 * i;
+        if (xout) xout[go * ldx + n] = v[i];
+        const float o = (v[i] - mu) * rs * gamma[n] + beta[n];
+        if (y_f32) ((float*)y)[go * ldy + n] = o;
+        else store_elem<T>((T*)y + go * ldy, n, o);
+    }
+}
+int add_ln_rows(int dtype, int N, const void* tin, long ldt, const float* pos, long ldp, int pmod, const float* res, long ldres, int rin, int rout,
+                int roff, float* xout, long ldx, void* y, long ldy, int y_f32, const float* gamma, const float* beta, float eps, float* mean,
+                float* rstd, int rows, hipStream_t st) {
+    if (rows <= 0) return MFVIT_OK;
+    if (!tin || !y || !gamma || !beta || (rin && (rout < rin || roff < 0))) return MFVIT_EINVAL;
+    const dim3 grid((rows + 3) / 4), blk(256);
+#define MFVIT_ALN(TT, NPL)                                                                                                                 \
+    MFVIT_LAUNCH((add_ln_rows_kernel<TT, NPL>), grid, blk, 0, st, (const TT*)tin, ldt, pos, ldp, pmod, res, ldres, rin, rout, roff, xout, ldx, y, \
+                 ldy, y_f32, gamma, beta, eps, mean, rstd, rows)
+#define MFVIT_ALN_N(NPL)                                  \
+    switch (dtype) {                                      \
+        case MFVIT_BF16: MFVIT_ALN(bf16, NPL); break;     \
+        case MFVIT_BF16X3: MFVIT_ALN(sbf16, NPL); break;  \
+        case MFVIT_F16: MFVIT_ALN(f16, NPL); break;       \
+        case MFVIT_F32: MFVIT_ALN(float, NPL); break;     \
+        default: return MFVIT_EINVAL;                     \
+    }
+    if (N == 384) { MFVIT_ALN_N(6) }
+    else if (N == 768) { MFVIT_ALN_N(12) }
+    else return MFVIT_EINVAL;
+#undef MFVIT_ALN_N
+#undef MFVIT_ALN
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+
 // ------------------------------------------------------------------------------------- dropout + residual + LayerNorm rows (TransFuser GPT)
 // One wave per row:  v = drop(t) with t = tin[row] (operand type, a GEMM output incl. bias)  or  a0[row] (+ a1[row % mod1]) (f32);
 // x = res[row] + v (res optional); writes x (f32), y = LN(x) (T or f32), mean, rstd.  The keep mask of element (row, n) is
@@ -230,7 +302,9 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ dres, long ldres,
                                                           float* __restrict__ dx, long lddx, T* __restrict__ dxT, long lddxT,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dcol,
-                                                          float* __restrict__ cpart, int rows, int row_stride, int row_off) {
+                                                          float* __restrict__ cpart, int rows, int row_stride, int row_off,
+                                                          const T* __restrict__ dyT, long lddyT) {
+    // (dyT != NULL: dy comes in the operand type - the output of a plain tile GEMM, the unfused path - instead of f32)
     constexpr int N = NPL * 64;
     __shared__ float red[3][4][N];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -245,7 +319,7 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             const int n = lane + 64 * i;
-            d[i] = dy[g * lddy + n];
+            d[i] = dyT ? load_elem<T>(dyT + g * lddyT, n) : dy[g * lddy + n];
             h[i] = (x[g * ldx + n] - mu) * rs;
             const float t = d[i] * gm[i];
             s1 += t;
@@ -288,14 +362,15 @@ __global__ __launch_bounds__(256) void ln_bwd_rows_kernel(const float* __restric
 }
 int ln_bwd_rows(int dtype, int N, const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                 const float* gamma, const float* dres, long ldres, float* dx, long lddx, void* dxT, long lddxT, float* dgamma, float* dbeta,
-                float* dcol, float* cpart, int rows, int row_stride, int row_off, hipStream_t st) {
+                float* dcol, float* cpart, int rows, int row_stride, int row_off, hipStream_t st, const void* dyT, long lddyT) {
     if (rows <= 0) return MFVIT_OK;
+    if (!dy && !dyT) return MFVIT_EINVAL;
     int blocks = (rows + 3) / 4;
     const int cap = cpart ? 256 : 1024;
     if (blocks > cap) blocks = cap;
 #define MFVIT_LNB(TT, NPL)                                                                                                         \
     MFVIT_LAUNCH((ln_bwd_rows_kernel<TT, NPL>), dim3(blocks), dim3(256), 0, st, dy, lddy, x, ldx, mean, rstd, gamma, dres, ldres, dx, \
-                       lddx, (TT*)dxT, lddxT, dgamma, dbeta, dcol, cpart, rows, row_stride, row_off)
+                       lddx, (TT*)dxT, lddxT, dgamma, dbeta, dcol, cpart, rows, row_stride, row_off, (const TT*)dyT, lddyT)
 #define MFVIT_LNB_N(NPL)                                  \
     switch (dtype) {                                      \
         case MFVIT_BF16: MFVIT_LNB(bf16, NPL); break;     \

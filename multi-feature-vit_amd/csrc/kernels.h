@@ -57,7 +57,11 @@ int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long
             int in0_bcast, hipStream_t st);
 int ln_bwd_rows(int dtype, int N, const float* dy, long lddy, const float* x, long ldx, const float* mean, const float* rstd,
                 const float* gamma, const float* dres, long ldres, float* dx, long lddx, void* dxT, long lddxT, float* dgamma, float* dbeta,
-                float* dcol, float* cpart, int rows, int row_stride, int row_off, hipStream_t st);
+                float* dcol, float* cpart, int rows, int row_stride, int row_off, hipStream_t st, const void* dyT = nullptr, long lddyT = 0);
+// v = tin[g] (operand type) (+ pos[go % pmod]) (+ res[go]) -> x[go], y[go] = LN(v), statistics; go = (g / rin) * rout + roff + g % rin (rin = 0: g)
+int add_ln_rows(int dtype, int N, const void* tin, long ldt, const float* pos, long ldp, int pmod, const float* res, long ldres, int rin, int rout,
+                int roff, float* xout, long ldx, void* y, long ldy, int y_f32, const float* gamma, const float* beta, float eps, float* mean,
+                float* rstd, int rows, hipStream_t st);
 int cast_transpose(int dtype, const float* src, void* dst, void* dstT, int R, int C, hipStream_t st);
 int cast_transpose_batched(int dtype, const float* src, void* dst, void* dstT, int R, int C, int nb, long s_src, long s_dst, long s_dstT,
                            hipStream_t st);

@@ -32,6 +32,7 @@ struct Dims {
     float p_embd, p_attn, p_resid;      // token-input mode: dropout sites (0 = off)
     unsigned long long seed;
     bool drop;                          // any site active
+    bool unfused;                       // residual + LayerNorm (and its backward) as row passes behind plain tile GEMMs instead of the row-complete GEMM kernels
 };
 
 bool get_dims(const mfvit_vit_cfg* c, Dims& d) {
@@ -41,7 +42,8 @@ bool get_dims(const mfvit_vit_cfg* c, Dims& d) {
     if (c->batch <= 0) return false;
     if (d.tok ? c->tokens <= 0 : (c->img_h <= 0 || c->img_w <= 0 || c->img_h % 16 || c->img_w % 16)) return false;
     if (c->act != 0 && c->act != 1) return false;
-    if (c->dim != 384 || c->depth <= 0 || c->heads <= 0 || c->dim % c->heads) return false;
+    // embed dim: 384 (vit_small: the row-complete GEMM kernels with their fused LayerNorm epilogues) or 768 (vit_base: plain tile GEMMs + row passes)
+    if ((c->dim != 384 && c->dim != 768) || c->depth <= 0 || c->heads <= 0 || c->dim % c->heads) return false;
     if (c->mlp_dim % 128 || c->mlp_dim <= 0) return false;
     d.dtype = c->dtype;
     d.B = c->batch;
@@ -70,6 +72,10 @@ bool get_dims(const mfvit_vit_cfg* c, Dims& d) {
     if (d.HD != 32 && d.HD != 64 && d.HD != 96) return false;
     if (d.HD == 96 && c->dtype == MFVIT_F32) return false;      // head_dim 96 runs on the streaming MFMA kernels (16-bit types, split bf16)
     if (c->dtype == MFVIT_BF16X3 && d.HD % 32) return false;    // a head's row piece is whole [hi x 32 | lo x 32] groups
+    // MFVIT_UNFUSED_ROWS=1 forces the unfused path at dim 384 too (tests: the same encoder through both paths; tools: A/B at small M)
+    // (read on every call, not cached: the workspace layout depends on it, and a test flips it between two encoders of one process)
+    const char* ue = getenv("MFVIT_UNFUSED_ROWS");
+    d.unfused = d.D != 384 || (ue && ue[0] == '1');
     return true;
 }
 
@@ -149,6 +155,7 @@ struct WsLayout {
     // backward scratch
     size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart, colpart_stride = 0, tnpart, tnpart_stride = 0;
     size_t dtmp;                // token-input mode with residual dropout: [M][D] of the operand type (branch output before the dropout; masked dY)
+    size_t utmp;                // unfused path: [M][D] of the operand type (output of the plain tile GEMM in front of a LayerNorm / LayerNorm-backward row pass)
     size_t pp_stride;           // distance between the two ping-pong copies of gxT / gmidT / dhpre / dqkv (0 = none)
     size_t total;
 };
@@ -204,6 +211,7 @@ WsLayout ws_layout(const Dims& d) {
         W.pp_stride = 0;
     }
     W.dtmp = o; o += (d.tok && d.p_resid > 0.f) ? align256(M * D * es) : 0;
+    W.utmp = o; o += align256(M * D * es);     // always there (1 / 200 of the workspace): the layout does not depend on which path a call takes
     W.total = o;
     return W;
 }
@@ -357,7 +365,18 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
     } else {
     // patch embedding: im2col -> row-complete GEMM (+bias +pos_embed) -> x_0, LN1_0 -> y1_0
     MFVIT_TRY(im2col16(d.dtype, img, ws + W.patches, d.B, cfg->img_h, cfg->img_w, st));
-    {
+    if (d.unfused) {
+        // plain GEMM + bias -> scratch, then one row pass: + pos_embed, the patch rows of image b behind its cls row, LN1_0
+        GemmP q = zero_gemm();
+        q.A = ws + W.patches; q.lda = 768 * e;
+        q.W = hw ? (const void*)(sh + S.pe_w) : (const void*)(params + L.pe_w); q.ldw = 768 * e;
+        q.M = d.Mp; q.N = d.D; q.K = 768;
+        q.bias = params + L.pe_b;
+        q.out0 = ws + W.utmp; q.ldo0 = D * e;
+        MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS, q, st));
+        MFVIT_TRY(add_ln_rows(d.dtype, d.D, ws + W.utmp, D * e, params + L.pos, D, d.T, nullptr, 0, d.np, d.T, 1, xbuf(0), D, blk(0) + W.y1, D * e, 0,
+                              pblk(0) + L.ln1_w, pblk(0) + L.ln1_b, eps, stat(0), stat(0) + d.M, d.Mp, st));
+    } else {
         GemmP p = zero_gemm();
         p.A = ws + W.patches; p.lda = 768 * e;
         p.W = hw ? (const void*)(sh + S.pe_w) : (const void*)(params + L.pe_w); p.ldw = 768 * e;
@@ -418,6 +437,14 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
                 MFVIT_TRY(drop_add_ln_rows(d.dtype, d.D, ws + W.dtmp, D * e, nullptr, 0, nullptr, 0, 0, xbuf(l), D,
                                            make_drop(d.p_resid, d.seed, site(l, 3)), (float*)(b + W.xmid), D, b + W.y2, D * e, 0, p.gamma, p.beta,
                                            eps, p.mean, p.rstd, d.M, st));
+            } else if (d.unfused) {
+                // plain GEMM + bias -> scratch, then residual + LN2 as one row pass
+                GemmP q = zero_gemm();
+                q.A = p.A; q.lda = p.lda; q.W = p.W; q.ldw = p.ldw; q.M = p.M; q.N = p.N; q.K = p.K; q.bias = p.bias;
+                q.out0 = ws + W.utmp; q.ldo0 = D * e;
+                MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS, q, st));
+                MFVIT_TRY(add_ln_rows(d.dtype, d.D, ws + W.utmp, D * e, nullptr, 0, 0, xbuf(l), D, 0, 0, 0, (float*)(b + W.xmid), D, b + W.y2, D * e, 0,
+                                      p.gamma, p.beta, eps, p.mean, p.rstd, d.M, st));
             } else {
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
             }
@@ -459,6 +486,13 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
                 MFVIT_TRY(drop_add_ln_rows(d.dtype, d.D, ws + W.dtmp, D * e, nullptr, 0, nullptr, 0, 0, (const float*)(b + W.xmid), D,
                                            make_drop(d.p_resid, d.seed, site(l, 4)), xbuf(l + 1), D, p.out1, p.ldo1, p.y_f32, p.gamma, p.beta, eps,
                                            p.mean, p.rstd, d.M, st));
+            } else if (d.unfused) {
+                GemmP q = zero_gemm();
+                q.A = p.A; q.lda = p.lda; q.W = p.W; q.ldw = p.ldw; q.M = p.M; q.N = p.N; q.K = p.K; q.bias = p.bias;
+                q.out0 = ws + W.utmp; q.ldo0 = D * e;
+                MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_BIAS, q, st));
+                MFVIT_TRY(add_ln_rows(d.dtype, d.D, ws + W.utmp, D * e, nullptr, 0, 0, (const float*)(b + W.xmid), D, 0, 0, 0, xbuf(l + 1), D, p.out1,
+                                      p.ldo1, p.y_f32, p.gamma, p.beta, eps, p.mean, p.rstd, d.M, st));
             } else {
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
             }
@@ -539,7 +573,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
 
     // only split bf16 (hi + lo = the f32 value to 2^-17) drops the f32 residual-gradient copies; plain bf16 / fp16 keep them: re-rounding the residual
     // gradient to 8 / 11 mantissa bits at each of the 2 x depth LayerNorm-backward stages departs from the reference's autocast (fp32 residual grads)
-    const bool lean_grad = d.dtype == MFVIT_BF16X3;
+    const bool lean_grad = d.dtype == MFVIT_BF16X3 && !d.unfused;   // (the unfused row passes read the f32 residual gradient)
     auto site = [](int l, int which) { return 16u * (unsigned)l + (unsigned)which; };
     const bool rdrop = d.p_resid > 0.f;             // the bias gradients of proj / fc2 then come from the MASKED dY (wgrad column sums)
     for (int s = stage_hi; s >= stage_lo; --s) {
@@ -607,6 +641,15 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 else { p.res = gx; p.ldres = D; p.out0 = gmid; }
                 p.ldo0 = D; p.out1 = gmidT; p.ldo1 = D * e;
                 p.cs0 = gb + L.ln2_w; p.cs1 = gb + L.ln2_b; p.cs2 = rdrop ? colscr + D : gb + L.proj_b; p.cpart = next_colpart();
+                if (d.unfused) {
+                    // plain data-gradient GEMM -> scratch, then the LayerNorm backward + residual-gradient add + column sums as one row pass
+                    GemmP q = zero_gemm();
+                    q.A = p.A; q.lda = p.lda; q.W = p.W; q.ldw = p.ldw; q.M = p.M; q.N = p.N; q.K = p.K;
+                    q.out0 = ws + W.utmp; q.ldo0 = D * e;
+                    MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, q, st));
+                    MFVIT_TRY(ln_bwd_rows(d.dtype, d.D, nullptr, 0, (const float*)(b + W.xmid), D, p.mean, p.rstd, p.gamma, gx, D, gmid, D, gmidT, D * e,
+                                          p.cs0, p.cs1, p.cs2, p.cpart, d.M, 1, 0, st, ws + W.utmp, D * e));
+                } else
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
             const void* gyp = gmidT;                              // dY of proj
@@ -683,6 +726,14 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 else { p.res = gmid; p.ldres = D; p.out0 = gx; }
                 p.ldo0 = D; p.out1 = pp(W.gxT, l - 1); p.ldo1 = D * e;
                 p.cs0 = gb + L.ln1_w; p.cs1 = gb + L.ln1_b; p.cs2 = (l > 0 && !rdrop) ? gblk(l - 1) + L.fc2_b : colscr; p.cpart = next_colpart();
+                if (d.unfused) {
+                    GemmP q = zero_gemm();
+                    q.A = p.A; q.lda = p.lda; q.W = p.W; q.ldw = p.ldw; q.M = p.M; q.N = p.N; q.K = p.K;
+                    q.out0 = ws + W.utmp; q.ldo0 = D * e;
+                    MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, q, st));
+                    MFVIT_TRY(ln_bwd_rows(d.dtype, d.D, nullptr, 0, xbuf(l), D, p.mean, p.rstd, p.gamma, gmid, D, gx, D, pp(W.gxT, l - 1), D * e,
+                                          p.cs0, p.cs1, p.cs2, p.cpart, d.M, 1, 0, st, ws + W.utmp, D * e));
+                } else
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
             }
         } else if (d.tok) {

@@ -137,9 +137,9 @@ class VisionTransformerMoCo(nn.Module):
         super().__init__()
         if patch_size != 16:
             raise NotImplementedError("only patch_size=16 (ViT-S/16) is built")
-        if embed_dim != 384:
-            raise NotImplementedError("the gfx950 row-complete kernels are built for embed_dim=384 (vit_small); "
-                                      "vit_base is not on the hot path (SURVEY.md §8)")
+        if embed_dim not in (384, 768):
+            raise NotImplementedError("the gfx950 encoder is built for embed_dim 384 (vit_small: row-complete GEMM kernels with fused LayerNorm "
+                                      "epilogues) and 768 (vit_base: tile GEMMs + LayerNorm row passes)")
         if not qkv_bias:
             raise NotImplementedError("qkv_bias=False is not used by the reference (moco-v3 vits: qkv_bias=True)")
         self.img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
@@ -196,20 +196,28 @@ class VisionTransformerMoCo(nn.Module):
                 nn.init.zeros_(self.head.bias)
 
     # ------------------------------------------------------------------ flat arena
+    def _param_holders(self):
+        """(name, holder module, attribute) of every arena parameter in arena order (include/mfvit.h); built once - the module tree of the
+        encoder is fixed at construction.  The parameters themselves are looked up through the holders on every use (a caller may rebind
+        ``holder.weight``), without going through ``nn.Module.__getattr__`` and without formatting 150 names per call (host time of a
+        small-batch step, tools/host_profile.py)."""
+        h = self.__dict__.get("_holders")
+        if h is None:
+            pe = self.patch_embed.proj
+            h = [("cls_token", self, "cls_token"), ("pos_embed", self, "pos_embed"),
+                 ("patch_embed.proj.weight", pe, "weight"), ("patch_embed.proj.bias", pe, "bias")]
+            for i, b in enumerate(self.blocks):
+                p = f"blocks.{i}."
+                for mod_name, mod in (("norm1", b.norm1), ("attn.qkv", b.attn.qkv), ("attn.proj", b.attn.proj), ("norm2", b.norm2),
+                                      ("mlp.fc1", b.mlp.fc1), ("mlp.fc2", b.mlp.fc2)):
+                    h += [(p + mod_name + ".weight", mod, "weight"), (p + mod_name + ".bias", mod, "bias")]
+            h += [("norm.weight", self.norm, "weight"), ("norm.bias", self.norm, "bias")]
+            self.__dict__["_holders"] = h
+        return h
+
     def arena_named_parameters(self):
         """(name, Parameter) in arena order (include/mfvit.h); the classifier head is not part of the arena."""
-        out = [("cls_token", self.cls_token), ("pos_embed", self.pos_embed),
-               ("patch_embed.proj.weight", self.patch_embed.proj.weight), ("patch_embed.proj.bias", self.patch_embed.proj.bias)]
-        for i, b in enumerate(self.blocks):
-            p = f"blocks.{i}."
-            out += [(p + "norm1.weight", b.norm1.weight), (p + "norm1.bias", b.norm1.bias),
-                    (p + "attn.qkv.weight", b.attn.qkv.weight), (p + "attn.qkv.bias", b.attn.qkv.bias),
-                    (p + "attn.proj.weight", b.attn.proj.weight), (p + "attn.proj.bias", b.attn.proj.bias),
-                    (p + "norm2.weight", b.norm2.weight), (p + "norm2.bias", b.norm2.bias),
-                    (p + "mlp.fc1.weight", b.mlp.fc1.weight), (p + "mlp.fc1.bias", b.mlp.fc1.bias),
-                    (p + "mlp.fc2.weight", b.mlp.fc2.weight), (p + "mlp.fc2.bias", b.mlp.fc2.bias)]
-        out += [("norm.weight", self.norm.weight), ("norm.bias", self.norm.bias)]
-        return out
+        return [(name, mod._parameters[attr]) for name, mod, attr in self._param_holders()]
 
     def _flatten(self):
         named = self.arena_named_parameters()
@@ -227,6 +235,7 @@ class VisionTransformerMoCo(nn.Module):
                 off += n
         self._arena = arena
         self._arena_params = [p for _, p in named]
+        self._arena_offsets = [self._offsets[name][0] for name, _ in named]      # (same order as _param_holders())
         self._shadow = None
         self._shadow_key = None
         self._ws_pool = {}
@@ -234,9 +243,10 @@ class VisionTransformerMoCo(nn.Module):
 
     def _arena_intact(self):
         base = self._arena.data_ptr()
-        for (name, p) in self.arena_named_parameters():
-            off, n = self._offsets[name]
-            if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+        f32 = torch.float32
+        for (_, mod, attr), off in zip(self._param_holders(), self._arena_offsets):
+            p = mod._parameters[attr]
+            if p.data_ptr() != base + 4 * off or p.dtype != f32:
                 return False
         return True
 
@@ -291,7 +301,7 @@ class VisionTransformerMoCo(nn.Module):
     def _get_ws(self, cfg):
         nbytes = lib().mfvit_vit_workspace_bytes(cfg)
         if nbytes == 0:
-            raise _lib.MfvitError("invalid encoder configuration (image size must be a multiple of 16, dim 384)")
+            raise _lib.MfvitError("invalid encoder configuration (image size must be a multiple of 16, dim 384 or 768, head_dim 32 / 64 / 96)")
         pool = self._ws_pool.setdefault(nbytes, [])
         return pool.pop() if pool else torch.empty(nbytes, device=self._arena.device, dtype=torch.uint8)
 
@@ -365,14 +375,12 @@ class VisionTransformerMoCo(nn.Module):
                 hook(self, hi, lo, gflat)
                 hi = lo - 1
         self._last_grad_arena = gflat
-        grads = []
-        for name, p in self.arena_named_parameters():
-            if p.requires_grad:
-                off, n = self._offsets[name]
-                grads.append(gflat[off:off + n].view(p.shape))
-            else:
-                grads.append(None)
-        return grads
+        # per-parameter views of the flat gradient arena, arena order: ONE C++ call for the 150 views (a Python loop of slice + view cost 0.3 ms
+        # of host time per encoder and step - at 16 pairs per step the host, not the GPU, sets the pace); fresh tensor objects every time, so
+        # autograd's AccumulateGrad can keep them as .grad without copying
+        params = [mod._parameters[attr] for _, mod, attr in self._param_holders()]
+        views = torch._utils._unflatten_dense_tensors(gflat, params)
+        return [v if p.requires_grad else None for v, p in zip(views, params)]
 
     # ------------------------------------------------------------------ public API (reference call sites)
     def _features(self, x, caller):

@@ -71,8 +71,10 @@ def test_vits_drop_in_surface():
     a = vits.vit_small()
     b = vits.vit_small()
     assert [tuple(p.shape) for p in a.parameters()] == [tuple(p.shape) for p in b.parameters()]   # BLD:52,88 zip order
+    vb = vits.vit_base(num_classes=3, depth=1)                                            # MAIN_MOCO:50 `-a vit_base`: 768 wide, head_dim 64
+    assert vb.head.in_features == 768 and vb.blocks[0].attn.qkv.weight.shape == (2304, 768) and vb.blocks[0].mlp.fc1.weight.shape == (3072, 768)
     with pytest.raises(NotImplementedError):
-        vits.vit_base()
+        vits.vit_conv_small()
     # MoCo checkpoint prefix handling (MAIN_SS:327-337): strict=False load leaves exactly the head missing
     sd = {k: v for k, v in a.state_dict().items() if not k.startswith("head")}
     msg = vits.vit_small(num_classes=3).load_state_dict(sd, strict=False)
