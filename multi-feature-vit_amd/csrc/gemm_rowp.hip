@@ -30,6 +30,10 @@
 
 #include <type_traits>
 
+#ifndef MFVIT_ROWY_STORE
+#define MFVIT_ROWY_STORE 1
+#endif
+
 namespace mfvit {
 
 namespace {
@@ -442,7 +446,14 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
             const u32x4 v = *(const u32x4 __attribute__((may_alias))*)(ybuf + row * YP + 16 * ch);
             int r = 16 * i0 + row;
             r = r < rows ? r : rows - 1;
+            // a PLAIN store for the operand-type output (y of the forward, the residual gradient of the backward): the NEXT launches read it - as the A
+            // operand of a tile GEMM, once per 128-column tile - and find it in the L2 / Infinity Cache: tile class 90.4 -> 85.4 us per launch in the
+            // step, this kernel + 1 us (same-box A/B, round 5).  MFVIT_ROWY_STORE=0 (A/B builds): system-scope streaming stores (no write-allocate fetch).
+#if MFVIT_ROWY_STORE
+            *(u32x4*)((char*)out + (long)(m0 + r) * ldo * 2 + 16 * ch) = v;
+#else
             store16_stream((char*)out + (long)(m0 + r) * ldo * 2 + 16 * ch, v);
+#endif
         }
         __syncthreads();
     };
@@ -686,7 +697,11 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
                     acc[i][j][r] = dx;
                     cx[j][r] += ok ? dx : 0.f;
                 }
-                if (dxo) store16_stream(dxo + (unsigned)row_of(i) * (unsigned)p.ldo0 + ncol0 + 16 * j, __builtin_bit_cast(u32x4_st, acc[i][j]));
+                // (a PLAIN store: the f32 copy is only asked for by block 0 of the lean split path and by the plain 16-bit types.  As an asm streaming
+                // store - 64-bit address registers per statement - this line pushed the seven-fragment kernel into 148 bytes of scratch: 65 spill
+                // accesses in the epilogue, each reload a drain of the LDS-DMA queue, 89.8 -> 100.3 us per launch in the step (round 5, same-box A/B
+                // against the round-4 library; __graft_entry__.build() now checks the hot kernels for scratch))
+                if (dxo) *(f32x4v*)(dxo + (unsigned)row_of(i) * (unsigned)p.ldo0 + ncol0 + 16 * j) = acc[i][j];
             }
         }
         col_out(cx, 2, p.cs2);
