@@ -244,6 +244,10 @@ typedef unsigned int u32x4_st __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store16_stream(void* gp, u32x4_st v) {
 #ifdef MFVIT_PLAIN_OUTPUT_STORES        // A/B builds only (tools/build_variant_lib.sh): the round-4 behaviour
     __builtin_nontemporal_store(v, (u32x4_st*)gp);
+#elif defined(MFVIT_STREAM_POLICY) && MFVIT_STREAM_POLICY == 1      // A/B builds: system scope without the non-temporal hint
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(gp), "v"(v) : "memory");
+#elif defined(MFVIT_STREAM_POLICY) && MFVIT_STREAM_POLICY == 2      // A/B builds: sc1 only
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(gp), "v"(v) : "memory");
 #else
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" ::"v"(gp), "v"(v) : "memory");
 #endif

@@ -17,7 +17,7 @@
 
 #include <type_traits>
 
-// A/B builds only (tools/build_variant_lib.sh): 1 = plain (L2-resident) stores for EVERY output of the tile kernel (default: qkv only, see copy_tile)
+// A/B builds only (tools/build_variant_lib.sh): 1 = plain (L2-resident) stores for EVERY output of the tile kernel (default: qkv only, see copy_tile), 2 = for the fc2 data gradient, 3 = for gelu(h)
 #ifndef MFVIT_TILE_PLAIN_STORE
 #define MFVIT_TILE_PLAIN_STORE 0
 #endif
@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
                 // qkv (the attention core reads it NEXT, 116 MB): a PLAIN store - the lines stay in the L2 / Infinity Cache on their way out and the
                 // forward attention launch behind it runs 54.5 -> 50.5 us in the step (same-box A/B, round 5; an `nt` store does not: 54.4).  Every
                 // other output of this kernel leaves through system-scope streaming stores (no write-allocate fetch, common.cuh).
-                if constexpr (EPI == EPI_BIAS_X3F16 || EPI == EPI_BIAS || MFVIT_TILE_PLAIN_STORE) *gp = *lp;
+                if constexpr (EPI == EPI_BIAS_X3F16 || EPI == EPI_BIAS || MFVIT_TILE_PLAIN_STORE == 1 || (MFVIT_TILE_PLAIN_STORE == 2 && EPI == EPI_GELU_BWD) ||
+                              (MFVIT_TILE_PLAIN_STORE == 3 && EPI == EPI_BIAS_GELU && RB == ROWB && ROWB != AROWB)) *gp = *lp;
                 else
                 store16_stream(gp, *lp);                                         // system-scope streaming store: no write-allocate fetch (common.cuh)
             } else {
