@@ -165,6 +165,16 @@ int mfvit_linear_res_ln_fwd(int dtype, const void* a, int64_t lda, const void* w
 int mfvit_linear_dgrad_ln_bwd(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, const float* mean,
                               const float* rstd, const float* gamma, const float* dres, float* dx, void* dx_t, float* dgamma,
                               float* dbeta, float* dcol, int M, int K, mfvit_stream_t stream);
+/* The same two with caller-owned scratch (MFVIT_ROWP_SCRATCH_FLOATS floats, 16-byte aligned; NULL = the calls above): at small M the tall-tile row
+ * kernel then splits K over up to 4 workgroups per row tile - each streams its share of W[384][K] through its CU - and the workgroup that arrives last
+ * adds the partial tiles from the scratch and runs the epilogue (csrc/gemm_rowp.hip; what the encoder does with its own workspace).  Round 5, additive. */
+#define MFVIT_ROWP_SCRATCH_FLOATS (264 * 7 * 12 * 512)
+int mfvit_linear_res_ln_fwd_ws(int dtype, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res,
+                               int64_t ldres, float* x_out, void* y, int y_f32, const float* gamma, const float* beta, float eps,
+                               float* mean, float* rstd, int M, int K, float* scratch, mfvit_stream_t stream);
+int mfvit_linear_dgrad_ln_bwd_ws(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, const float* mean,
+                                 const float* rstd, const float* gamma, const float* dres, float* dx, void* dx_t, float* dgamma,
+                                 float* dbeta, float* dcol, int M, int K, float* scratch, mfvit_stream_t stream);
 /* softmax(q k^T / sqrt(d)) v per (image, head); qkv [B][T][3][H][d], out [B][T][H*d], lse [B][H][T] (module.py:52-64 is the same math for
  * the cross-attention; the self-attention of the timm block: SURVEY Appendix A).  dtype MFVIT_X3F16: qkv split fp16, out / dout / dqkv
  * MFVIT_BF16X3.  mfvit_attention_qkv_dtype: the tag the encoder uses for the qkv tensor of an activation dtype at (T, head_dim) -

@@ -217,7 +217,9 @@ struct GemmP {
     float* cpart;      // optional scratch for per-workgroup column-sum partials (then reduced by colpart_reduce): avoids
                        // hundreds of workgroups hammering the same few hundred addresses with float atomics (14x slower)
     int y_f32;
-    int splits;        // wgrad: number of m-splits (grid.y)
+    int splits;        // wgrad: number of m-splits (grid.y); gemm_rowp: number of K splits of a row tile (set by its launcher)
+    float* kpart;      // gemm_rowp with K splits: scratch for the partial accumulator tiles ([workgroup][MF * 12 * 512] floats), see gemm_rowp.hip
+    unsigned* kcnt;    // ... and one arrival counter per row tile (zero between launches: the last arrival resets it)
     int rows_per_wg;   // row kernels: token rows owned by one workgroup (<= its tile height; 0 = the tile height), see launch_row
     // two-level batch over blockIdx.z = zo * nbi + zi (element offsets; bias/out0 only)
     int nb, nbi;

@@ -28,6 +28,8 @@
 
 #include <stdlib.h>
 
+#include <mutex>
+
 #include <type_traits>
 
 #ifndef MFVIT_ROWX_STORE
@@ -116,7 +118,13 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rows = p.M - m0 < rpt ? p.M - m0 : rpt;                 // valid rows of this tile (1 .. RP_TH)
-    const int nk = p.K / KG;
+    // K splits (small M, round 5): S workgroups share a row tile, workgroup ks multiplies k groups [ks nk, (ks + 1) nk) of it, the partial accumulator
+    // tiles meet in scratch and the workgroup that arrives LAST adds them up and runs the epilogue (no workgroup ever waits for another one: nothing
+    // to deadlock beside a second kernel stream).  Why: a tile streams the whole W[384][K] through its CU's LDS whatever its height - at M = 3,152 that
+    // stream (2.4 MB at K = 1,536) is all a launch does (48 us for 13 - 25 rows per CU); with S = 4 a CU streams a quarter of W for four times the rows.
+    const int S = p.splits > 1 ? p.splits : 1;
+    const int ks = S > 1 ? (int)blockIdx.x % S : 0;
+    const int nk = p.K / KG / S;
     const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
 
     // ---- LDS-DMA: a row = 8 chunks of 16 B, positions XOR (R >> 1) & 7 (R = row inside its slot); a piece = 8 rows = one 1 KB instruction:
@@ -134,8 +142,9 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
         r = r < rows ? r : rows - 1;                                   // rows past the tile replicate its last valid row
         voffa[i] = (unsigned)(m0 + r) * (unsigned)(p.lda * 2) + coff_of(pc);
     }
-    const char* gA = rp_uniform_ptr(p.A);
-    const char* gW = rp_uniform_ptr(p.W);
+    const char* gW0 = rp_uniform_ptr(p.W);                             // (the L2 warm-up touches walk the WHOLE matrix)
+    const char* gA = rp_uniform_ptr((const char*)p.A + (long)ks * nk * 128);
+    const char* gW = rp_uniform_ptr((const char*)p.W + (long)ks * nk * 128);
     const long wpass = (long)RP_N * p.ldw * 2;                         // bytes between the W rows of two passes
     auto issue_w = [&](int pass, int stage, int slot, int i) __attribute__((always_inline)) {   // W rows of `pass`, k group `stage` -> W slot
         rp_dma16(voffw[i], rp_uniform_ptr(gW + pass * wpass + (long)stage * 128),
@@ -172,7 +181,7 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
         for (int k = 0; k < RP_TOUCH; ++k) {
             unsigned ln = t0 + (unsigned)k * nthr;
             ln = ln < lines ? ln : lines - 1;
-            rp_dma4((ln / lpr) * (unsigned)(p.ldw * 2) + (ln % lpr) * 128u, gW, __builtin_amdgcn_readfirstlane(lbase + RP_RING + RP_SCR - 256));
+            rp_dma4((ln / lpr) * (unsigned)(p.ldw * 2) + (ln % lpr) * 128u, gW0, __builtin_amdgcn_readfirstlane(lbase + RP_RING + RP_SCR - 256));
         }
     }
     // W stages 0, 1 and A stages 0 .. 3 in flight (clamped to the last stage for very short K), stage 0 landed
@@ -202,7 +211,7 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
                 // the epilogue)
                 const int n = 48 * wave + 4 * fq + 16 * j;
                 f32x4v rv = {0.f, 0.f, 0.f, 0.f};
-                if (p.res) rv = *(const f32x4v*)(p.res + (unsigned)(m0 + r0) * (unsigned)p.ldres + n);
+                if (p.res && ks == 0) rv = *(const f32x4v*)(p.res + (unsigned)(m0 + r0) * (unsigned)p.ldres + n);     // (one split carries the residual)
                 acc[i][j] = rv;
             } else {
 #pragma unroll
@@ -360,6 +369,55 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                                   // the ring is free: epilogue scratch
+    if (S > 1) {
+        // Hand-off of the partial tiles (MI355X_MICROARCH.md, cross-CU visibility, the "last arrival" row of its table): every byte is stored and loaded
+        // by relaxed agent-scope 8-byte atomics (global_store / global_load ... sc1: through the XCD's L2 to memory), every storing wave waits for its
+        // stores, a workgroup barrier, then ONE lane adds to the tile's counter; the workgroup whose add returns S - 1 is the last one - its other waves
+        // learn that behind a second barrier - and only it reads.  The counter goes back to zero for the next launch on this stream.
+        typedef unsigned long long u64;
+        u64* const mine = (u64*)p.kpart + ((long)blockIdx.x * (RP_MF * 6) * 512 + tid);      // (one fixed-size slot per workgroup)
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const u64 lo = ((u64)__float_as_uint(acc[i][j][1]) << 32) | __float_as_uint(acc[i][j][0]);
+                const u64 hi = ((u64)__float_as_uint(acc[i][j][3]) << 32) | __float_as_uint(acc[i][j][2]);
+                __hip_atomic_store(mine + (long)((i * 3 + j) * 2) * 512, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + (long)((i * 3 + j) * 2 + 1) * 512, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* const lastf = (int*)(lds + RP_RING + RP_SCR - 16);
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.kcnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == (unsigned)(S - 1);
+            if (last) __hip_atomic_store(p.kcnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *lastf = last;
+        }
+        __syncthreads();
+        if (!*lastf) return;
+        // the sum in a FIXED order, ((p0 + p1) + p2) + p3, whoever arrived last - its own partial comes back from the scratch like the others - so that
+        // the result is the same bits on every run (tests/test_encoder_gpu.py::test_weight_gradients_are_bit_identical_from_run_to_run)
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < S; ++o) {
+            const u64* const theirs = (const u64*)p.kpart + ((long)(tile * S + o) * (RP_MF * 6) * 512 + tid);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const u64 lo = __hip_atomic_load(theirs + (long)((i * 3 + j) * 2) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u64 hi = __hip_atomic_load(theirs + (long)((i * 3 + j) * 2 + 1) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const f32x4v v = {__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
+                                      __uint_as_float((unsigned)(hi >> 32))};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += v[r];
+                }
+        }
+        __syncthreads();                                               // (lastf sits in the scratch area the epilogue reuses)
+    }
 
     // ------------------------------------------------------------------------------------------------ epilogues
     // acc[i][j][r] = out[m0 + 16 i + fr][48 wave + 16 j + 4 fq + r]; rows past `rows` replicate the tile's last valid row exactly (clamped
@@ -724,7 +782,8 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
 
 template <int MODE, int MF, typename T>
 __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int npass) {
-    rowp_body<MODE, MF, T>(p, (int)blockIdx.x, (int)blockIdx.x * rpt, rpt, npass);
+    const int tile = (int)blockIdx.x / (p.splits > 1 ? p.splits : 1);
+    rowp_body<MODE, MF, T>(p, tile, tile * rpt, rpt, npass);
 }
 // MIXED tile heights (round 4): the first n_lo tiles carry 16 (MF - 1) rows and run the (MF - 1)-fragment body, the others rpt_hi <= 16 MF rows.  With one
 // tile per CU, 25,216 rows are 98.5 per tile: 99 rows in 7 fragments of 16 multiply 13 padding rows in EVERY tile (12 % of the MFMAs); 216 tiles of 96 rows
@@ -732,7 +791,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowp_kernel(GemmP p, int rpt, int
 // the work the other tiles no longer do is clock for those.
 template <int MODE, int MF, typename T>
 __global__ __launch_bounds__(512, 1) void gemm_rowp_mixed_kernel(GemmP p, int n_lo, int rpt_hi, int npass) {
-    const int tile = (int)blockIdx.x;
+    const int tile = (int)blockIdx.x / (p.splits > 1 ? p.splits : 1);
     if (tile < n_lo) rowp_body<MODE, MF - 1, T>(p, tile, tile * 16 * (MF - 1), 16 * (MF - 1), npass);
     else rowp_body<MODE, MF, T>(p, tile, n_lo * 16 * (MF - 1) + (tile - n_lo) * rpt_hi, rpt_hi, npass);
 }
@@ -753,6 +812,53 @@ int rp_rows_per_tile(int M, int cap = RP_TH) {
     if (minr > 0 && rpt < minr) rpt = minr < cap ? minr : cap;
     return rpt;
 }
+
+// launch geometry: rows per tile, row tiles, K splits per tile (1: none).  K splits (see rowp_body) when the caller handed scratch in, K >= 1,024 and the
+// rows are too few to give every workgroup of the stream's share of the chip (all CUs, or half of them beside a second kernel stream) a tall tile:
+// S = that many workgroups per tile of ~ 56 rows, at most 4, each split an even number >= 4 of k groups.  MFVIT_ROWP_KSPLIT=0 switches them off, N forces N.
+struct RpGeo { int rpt, tiles, S; };
+RpGeo rp_geometry(const GemmP& p, int cap, int kg, bool bwd) {
+    RpGeo g;
+    g.S = 1;
+    static int sw_ks = INT_MIN, sw_ksb = INT_MIN;
+    const int ks_env = env_switch("MFVIT_ROWP_KSPLIT", -1, sw_ks);
+    const int nk = p.K / kg;
+    if (p.kpart && p.kcnt && ks_env != 0 && p.K >= 1024 && (!bwd || ks_env > 0 || env_switch("MFVIT_ROWP_KSPLIT_BWD", 1, sw_ksb) != 0)) {
+        const int wgs = rp_cus() / (stream_share() >= 2 ? 2 : 1);      // workgroups this launch should put on the chip
+        // as many splits as leave a tile ~ 56 rows (3 - 4 row fragments): measured at 16 pairs per step beside a second stream (M = 3,152, 128 workgroups):
+        // S = 2 (64 tiles of 49 rows) 6.16 ms per step, 3 (43 x 74) 6.22, 4 (32 x 99) 6.42, none 6.5; at 32 pairs two splits of 99-row tiles lose (9.02 -> 9.17)
+        int S = ks_env > 0 ? ks_env : (int)((long)wgs * 56 / p.M);
+        S = S > 4 ? 4 : S;
+        for (; S >= 2; --S) {
+            if (nk % (2 * S) || nk / S < 4) continue;
+            const int tiles = (wgs + S - 1) / S;
+            const int rpt = (p.M + tiles - 1) / tiles;
+            if (rpt > cap || rpt < 16) continue;
+            g.S = S;
+            g.rpt = rpt;
+            g.tiles = (p.M + rpt - 1) / rpt;
+            return g;
+        }
+    }
+    g.rpt = rp_rows_per_tile(p.M, cap);
+    g.tiles = (p.M + g.rpt - 1) / g.rpt;
+    return g;
+}
+// arrival counters of the K-split launches: one zeroed set of 512 per stream (launches of one stream never overlap; every launch leaves its counters zero)
+__device__ unsigned g_rowp_kcnt[16][512];
+unsigned* rowp_counters(hipStream_t st) {
+    static std::mutex mu;
+    static hipStream_t owner[16];
+    static int used = 0;
+    static unsigned* base = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_rowp_kcnt)) != hipSuccess) return nullptr;
+    for (int i = 0; i < used; ++i)
+        if (owner[i] == st) return base + i * 512;
+    if (used == 16) return nullptr;                                    // more streams than sets: no K splits for the newcomers
+    owner[used] = st;
+    return base + (used++) * 512;
+}
 template <int MODE> constexpr int rp_cap() { return MODE == REPI_LNBWD_RES ? RP_XROWS : RP_TH; }
 
 template <int MODE, int MF, typename T> int launch_rowp_mf(const GemmP& q, int grid, int rpt, hipStream_t st) {
@@ -766,13 +872,17 @@ template <int MODE, int MF, typename T> int launch_rowp_mf(const GemmP& q, int g
 }
 
 template <int MODE, typename T> int launch_rowp(const GemmP& p, hipStream_t st) {
-    const int rpt = rp_rows_per_tile(p.M, rp_cap<MODE>());
-    const int grid = (p.M + rpt - 1) / rpt;
-    ProfScope ps(MODE == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
     GemmP q = p;
     q.rows_per_wg = 0;
+    q.kcnt = q.kpart ? rowp_counters(st) : nullptr;
+    const RpGeo geo = rp_geometry(q, rp_cap<MODE>(), is_split<T>::value ? 32 : 64, MODE == REPI_LNBWD_RES);
+    const int rpt = geo.rpt, tiles = geo.tiles;
+    if (geo.S > 1 && tiles > 512) return MFVIT_EINVAL;                  // (cannot happen: tiles <= #CUs)
+    q.splits = geo.S;
+    const int grid = tiles * geo.S;                                      // workgroups: tile * S + k split
+    ProfScope ps(MODE == REPI_RES_LN ? PROF_GEMM_ROW_FWD : PROF_GEMM_ROW_BWD, 2.0 * p.M * p.N * p.K, 0, st);
     const int mf = (rpt + 15) / 16;
-    if (mf >= 2 && grid > 1 && rpt % 16) {
+    if (mf >= 2 && tiles > 1 && rpt % 16) {
         // mixed heights: n_lo tiles of 16 (mf - 1) rows, the rest as many rows as it takes, at most 16 mf and the mode's cap
         // rows of the tall tiles at most.  Their epilogue is the launch's critical path, so in the SERIALIZED pass the forward launch is shortest with
         // short tall tiles (74.9 us at 100 rows, 77.2 at 112) - but the timed step, at the power cap, follows the MFMA count: 26.85 ms uniform,
@@ -781,9 +891,9 @@ template <int MODE, typename T> int launch_rowp(const GemmP& p, hipStream_t st) 
         int cap = RP_TH;
         cap = cap > rp_cap<MODE>() ? rp_cap<MODE>() : cap;
         cap = cap > 16 * mf ? 16 * mf : (cap < lo + 1 ? lo + 1 : cap);
-        int n_lo = (cap * grid - p.M) / (cap - lo);                      // the most short tiles that leave <= cap rows for each of the others
-        n_lo = n_lo < 0 ? 0 : (n_lo > grid - 1 ? grid - 1 : n_lo);
-        const int rpt_hi = (p.M - lo * n_lo + (grid - n_lo) - 1) / (grid - n_lo);
+        int n_lo = (cap * tiles - p.M) / (cap - lo);                     // the most short tiles that leave <= cap rows for each of the others
+        n_lo = n_lo < 0 ? 0 : (n_lo > tiles - 1 ? tiles - 1 : n_lo);
+        const int rpt_hi = (p.M - lo * n_lo + (tiles - n_lo) - 1) / (tiles - n_lo);
         if (n_lo > 0 && rpt_hi > lo && rpt_hi <= cap) {
             auto go = [&](auto mtag) {
                 constexpr int MFH = decltype(mtag)::value;
@@ -859,8 +969,10 @@ int gemm_nt_rowp(int dtype, int repi, const GemmP& p, hipStream_t st) {
     if (repi == REPI_LNBWD_RES) {
         const int rc = launch_rowp_t<REPI_LNBWD_RES>(dtype, p, st);
         if (rc != MFVIT_OK || !p.cpart) return rc;
-        const int rpt = rp_rows_per_tile(p.M, RP_XROWS);
-        return colpart_reduce(p.cpart, (p.M + rpt - 1) / rpt, RP_N, 3, p.cs0, p.cs1, p.cs2, st);   // [tile][3][384] partials -> dgamma, dbeta, dcol
+        GemmP q = p;
+        q.kcnt = q.kpart ? rowp_counters(st) : nullptr;               // (the same geometry the launch used)
+        const RpGeo geo = rp_geometry(q, RP_XROWS, dtype == MFVIT_BF16X3 ? 32 : 64, true);
+        return colpart_reduce(p.cpart, geo.tiles, RP_N, 3, p.cs0, p.cs1, p.cs2, st);   // [tile][3][384] partials -> dgamma, dbeta, dcol
     }
     return MFVIT_EINVAL;
 }

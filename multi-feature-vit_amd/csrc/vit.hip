@@ -155,6 +155,7 @@ struct WsLayout {
     // backward scratch
     size_t gx, gmid, gxT, gmidT, dhpre, dattn, dqkv, colscratch, colpart, colpart_stride = 0, tnpart, tnpart_stride = 0;
     size_t dtmp;                // token-input mode with residual dropout: [M][D] of the operand type (branch output before the dropout; masked dY)
+    size_t kpart;               // gemm_rowp with K splits (small M): partial accumulator tiles, 264 workgroups x 7 x 12 x 512 floats (gemm_rowp.hip)
     size_t utmp;                // unfused path: [M][D] of the operand type (output of the plain tile GEMM in front of a LayerNorm / LayerNorm-backward row pass)
     size_t pp_stride;           // distance between the two ping-pong copies of gxT / gmidT / dhpre / dqkv (0 = none)
     size_t total;
@@ -211,6 +212,7 @@ WsLayout ws_layout(const Dims& d) {
         W.pp_stride = 0;
     }
     W.dtmp = o; o += (d.tok && d.p_resid > 0.f) ? align256(M * D * es) : 0;
+    W.kpart = o; o += d.D == 384 ? align256((size_t)264 * 7 * 12 * 512 * 4) : 0;
     W.utmp = o; o += align256(M * D * es);     // always there (1 / 200 of the workspace): the layout does not depend on which path a call takes
     W.total = o;
     return W;
@@ -446,6 +448,7 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
                 MFVIT_TRY(add_ln_rows(d.dtype, d.D, ws + W.utmp, D * e, nullptr, 0, 0, xbuf(l), D, 0, 0, 0, (float*)(b + W.xmid), D, b + W.y2, D * e, 0,
                                       p.gamma, p.beta, eps, p.mean, p.rstd, d.M, st));
             } else {
+                p.kpart = (float*)(ws + W.kpart);
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
             }
         }
@@ -494,6 +497,7 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
                 MFVIT_TRY(add_ln_rows(d.dtype, d.D, ws + W.utmp, D * e, nullptr, 0, 0, (const float*)(b + W.xmid), D, 0, 0, 0, xbuf(l + 1), D, p.out1,
                                       p.ldo1, p.y_f32, p.gamma, p.beta, eps, p.mean, p.rstd, d.M, st));
             } else {
+                p.kpart = (float*)(ws + W.kpart);
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
             }
         }
@@ -649,8 +653,10 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                     MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, q, st));
                     MFVIT_TRY(ln_bwd_rows(d.dtype, d.D, nullptr, 0, (const float*)(b + W.xmid), D, p.mean, p.rstd, p.gamma, gx, D, gmid, D, gmidT, D * e,
                                           p.cs0, p.cs1, p.cs2, p.cpart, d.M, 1, 0, st, ws + W.utmp, D * e));
-                } else
-                MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
+                } else {
+                    p.kpart = (float*)(ws + W.kpart);
+                    MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
+                }
             }
             const void* gyp = gmidT;                              // dY of proj
             if (rdrop) {
@@ -733,8 +739,10 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                     MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, q, st));
                     MFVIT_TRY(ln_bwd_rows(d.dtype, d.D, nullptr, 0, xbuf(l), D, p.mean, p.rstd, p.gamma, gmid, D, gx, D, pp(W.gxT, l - 1), D * e,
                                           p.cs0, p.cs1, p.cs2, p.cpart, d.M, 1, 0, st, ws + W.utmp, D * e));
-                } else
-                MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
+                } else {
+                    p.kpart = (float*)(ws + W.kpart);
+                    MFVIT_TRY(gemm_nt_row(d.dtype, REPI_LNBWD_RES, p, st));
+                }
             }
         } else if (d.tok) {
             MFVIT_TRY(colpart_batch_flush(st));
@@ -852,8 +860,14 @@ int mfvit_linear_wgrad_pair(int dtype, const void* dy_a, int64_t lddy_a, const v
 int mfvit_linear_res_ln_fwd(int dtype, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res,
                             int64_t ldres, float* x_out, void* y, int y_f32, const float* gamma, const float* beta, float eps,
                             float* mean, float* rstd, int M, int K, mfvit_stream_t stream) {
-    if (!a || !w || !y || !gamma || !beta) return MFVIT_EINVAL;
+    return mfvit_linear_res_ln_fwd_ws(dtype, a, lda, w, ldw, bias, res, ldres, x_out, y, y_f32, gamma, beta, eps, mean, rstd, M, K, nullptr, stream);
+}
+int mfvit_linear_res_ln_fwd_ws(int dtype, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res,
+                               int64_t ldres, float* x_out, void* y, int y_f32, const float* gamma, const float* beta, float eps,
+                               float* mean, float* rstd, int M, int K, float* scratch, mfvit_stream_t stream) {
+    if (!a || !w || !y || !gamma || !beta || ((size_t)scratch & 15)) return MFVIT_EINVAL;
     GemmP p = zero_gemm();
+    p.kpart = scratch;
     p.A = a; p.lda = lda; p.W = w; p.ldw = ldw; p.M = M; p.N = 384; p.K = K;
     p.bias = bias; p.res = res; p.ldres = ldres;
     p.out0 = x_out; p.ldo0 = 384; p.out1 = y; p.ldo1 = (dtype == MFVIT_BF16X3 && !y_f32) ? 768 : 384; p.y_f32 = y_f32;
@@ -863,8 +877,14 @@ int mfvit_linear_res_ln_fwd(int dtype, const void* a, int64_t lda, const void* w
 int mfvit_linear_dgrad_ln_bwd(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, const float* mean,
                               const float* rstd, const float* gamma, const float* dres, float* dx, void* dx_t, float* dgamma,
                               float* dbeta, float* dcol, int M, int K, mfvit_stream_t stream) {
-    if (!dy || !wt || !x || !mean || !rstd || !gamma || !dx) return MFVIT_EINVAL;
+    return mfvit_linear_dgrad_ln_bwd_ws(dtype, dy, lddy, wt, ldwt, x, mean, rstd, gamma, dres, dx, dx_t, dgamma, dbeta, dcol, M, K, nullptr, stream);
+}
+int mfvit_linear_dgrad_ln_bwd_ws(int dtype, const void* dy, int64_t lddy, const void* wt, int64_t ldwt, const float* x, const float* mean,
+                                 const float* rstd, const float* gamma, const float* dres, float* dx, void* dx_t, float* dgamma,
+                                 float* dbeta, float* dcol, int M, int K, float* scratch, mfvit_stream_t stream) {
+    if (!dy || !wt || !x || !mean || !rstd || !gamma || !dx || ((size_t)scratch & 15)) return MFVIT_EINVAL;
     GemmP p = zero_gemm();
+    p.kpart = scratch;
     p.A = dy; p.lda = lddy; p.W = wt; p.ldw = ldwt; p.M = M; p.N = 384; p.K = K;
     p.aux = x; p.ldaux = 384; p.mean = (float*)mean; p.rstd = (float*)rstd; p.gamma = gamma;
     p.res = dres; p.ldres = 384;

@@ -55,6 +55,8 @@ SIGNATURES = {
     "mfvit_linear_wgrad_pair": (I, [I, P, L, P, L, P, L, P, I, P, L, P, L, P, L, I, I, I, P]),
     "mfvit_linear_res_ln_fwd": (I, [I, P, L, P, L, P, P, L, P, P, I, P, P, F, P, P, I, I, P]),
     "mfvit_linear_dgrad_ln_bwd": (I, [I, P, L, P, L, P, P, P, P, P, P, P, P, P, P, I, I, P]),
+    "mfvit_linear_res_ln_fwd_ws": (I, [I, P, L, P, L, P, P, L, P, P, I, P, P, F, P, P, I, I, P, P]),
+    "mfvit_linear_dgrad_ln_bwd_ws": (I, [I, P, L, P, L, P, P, P, P, P, P, P, P, P, P, I, I, P, P]),
     "mfvit_attention_fwd": (I, [I, P, P, P, I, I, I, I, P]),
     "mfvit_attention_bwd": (I, [I, P, P, P, P, P, P, I, I, I, I, P]),
     "mfvit_attention_qkv_dtype": (I, [I, I, I]),

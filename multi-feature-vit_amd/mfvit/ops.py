@@ -144,8 +144,12 @@ def linear_wgrad_pair(dy_a, x_a, dy_b, x_b, want_dbias=True, split=False):
     return dw_a, db_a, dw_b
 
 
-def linear_res_ln_fwd(a, w, bias, res, gamma, beta, eps, y_f32=False, split=False):
-    """x_out = a @ w.T + bias + res ; y = LayerNorm(x_out).  Returns (x_out f32, y, mean, rstd)."""
+ROWP_SCRATCH_FLOATS = 264 * 7 * 12 * 512      # include/mfvit.h: MFVIT_ROWP_SCRATCH_FLOATS
+
+
+def linear_res_ln_fwd(a, w, bias, res, gamma, beta, eps, y_f32=False, split=False, scratch=None):
+    """x_out = a @ w.T + bias + res ; y = LayerNorm(x_out).  Returns (x_out f32, y, mean, rstd).  scratch (f32[ROWP_SCRATCH_FLOATS]): lets the
+    row kernel split K over several workgroups per row tile at small M (mfvit_linear_res_ln_fwd_ws)."""
     require_cuda(a, w, res)
     code = _code_of(a, split)
     e = 2 if split else 1
@@ -154,13 +158,13 @@ def linear_res_ln_fwd(a, w, bias, res, gamma, beta, eps, y_f32=False, split=Fals
     y = torch.empty(M, 384 if y_f32 else 384 * e, device=a.device, dtype=torch.float32 if y_f32 else a.dtype)
     mean = torch.empty(M, device=a.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
-    check(lib().mfvit_linear_res_ln_fwd(code, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(res),
-                                        res.stride(0) if res is not None else 0, ptr(x_out), ptr(y), int(y_f32), ptr(gamma),
-                                        ptr(beta), eps, ptr(mean), ptr(rstd), M, K, stream()), "mfvit_linear_res_ln_fwd")
+    check(lib().mfvit_linear_res_ln_fwd_ws(code, ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(res),
+                                           res.stride(0) if res is not None else 0, ptr(x_out), ptr(y), int(y_f32), ptr(gamma),
+                                           ptr(beta), eps, ptr(mean), ptr(rstd), M, K, ptr(scratch), stream()), "mfvit_linear_res_ln_fwd_ws")
     return x_out, y, mean, rstd
 
 
-def linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, gamma, dres, want_copy=True, split=False):
+def linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, gamma, dres, want_copy=True, split=False, scratch=None):
     """dx = LNbwd(dy @ wt.T ; x, mean, rstd, gamma) + dres.  wt is the TRANSPOSED weight [384, K].
     Returns (dx f32, dx copy in dy.dtype, dgamma, dbeta, dcol)."""
     require_cuda(dy, wt, x)
@@ -172,9 +176,9 @@ def linear_dgrad_ln_bwd(dy, wt, x, mean, rstd, gamma, dres, want_copy=True, spli
     dgamma = torch.zeros(384, device=dy.device, dtype=torch.float32)
     dbeta = torch.zeros_like(dgamma)
     dcol = torch.zeros_like(dgamma)
-    check(lib().mfvit_linear_dgrad_ln_bwd(code, ptr(dy), dy.stride(0), ptr(wt), wt.stride(0), ptr(x), ptr(mean), ptr(rstd),
-                                          ptr(gamma), ptr(dres), ptr(dx), ptr(dx_t), ptr(dgamma), ptr(dbeta), ptr(dcol), M, K,
-                                          stream()), "mfvit_linear_dgrad_ln_bwd")
+    check(lib().mfvit_linear_dgrad_ln_bwd_ws(code, ptr(dy), dy.stride(0), ptr(wt), wt.stride(0), ptr(x), ptr(mean), ptr(rstd),
+                                             ptr(gamma), ptr(dres), ptr(dx), ptr(dx_t), ptr(dgamma), ptr(dbeta), ptr(dcol), M, K,
+                                             ptr(scratch), stream()), "mfvit_linear_dgrad_ln_bwd_ws")
     return dx, dx_t, dgamma, dbeta, dcol
 
 

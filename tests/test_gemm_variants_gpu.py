@@ -83,6 +83,51 @@ def test_row_kernel_dgrad_layernorm_backward(monkeypatch, M, tag, K, mode):
     assert max(errs["dx"], errs["dx_split"]) < 3e-5 and max(errs["dgamma"], errs["dbeta"], errs["dcol"]) < 2e-4, (tag, K, mode, errs)
 
 
+@pytest.mark.parametrize("M", [1024, 3152, 3349, 6304])
+@pytest.mark.parametrize("ksplit", ["2", "3", "4", "-1"])
+@pytest.mark.parametrize("share", [1, 2])
+def test_row_kernels_with_k_splits(monkeypatch, M, ksplit, share):
+    """The tall-tile row kernels with K split over 2 - 4 workgroups per row tile (small M, round 5: partial accumulator tiles through scratch, the workgroup
+    that arrives last adds them and runs the epilogue): forward (+ residual + LayerNorm) at K = 1536, LayerNorm backward at K = 1152 and 1536, forced split
+    counts and the launcher's own choice (-1), alone on the chip and with the half-chip hint of the two-stream model; against float64, and REPEATED on the
+    same scratch (the arrival counters must be back at zero after every launch)."""
+    from mfvit._lib import lib
+    monkeypatch.setenv("MFVIT_ROWP_KSPLIT", ksplit)
+    lib().mfvit_set_stream_share(share)
+    try:
+        scratch = torch.empty(ops.ROWP_SCRATCH_FLOATS, device=DEV, dtype=torch.float32)
+        g = _gen(51 + M)
+        K = F
+        a, w = sp(rn(g, M, K)), sp(rn(g, D, K, sc=.05))
+        b, res = rn(g, D), rn(g, M, D)
+        gam, bet = torch.rand(D, device=DEV, generator=g) + .5, rn(g, D)
+        x64 = ops.split_unpack(a).double() @ ops.split_unpack(w).double().T + b.double() + res.double()
+        mu = x64.mean(1, keepdim=True)
+        var = ((x64 - mu) ** 2).mean(1, keepdim=True)
+        y64 = (x64 - mu) / torch.sqrt(var + 1e-6) * gam.double() + bet.double()
+        for rep in range(3):
+            x, y, mean, rstd = ops.linear_res_ln_fwd(a, w, b, res, gam, bet, 1e-6, split=True, scratch=scratch)
+            errs = dict(x=rel(x, x64), y=rel(ops.split_unpack(y), y64), mean=rel(mean, mu.squeeze(1)), rstd=rel(rstd, 1 / torch.sqrt(var + 1e-6).squeeze(1)))
+            assert max(errs.values()) < 3e-5, (M, ksplit, share, rep, errs)
+        for K in (3 * D, F):
+            dy, wt = sp(rn(g, M, K, sc=.1)), sp(rn(g, D, K, sc=.05))
+            xx = rn(g, M, D, sc=1.5) + .3
+            mean = xx.mean(1)
+            rstd = 1 / torch.sqrt(xx.var(1, unbiased=False) + 1e-6)
+            dres = rn(g, M, D, sc=.1)
+            d64 = ops.split_unpack(dy).double() @ ops.split_unpack(wt).double().T
+            h = (xx.double() - mean.double()[:, None]) * rstd.double()[:, None]
+            gg = d64 * gam.double()
+            dx64 = rstd.double()[:, None] * (gg - gg.mean(1, keepdim=True) - h * (gg * h).mean(1, keepdim=True)) + dres.double()
+            for rep in range(2):
+                dx, dxt, dgm, dbt, dcl = ops.linear_dgrad_ln_bwd(dy, wt, xx, mean, rstd, gam, dres, split=True, scratch=scratch)
+                errs = dict(dx=rel(dx, dx64), dx_split=rel(ops.split_unpack(dxt), dx64), dgamma=rel(dgm, (d64 * h).sum(0)), dbeta=rel(dbt, d64.sum(0)),
+                            dcol=rel(dcl, dx64.sum(0)))
+                assert max(errs["dx"], errs["dx_split"]) < 3e-5 and max(errs["dgamma"], errs["dbeta"], errs["dcol"]) < 2e-4, (M, K, ksplit, share, rep, errs)
+    finally:
+        lib().mfvit_set_stream_share(1)
+
+
 @pytest.mark.parametrize("M,tag", SHAPES)
 @pytest.mark.parametrize("glds", ["1", "0"])
 def test_weight_gradient_variants(monkeypatch, M, tag, glds):
