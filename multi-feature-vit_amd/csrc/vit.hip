@@ -251,7 +251,7 @@ SideStream& side_stream(hipStream_t caller) {
     }
     SideStream& x = *px;
     if (!x.s) {
-        static const bool enabled = [] { const char* e = getenv("MFVIT_WGRAD_STREAM"); return e && e[0] == '1'; }();
+        static const bool enabled = [] { const char* e = getenv("MFVIT_WGRAD_STREAM"); return !(e && e[0] == '0'); }();   // (0: never; created on first use)
         if (enabled && hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&x.in, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&x.end, hipEventDisableTiming) == hipSuccess) {
@@ -559,11 +559,24 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     } tn_scope(&tbatch, tn_part_env);
     // dY buffers by layer parity (the embed stage counts as layer -1 -> parity 1)
     auto pp = [&](size_t off, int l) { return (void*)(ws + off + (size_t)(l & 1) * W.pp_stride); };
-    SideStream& ss = side_stream(st);
+    // (side_wanted, below, decides whether the side stream of this caller stream is looked up - and created - at all)
+    static const int side_env = [] { const char* e = getenv("MFVIT_WGRAD_STREAM"); return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1; }();
+    // (never inside a stream capture: forking the library's side stream into a hipGraph capture crashed capture_end on ROCm 7.2 - tests/test_graph_gpu.py)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    const bool side_wanted = (side_env == 1 || (side_env < 0 && d.M <= 4096)) && g_wgrad_stream.load(std::memory_order_relaxed) != 0 && !(d.p_resid > 0.f) &&
+                             !capturing;
+    static SideStream no_side;
+    SideStream& ss = side_wanted ? side_stream(st) : no_side;
     // (residual dropout: the masked dY copies live in ONE scratch buffer - everything stays on the caller's stream)
-    const bool use_side = ss.ok && W.pp_stride != 0 && g_wgrad_stream.load(std::memory_order_relaxed) != 0 && !(d.p_resid > 0.f);
+    // Default since round 5: the side stream at SMALL M only (<= 4,096 token rows: 20 images) - there no kernel fills the chip, the launches of a block are
+    // a dependent chain of ~10 us kernels with ~5 us of dispatch gap each, and the weight gradients (leaves) beside the data-gradient chain shorten it:
+    // 16 pairs per step 6.29 -> 5.92 ms, 32 pairs 8.79 -> 8.70 (profiles/r05_small_batch.txt).  MFVIT_WGRAD_STREAM=1: at every M (round 2 behaviour), 0: never.
+    const bool use_side = side_wanted && ss.ok && W.pp_stride != 0;
     hipStream_t wst = use_side ? ss.s : st;                       // stream of the weight-gradient GEMMs
-    tn_part = tn_part_env && !use_side;
+    // (with the side stream every weight gradient AND every reduce of their partials runs on it - the patch embedding's too, below - so the scratch slots
+    // are still written and read in one stream's order)
+    tn_part = tn_part_env;
     // the side stream may only start after everything already queued on the caller's stream (activations, zeroed gradients)
     auto fork = [&]() -> int {                                    // main -> side dependency at this point of the main stream
         if (!use_side) return MFVIT_OK;
@@ -768,15 +781,16 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.orow_in = d.np; p.orow_out = d.T; p.orow_off = 1;
                 p.out0 = dparams + L.pe_w; p.ldo0 = 768;
                 p.cpart = next_tnpart();
-                MFVIT_TRY(gemm_tn(d.dtype, p, st));
+                MFVIT_TRY(fork());                                // (the residual gradient of block 0 is ready on the main stream)
+                MFVIT_TRY(gemm_tn(d.dtype, p, wst));
             }
         }
     }
     MFVIT_TRY(colpart_batch_flush(st));
+    MFVIT_TRY(tnpart_batch_flush(wst));     // dW += the split partials still pending (the patch embedding's), splits in a fixed order
     if (use_side) {   // join: everything the side stream did is ordered before whatever the caller queues next
         if (hipEventRecord(ss.end, ss.s) != hipSuccess || hipStreamWaitEvent(st, ss.end, 0) != hipSuccess) return MFVIT_ELAUNCH;
     }
-    MFVIT_TRY(tnpart_batch_flush(st));      // dW += the split partials of every weight gradient of this call, splits in a fixed order
     return MFVIT_OK;
 }
 
