@@ -564,14 +564,15 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     // (never inside a stream capture: forking the library's side stream into a hipGraph capture crashed capture_end on ROCm 7.2 - tests/test_graph_gpu.py)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    const bool side_wanted = (side_env == 1 || (side_env < 0 && d.M <= 4096)) && g_wgrad_stream.load(std::memory_order_relaxed) != 0 && !(d.p_resid > 0.f) &&
+    const bool side_wanted = (side_env == 1 || (side_env < 0 && d.M >= 1024 && d.M <= 4096)) && g_wgrad_stream.load(std::memory_order_relaxed) != 0 && !(d.p_resid > 0.f) &&
                              !capturing;
     static SideStream no_side;
     SideStream& ss = side_wanted ? side_stream(st) : no_side;
     // (residual dropout: the masked dY copies live in ONE scratch buffer - everything stays on the caller's stream)
-    // Default since round 5: the side stream at SMALL M only (<= 4,096 token rows: 20 images) - there no kernel fills the chip, the launches of a block are
-    // a dependent chain of ~10 us kernels with ~5 us of dispatch gap each, and the weight gradients (leaves) beside the data-gradient chain shorten it:
-    // 16 pairs per step 6.29 -> 5.92 ms, 32 pairs 8.79 -> 8.70 (profiles/r05_small_batch.txt).  MFVIT_WGRAD_STREAM=1: at every M (round 2 behaviour), 0: never.
+    // Default since round 5: the side stream at SMALL M only (1,024 ... 4,096 token rows: 6 - 20 images) - there no kernel fills the chip, the launches of a
+    // block are a dependent chain of ~10 us kernels with ~5 us of dispatch gap each, and the weight gradients (leaves) beside the data-gradient chain
+    // shorten it: 20 pairs per step 7.31 -> 6.66 ms, 16 pairs 6.31 -> 6.10 (then host-bound), 8 pairs 5.18 -> 4.96; 4 pairs LOSE (host-bound either way, 5.1 ->
+    // 6.9 ms) and 32 pairs gain 1 % (profiles/r05_small_batch.txt).  MFVIT_WGRAD_STREAM=1: at every M (round 2 behaviour), 0: never.
     const bool use_side = side_wanted && ss.ok && W.pp_stride != 0;
     hipStream_t wst = use_side ? ss.s : st;                       // stream of the weight-gradient GEMMs
     // (with the side stream every weight gradient AND every reduce of their partials runs on it - the patch embedding's too, below - so the scratch slots
@@ -611,7 +612,15 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
             void* dhpre = pp(W.dhpre, l);
             void* dqkv = pp(W.dqkv, l);
             MFVIT_TRY(wait_layer(l + 2));                         // layer l+2's wgrads read this parity's dhpre / gmidT / dqkv
-            MFVIT_TRY(fork());                                    // gxT(l) is ready on the main stream
+            // Side stream: the four weight gradients of a block are queued TOGETHER, behind the attention backward (their last input), with ONE
+            // main -> side dependency per block: an event record + wait costs the host ~9 us on this ROCm, and a fork in front of every gradient made
+            // the host the bottleneck of a small-batch step (B = 8: 5.1 -> 6.1 ms).  Their inputs are this layer parity's copies, untouched until then.
+            GemmP def_tn[2];
+            int ndef = 0;
+            auto tn_now_or_later = [&](const GemmP& g) -> int {
+                if (use_side) { def_tn[ndef++] = g; return MFVIT_OK; }
+                return gemm_tn(d.dtype, g, wst);
+            };
             const void* gy2 = gxT;                                // dY of fc2: the residual gradient, masked where the branch was dropped
             if (rdrop) {
                 MFVIT_TRY(mask_scale_rows(d.dtype, false, gxT, D * e, ws + W.dtmp, D * e, make_drop(d.p_resid, d.seed, site(l, 4)), d.M, d.D, st));
@@ -624,7 +633,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 if (rdrop) p.cs0 = gb + L.fc2_b;
                 p.out0 = gb + L.fc2_w; p.ldo0 = F;
                 p.cpart = next_tnpart();                          // split partials: plain stores, reduced in a fixed order at the end of the call
-                MFVIT_TRY(gemm_tn(d.dtype, p, wst));
+                MFVIT_TRY(tn_now_or_later(p));
             }
             {   // dhpre = (gx W2) * gelu'(hpre)
                 GemmP p = zero_gemm();
@@ -635,7 +644,6 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 if (fc1b_in_tile()) p.cs0 = gb + L.fc1_b;         // d fc1_b += column sums of dhpre from the accumulators of this epilogue (float atomics)
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_GELU_BWD, p, st));
             }
-            MFVIT_TRY(fork());
             {   // dW1 += dhpre^T y2
                 GemmP p = zero_gemm();
                 p.A = dhpre; p.lda = F * e; p.W = b + W.y2; p.ldw = D * e;
@@ -643,7 +651,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 if (!fc1b_in_tile()) p.cs0 = gb + L.fc1_b;        // d fc1_b += column sums of dhpre (ones-fragment MFMA in the wgrad kernel)
                 p.out0 = gb + L.fc1_w; p.ldo0 = D;
                 p.cpart = next_tnpart();                          // split partials: plain stores, reduced in a fixed order at the end of the call
-                MFVIT_TRY(gemm_tn(d.dtype, p, wst));
+                MFVIT_TRY(tn_now_or_later(p));
             }
             {   // gmid = LN2bwd(dhpre W1) + gx ; d ln2_w, d ln2_b, d proj_b
                 GemmP p = zero_gemm();
@@ -676,7 +684,6 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 MFVIT_TRY(mask_scale_rows(d.dtype, false, gmidT, D * e, ws + W.dtmp, D * e, make_drop(d.p_resid, d.seed, site(l, 3)), d.M, d.D, st));
                 gyp = ws + W.dtmp;
             }
-            MFVIT_TRY(fork());
             GemmP pend_proj = zero_gemm();                        // dWproj: launched here, or held back to ride along with dWqkv (one launch for both)
             bool have_pend = false;
             {   // dWproj += gmid^T attn
@@ -688,7 +695,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.cpart = next_tnpart();                          // split partials: plain stores, reduced in a fixed order at the end of the call
                 // held back by default when the weight gradients run on the caller's stream (nothing to overlap: one launch less is a pure gain,
                 // 30.81 -> 30.68 ms per step)
-                if (!rdrop && !use_side) {
+                if (!rdrop) {
                     pend_proj = p;
                     have_pend = true;
                 } else {
@@ -708,7 +715,8 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
             else
             MFVIT_TRY(attn_bwd(attn_qkv_dtype(d.dtype, d.T, d.HD), b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, nullptr,
                                d.B, d.T, d.H, d.HD, st));
-            MFVIT_TRY(fork());
+            MFVIT_TRY(fork());                                    // dqkv - and with it every input of this block's weight gradients - is ready
+            for (int i = 0; i < ndef; ++i) MFVIT_TRY(gemm_tn(d.dtype, def_tn[i], wst));
             {   // dWqkv += dqkv^T y1 ; d qkv_b += column sums of dqkv (ones-fragment MFMA inside the wgrad kernel)
                 GemmP p = zero_gemm();
                 p.A = dqkv; p.lda = 3 * D * e; p.W = b + W.y1; p.ldw = D * e;
