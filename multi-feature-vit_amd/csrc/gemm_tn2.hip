@@ -23,6 +23,10 @@
 #include "kernels.h"
 #include "prof.h"
 
+#ifndef MFVIT_TNPART_PLAIN
+#define MFVIT_TNPART_PLAIN 0
+#endif
+
 namespace mfvit {
 
 namespace {
@@ -373,7 +377,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
                     for (int r = 0; r < 16; ++r) {
                         const int n = nw + i * 32 + acc_row(r, lane);
                         const int k = kw + j * 32 + (lane & 31);
+#if MFVIT_TNPART_PLAIN        // A/B builds only: plain stores for the split partials (the reduce launch reads them back within microseconds)
+                        part[(long)n * p.K + k] = acc[i][j][r];
+#else
                         __builtin_nontemporal_store(acc[i][j][r], part + (long)n * p.K + k);
+#endif
                     }
         } else {
 #pragma unroll

@@ -24,3 +24,16 @@ for ev in prof.events():
         cnt[(ev.name, st[0] if st else "(no python frame: autograd engine / C++)")] += 1
 for (name, where), n in cnt.most_common(40):
     print(f"{n / 3:6.1f} per step  {name:18s} {where}")
+
+# the same three steps at the KERNEL level: launches per step by kernel name (what rocprofv3 --stats counts over the whole process, model construction included)
+kc = collections.Counter()
+for ev in prof.events():
+    if ev.device_type == torch.autograd.DeviceType.CUDA:
+        kc[ev.name.split("(")[0][:100]] += 1
+print("---- device kernels / memory operations per step (3 profiled steps)")
+tot = 0
+for name, n in kc.most_common():
+    tot += n
+    if any(t in name for t in ("Fill", "fill", "copy", "Copy", "Memset", "Memcpy", "elementwise")) or n / 3 >= 20:
+        print(f"{n / 3:7.1f} per step  {name}")
+print(f"{tot / 3:7.1f} per step  ALL")
