@@ -820,10 +820,12 @@ struct RpGeo { int rpt, tiles, S; };
 RpGeo rp_geometry(const GemmP& p, int cap, int kg, bool bwd) {
     RpGeo g;
     g.S = 1;
-    static int sw_ks = INT_MIN, sw_ksb = INT_MIN;
+    static int sw_ks = INT_MIN;
     const int ks_env = env_switch("MFVIT_ROWP_KSPLIT", -1, sw_ks);
     const int nk = p.K / kg;
-    if (p.kpart && p.kcnt && ks_env != 0 && p.K >= 1024 && (!bwd || ks_env > 0 || env_switch("MFVIT_ROWP_KSPLIT_BWD", 1, sw_ksb) != 0)) {
+    // (both epilogues: split in the forward only, the B = 16 step took 6.5 instead of 6.17 ms)
+    (void)bwd;
+    if (p.kpart && p.kcnt && ks_env != 0 && p.K >= 1024) {
         const int wgs = rp_cus() / (stream_share() >= 2 ? 2 : 1);      // workgroups this launch should put on the chip
         // as many splits as leave a tile ~ 56 rows (3 - 4 row fragments): measured at 16 pairs per step beside a second stream (M = 3,152, 128 workgroups):
         // S = 2 (64 tiles of 49 rows) 6.16 ms per step, 3 (43 x 74) 6.22, 4 (32 x 99) 6.42, none 6.5; at 32 pairs two splits of 99-row tiles lose (9.02 -> 9.17)
