@@ -849,17 +849,21 @@ RpGeo rp_geometry(const GemmP& p, int cap, int kg, bool bwd) {
 // arrival counters of the K-split launches: one zeroed set of 512 per stream (launches of one stream never overlap; every launch leaves its counters zero)
 __device__ unsigned g_rowp_kcnt[16][512];
 unsigned* rowp_counters(hipStream_t st) {
+    // per DEVICE: the symbol has one instance on every GPU of the process, stream handles belong to a device
+    constexpr int MAXDEV = 16;
     static std::mutex mu;
-    static hipStream_t owner[16];
-    static int used = 0;
-    static unsigned* base = nullptr;
+    static hipStream_t owner[MAXDEV][16];
+    static int used[MAXDEV] = {};
+    static unsigned* base[MAXDEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
-    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_rowp_kcnt)) != hipSuccess) return nullptr;
-    for (int i = 0; i < used; ++i)
-        if (owner[i] == st) return base + i * 512;
-    if (used == 16) return nullptr;                                    // more streams than sets: no K splits for the newcomers
-    owner[used] = st;
-    return base + (used++) * 512;
+    if (!base[dev] && hipGetSymbolAddress((void**)&base[dev], HIP_SYMBOL(g_rowp_kcnt)) != hipSuccess) return nullptr;
+    for (int i = 0; i < used[dev]; ++i)
+        if (owner[dev][i] == st) return base[dev] + i * 512;
+    if (used[dev] == 16) return nullptr;                               // more streams than sets: no K splits for the newcomers
+    owner[dev][used[dev]] = st;
+    return base[dev] + (used[dev]++) * 512;
 }
 template <int MODE> constexpr int rp_cap() { return MODE == REPI_LNBWD_RES ? RP_XROWS : RP_TH; }
 

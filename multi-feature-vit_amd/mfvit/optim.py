@@ -60,7 +60,7 @@ class _TableOptimizer(torch.optim.Optimizer):
         # tensor - mean the same table.  One flat list of integers is compared; nothing else is touched.
         params = group["params"]
         last = cache.get("last")
-        if last is not None and len(last[0]) == len(params):
+        if last is not None and len(last[0]) == len(params) and last[4] == len(self.state):     # (state.clear() / a new parameter: the slow path)
             names = self.state_names
             sig = []
             try:
@@ -119,7 +119,7 @@ class _TableOptimizer(torch.optim.Optimizer):
             if st is not None:
                 for n in self.state_names:
                     sig.append(st[n].data_ptr())
-        cache["last"] = (list(params), sts, sig, out)
+        cache["last"] = (list(params), sts, sig, out, len(self.state))
         return out
 
     def _flag(self, p, group):
