@@ -63,6 +63,8 @@ def parse():
                     help="run the whole benchmark on ONE stream (no second encoder stream, no wgrad side stream): the mode whose "
                          "rocprofv3 kernel durations the roofline's per-kernel numbers are checked against")
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--arch", choices=["vit_small", "vit_base"], default="vit_small",
+                    help="backbone of the `single` workload (MAIN_MOCO:50 `-a`): vit_base runs the unfused encoder path (tile GEMMs + LayerNorm row passes)")
     return ap.parse_args()
 
 
@@ -197,7 +199,7 @@ def other_workloads(args, world, rank, dev, lib):
     sync = GradSync()
     if args.workload == "single":
         B = 64 if args.batch == 128 else args.batch
-        model = vits.vit_small(num_classes=3, precision=args.precision, img_size=args.img).to(dev)     # MAIN_SS:276,290
+        model = vits.__dict__[args.arch](num_classes=3, precision=args.precision, img_size=args.img).to(dev)     # MAIN_SS:276,290
         sync.attach(model)
         x = torch.randn(B, 3, args.img, args.img, generator=g).to(dev)
         y = torch.randint(0, 3, (B,), generator=g).to(dev)
@@ -212,6 +214,8 @@ def other_workloads(args, world, rank, dev, lib):
             opt.step()
             return loss
         gflop, name = 27.59, "images/sec (single-stream vit_small fwd+bwd step, BASELINE configs[1])"
+        if args.arch == "vit_base":        # 3 x (12 blocks x 2 x 197 x (4 + 8) x 768^2 + attention 4 x 197^2 x 768 per block + patch embedding) flops per image
+            gflop, name = 3 * (12 * (2 * 197 * 12 * 768 * 768 + 4 * 197 * 197 * 768) + 2 * 196 * 768 * 768) / 1e9, "images/sec (single-stream vit_base fwd+bwd step)"
     else:
         import moco.builder_vit_mocov3structure_mocov2loss as bld
         from mfvit.moco_ops import cross_entropy_rows
