@@ -27,7 +27,8 @@ constexpr int TILE_BYTES = BM * ROWB;                    // 16 KB per operand an
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + 16 * (chunk ^ (row & 7)); }
 
 // FORMAT 0: x3, 1: hf8.  K tiles: ktiles = K / 32 for both (x3: one 32-group per tile; hf8: tiles alternate hi / 8-bit, two per 64-group)
-template <int FORMAT>
+template <int FORMAT, int ABL = 0>      // ABL (timing only, results invalid): 1 no MFMAs, 2 no global loads after the first tile, 4 no LDS stores, 8 no fragment reads; 16 (VALID results): staging by LDS-DMA
+// (global_load_lds_dwordx4: L2 -> LDS without the register round trip and the ds_write; the XOR swizzle goes on the per-lane SOURCE address)
 __global__ __launch_bounds__(256, 2) void gemm_proto(const char* __restrict__ A, const char* __restrict__ W, float* __restrict__ C, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -64,28 +65,61 @@ __global__ __launch_bounds__(256, 2) void gemm_proto(const char* __restrict__ A,
     };
     auto frag = [&](const char* t, int rowbase, int chunk) { return *(const i32x4*)(t + lds_off(rowbase + (lane & 31), chunk)); };
     const int h = lane >> 5;
-    gload(0);
-    lstore(lds);
+    i32x4 keep[2][2][4];
+    (void)keep;
+    // LDS-DMA: one wave instruction fills 1 KB = 8 rows x 128 B (lane l -> row 8 i + l / 8, slot l % 8, which must hold chunk slot ^ (row & 7))
+    auto dma = [&](int kt, char* st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int blk = wave * 4 + i, row = 8 * blk + (lane >> 3), c = (lane & 7) ^ (row & 7);
+            int gm = m0 + row;
+            gm = gm < M ? gm : M - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + (long)gm * ldb + (long)kt * ROWB + 16 * c),
+                                             (__attribute__((address_space(3))) void*)(st + blk * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (long)(n0 + row) * ldb + (long)kt * ROWB + 16 * c),
+                                             (__attribute__((address_space(3))) void*)(st + TILE_BYTES + blk * 1024), 16, 0, 0);
+        }
+    };
+    if constexpr (ABL & 16) {
+        dma(0, lds);
+    } else {
+        gload(0);
+        lstore(lds);
+    }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const char* ta = lds + (kt & 1) * 2 * TILE_BYTES;
         const char* tb = ta + TILE_BYTES;
-        if (kt + 1 < nkt) gload(kt + 1);
+        if constexpr (ABL & 16) { if (kt + 1 < nkt) dma(kt + 1, lds + ((kt + 1) & 1) * 2 * TILE_BYTES); }
+        else if (kt + 1 < nkt && !(ABL & 2)) gload(kt + 1);
         if constexpr (FORMAT == 0) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
+                    if ((ABL & 8) && kt > 0) {        // keep the first tile's fragments (made opaque so that nothing is hoisted or folded)
+                        asm volatile("" : "+v"(keep[s][i][0]), "+v"(keep[s][i][1]), "+v"(keep[s][i][2]), "+v"(keep[s][i][3]));
+                        ah[i] = __builtin_bit_cast(bf16x8, keep[s][i][0]); al[i] = __builtin_bit_cast(bf16x8, keep[s][i][1]);
+                        bh[i] = __builtin_bit_cast(bf16x8, keep[s][i][2]); bl[i] = __builtin_bit_cast(bf16x8, keep[s][i][3]);
+                        continue;
+                    }
                     ah[i] = __builtin_bit_cast(bf16x8, frag(ta, (wm * 2 + i) * 32, 2 * s + h));
                     al[i] = __builtin_bit_cast(bf16x8, frag(ta, (wm * 2 + i) * 32, 4 + 2 * s + h));
                     bh[i] = __builtin_bit_cast(bf16x8, frag(tb, (wn * 2 + i) * 32, 2 * s + h));
                     bl[i] = __builtin_bit_cast(bf16x8, frag(tb, (wn * 2 + i) * 32, 4 + 2 * s + h));
+                    if (ABL & 8) { keep[s][i][0] = __builtin_bit_cast(i32x4, ah[i]); keep[s][i][1] = __builtin_bit_cast(i32x4, al[i]);
+                                   keep[s][i][2] = __builtin_bit_cast(i32x4, bh[i]); keep[s][i][3] = __builtin_bit_cast(i32x4, bl[i]); }
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+                        if (ABL & 1) {                // consume the fragments with two VALU ops instead of three MFMAs
+                            const i32x4 u = __builtin_bit_cast(i32x4, al[i]) ^ __builtin_bit_cast(i32x4, bh[j]) ^ __builtin_bit_cast(i32x4, ah[i]) ^ __builtin_bit_cast(i32x4, bl[j]);
+                            acc[i][j][0] += __int_as_float((u[0] ^ u[1] ^ u[2] ^ u[3]) & 0x3fffffff);
+                            continue;
+                        }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
@@ -129,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void gemm_proto(const char* __restrict__ A,
                     }
             }
         }
-        if (kt + 1 < nkt) lstore(lds + ((kt + 1) & 1) * 2 * TILE_BYTES);
+        if (kt + 1 < nkt && !(ABL & 4) && !(ABL & 16)) lstore(lds + ((kt + 1) & 1) * 2 * TILE_BYTES);
         __syncthreads();
     }
     // C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -205,6 +239,11 @@ int main(int argc, char** argv) {
     const int grid = ((M + BM - 1) / BM) * (N / BN), ldsb = 4 * TILE_BYTES;
     (void)hipFuncSetAttribute((const void*)gemm_proto<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
     (void)hipFuncSetAttribute((const void*)gemm_proto<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    (void)hipFuncSetAttribute((const void*)gemm_proto<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb); (void)hipFuncSetAttribute((const void*)gemm_proto<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    (void)hipFuncSetAttribute((const void*)gemm_proto<0, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb); (void)hipFuncSetAttribute((const void*)gemm_proto<0, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    (void)hipFuncSetAttribute((const void*)gemm_proto<0, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb); (void)hipFuncSetAttribute((const void*)gemm_proto<0, 13>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    (void)hipFuncSetAttribute((const void*)gemm_proto<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    (void)hipFuncSetAttribute((const void*)gemm_proto<0, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb); (void)hipFuncSetAttribute((const void*)gemm_proto<0, 17>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
     double t0 = 0;
     for (int f = 0; f < 2; ++f) {
         (void)hipMemcpy(dA, pa[f].data(), pa[f].size(), hipMemcpyHostToDevice);
@@ -229,6 +268,46 @@ int main(int argc, char** argv) {
                 for (int k = 0; k < K; ++k) y += (double)a[(size_t)m * K + k] * (double)w[(size_t)n * K + k];
                 const double d = fabs((double)c[(size_t)m * N + n] - y);
                 emax = d > emax ? d : emax; ymax = fabs(y) > ymax ? fabs(y) : ymax; e2 += d * d; y2 += y * y;
+            }
+        }
+        if (f == 0 && argc > 4) {           // ablation sweep of the x3 loop (timing only)
+            auto timeit = [&](auto kern, const char* what) {
+                float b2 = 1e30f;
+                for (int rep = 0; rep < 20; ++rep) {
+                    (void)hipEventRecord(e0);
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsb, 0, dA, dW, dC, M, N, K);
+                    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+                    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                    if (rep >= 5 && ms < b2) b2 = ms;
+                }
+                printf("   x3 ablation %-58s %8.1f us\n", what, b2 * 1e3);
+            };
+            timeit(gemm_proto<0, 1>, "no MFMAs (loads + LDS stores + fragment reads)");
+            timeit(gemm_proto<0, 2>, "no global loads after the first tile");
+            timeit(gemm_proto<0, 2 | 4>, "no global loads, no LDS stores (fragment reads + MFMAs)");
+            timeit(gemm_proto<0, 2 | 4 | 8>, "MFMAs only");
+            timeit(gemm_proto<0, 1 | 8>, "loads + LDS stores only (no fragment reads, no MFMAs)");
+            timeit(gemm_proto<0, 1 | 4 | 8>, "global loads only");
+            timeit(gemm_proto<0, 8>, "no fragment reads (loads + LDS stores + MFMAs)");
+            timeit(gemm_proto<0, 16>, "FULL kernel with LDS-DMA staging (valid results)");
+            timeit(gemm_proto<0, 16 | 1>, "LDS-DMA staging, no MFMAs");
+            (void)hipMemset(dC, 0, (size_t)M * N * 4);
+            hipLaunchKernelGGL((gemm_proto<0, 16>), dim3(grid), dim3(256), ldsb, 0, dA, dW, dC, M, N, K);
+            (void)hipDeviceSynchronize();
+            {
+                std::vector<float> c2((size_t)64 * N);
+                double emax = 0, ymax = 0;
+                for (int s2 = 0; s2 < 64; ++s2) {
+                    const int m = (int)(((long)s2 * 7919) % M);
+                    (void)hipMemcpy(c2.data(), dC + (size_t)m * N, (size_t)N * 4, hipMemcpyDeviceToHost);
+                    for (int n = 0; n < N; ++n) {
+                        double y = 0;
+                        for (int k = 0; k < K; ++k) y += (double)a[(size_t)m * K + k] * (double)w[(size_t)n * K + k];
+                        const double d = fabs((double)c2[n] - y);
+                        emax = d > emax ? d : emax; ymax = fabs(y) > ymax ? fabs(y) : ymax;
+                    }
+                }
+                printf("   LDS-DMA staging: max-rel error against float64 %.2e\n", emax / ymax);
             }
         }
         const double tf = 2.0 * M * N * K / (best * 1e-3) / 1e12;
