@@ -47,7 +47,8 @@ typedef void* mfvit_stream_t; /* hipStream_t */
 #define MFVIT_X3F16 4
 
 /* ABI history: 3 = rounds 3 - 4.  4 (round 5, BREAKING): mfvit_linear_fwd_persistent / mfvit_linear_fwd_ws (dropped in round 4 without a
- * version bump) and mfvit_mhsa_fused_fwd are gone; MFVIT_X3F16, linear epilogue 5, mfvit_attention_qkv_dtype and mfvit_adam_step_dev are new. */
+ * version bump) and mfvit_mhsa_fused_fwd are gone; MFVIT_X3F16, linear epilogue 5, mfvit_attention_qkv_dtype and mfvit_adam_step_dev are new.
+ * 5 (round 6, BREAKING): mfvit_adam_step_dev is gone (the whole-step HIP graph it served was removed). */
 int mfvit_abi_version(void);
 const char* mfvit_build_info(void);
 
@@ -351,10 +352,6 @@ int mfvit_lars_step(const int64_t* table, int nchunks, int ntensors, float* norm
                     float trust_coefficient, mfvit_stream_t stream);
 int mfvit_adam_step(const int64_t* table, int nchunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     mfvit_stream_t stream);
-/* The same update with the hyper-parameters in DEVICE memory - hyper[0..5] = lr, beta1, beta2, eps, weight_decay, step count (a float,
- * counting from 1 at the first update) - for train steps captured into a HIP graph (a step number passed by value would freeze the bias
- * correction at the capture's).  advance != 0: hyper[5] += 1 on the device before the update (once per optimizer step). */
-int mfvit_adam_step_dev(const int64_t* table, int nchunks, float* hyper, int advance, mfvit_stream_t stream);
 int mfvit_sgd_step(const int64_t* table, int nchunks, float lr, float momentum, float weight_decay, int first_step,
                    mfvit_stream_t stream);
 /* torch.cuda.amp.GradScaler.unscale_ over the same chunk table (MAIN_MOCO:349,546-548: scaler.scale(loss).backward();

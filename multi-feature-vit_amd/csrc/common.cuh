@@ -235,7 +235,7 @@ template <int NT> __device__ __forceinline__ float block_max(float v, float* scr
 // Streaming 16-byte OUTPUT store (`sc0 sc1 nt`: system scope, non-temporal).  Round 5, measured with FETCH_SIZE: with plain or nt-only stores the L2
 // FETCHES every output line it allocates (write-allocate: fc1 + GELU read 135 MB from HBM for 41 MB of operands, the fc2 data gradient 221 for 119 -
 // the "1.4 - 1.5 x wasted traffic" of rounds 3 - 4 was never operand re-reads); with the scope bits the line goes through without the fetch: 56 / 152 MB,
-// -3 ... -4 % per launch (profiles/r05_tile_store_policy.txt).  For tensors the NEXT kernel streams from HBM anyway (hundreds of MB per launch).
+// -3 ... -4 % per launch (profiles/r05_tile_gemm_experiments.txt).  For tensors the NEXT kernel streams from HBM anyway (hundreds of MB per launch).
 typedef unsigned int u32x4_st __attribute__((ext_vector_type(4)));
 // (s_nop behind it: a vector-memory store of more than 64 bits reads its data registers late - the next write of those registers needs wait states
 // (CDNA3 ISA 4.5, "VMEM store more than 8 bytes followed by a write of the write-data VGPRs").  The compiler inserts them for the stores it knows;

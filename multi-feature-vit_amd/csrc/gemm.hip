@@ -30,7 +30,7 @@ namespace mfvit {
 // ------------------------------------------------------------------------------------------ tile kernel
 // (Round 5 tried an N-wide 128 x 256 tile of 8 waves, one workgroup per CU - half the A re-reads across the N tiles of a row block, 3/4 of the staged
 // operand bytes per MFMA: bit-identical, L2 requests - 17 %, and 4 - 9 % SLOWER (fc1 + GELU 130.0 -> 135.7 us, fc2 data gradient 112.9 -> 122.9 us);
-// like the M-tall 256 x 128 tile of round 4 it gives up the second independent workgroup per CU.  Removed; profiles/r05_tile_wide_ab.txt.)
+// like the M-tall 256 x 128 tile of round 4 it gives up the second independent workgroup per CU.  Removed; profiles/r05_tile_gemm_experiments.txt.)
 template <typename T, int EPI, int DEEP = 0>     // DEEP: K tiles kept in flight by the main loop (0: NtLoop's one; 2: NtLoopDeep, 16-bit types; 12: interleaved, split)
 __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 workgroups per CU (64 - 68 KB of LDS each): register budget 256 per wave
     constexpr int BM = 128, BN = 128, BKB = 128, WM = 2, WN = 2, NTHR = WM * WN * 64;

@@ -107,45 +107,6 @@ __global__ __launch_bounds__(256) void adam_kernel(const long* __restrict__ tab,
         p[i] = pv;
     }
 }
-// The same update with the hyper-parameters in DEVICE memory (hyper[0..5] = lr, beta1, beta2, eps, weight decay, step count as a float): what a
-// captured HIP graph replays - a step number passed by value would freeze the bias correction at the value of the capture.  hyper_step_kernel
-// advances the count once per optimizer step, in front of the update kernels.
-__global__ void hyper_step_kernel(float* __restrict__ hyper) { hyper[5] += 1.0f; }
-__global__ __launch_bounds__(256) void adam_dev_kernel(const long* __restrict__ tab, const float* __restrict__ hyper) {
-    const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4], step = hyper[5];
-    const float bc1 = 1.f - powf(beta1, step), bc2_sqrt = sqrtf(1.f - powf(beta2, step));
-    const long* e = tab + (long)blockIdx.x * CH;
-    float* p = (float*)e[1];
-    const float* g = (const float*)e[2];
-    float* m = (float*)e[3];
-    float* v = (float*)e[4];
-    const long n = e[5];
-    const bool decoupled = e[6] & 1;
-    long done = 0;
-    if ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0) {
-        const long n4 = n >> 2;
-        float4* p4 = (float4*)p;
-        const float4* g4 = (const float4*)g;
-        float4* m4 = (float4*)m;
-        float4* v4 = (float4*)v;
-        for (long i = threadIdx.x; i < n4; i += 256) {
-            float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
-            adam_elem(pa.x, ga.x, ma.x, va.x, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
-            adam_elem(pa.y, ga.y, ma.y, va.y, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
-            adam_elem(pa.z, ga.z, ma.z, va.z, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
-            adam_elem(pa.w, ga.w, ma.w, va.w, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
-            p4[i] = pa; m4[i] = ma; v4[i] = va;
-        }
-        done = n4 << 2;
-    }
-    for (long i = done + threadIdx.x; i < n; i += 256) {
-        float pv = p[i], mv = m[i], vv = v[i];
-        adam_elem(pv, g[i], mv, vv, decoupled, lr, beta1, beta2, eps, wd, bc1, bc2_sqrt);
-        m[i] = mv;
-        v[i] = vv;
-        p[i] = pv;
-    }
-}
 __global__ __launch_bounds__(256) void sgd_kernel(const long* __restrict__ tab, float lr, float momentum, float wd, int first) {
     const long* e = tab + (long)blockIdx.x * CH;
     float* p = (float*)e[1];
@@ -202,13 +163,6 @@ int mfvit_adam_step(const int64_t* table, int nchunks, float lr, float beta1, fl
     const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
     MFVIT_LAUNCH(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, lr, beta1, beta2, eps, weight_decay,
                        bc1, bc2s);
-    MFVIT_CHECK_LAUNCH();
-    return MFVIT_OK;
-}
-int mfvit_adam_step_dev(const int64_t* table, int nchunks, float* hyper, int advance, mfvit_stream_t stream) {
-    if (!table || !hyper || nchunks <= 0) return MFVIT_EINVAL;
-    if (advance) MFVIT_LAUNCH(hyper_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper);
-    MFVIT_LAUNCH(adam_dev_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const long*)table, (const float*)hyper);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

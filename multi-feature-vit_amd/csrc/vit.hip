@@ -273,7 +273,7 @@ SideStream& side_stream(hipStream_t caller) {
 
 extern "C" {
 
-int mfvit_abi_version(void) { return 4; }
+int mfvit_abi_version(void) { return 5; }
 int mfvit_set_stream_share(int n) {
     mfvit::g_stream_share.store(n < 1 ? 1 : (n > 8 ? 8 : n), std::memory_order_relaxed);
     return MFVIT_OK;
@@ -544,7 +544,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     // order the workgroups finish).  Round 3 measured the same idea with a reduce launch behind EVERY gradient as a loss (77.2 -> 80.8 us per
     // launch); batched it costs 0.4 - 0.6 % of the step (round 5, profiles/r05_wgrad_partials_ab.txt: weight-gradient class 95.6 -> 90.8 us per launch,
     // the reduce launches take most of it back; per block - partials still in the Infinity Cache - beats per call by 0.07 ms).  MFVIT_TN_PART=0: float
-    // atomics.  (With the opt-in weight-gradient side stream the partial path is off: its launches are not ordered with the reduce on this stream.)
+    // atomics.  (With the weight-gradient side stream the partial path stays ON: every weight gradient and every reduce of a call then runs in the side stream's order.)
     static const bool tn_part_env = [] { const char* e = getenv("MFVIT_TN_PART"); return !(e && e[0] == '0'); }();
     int tn_used = 0;
     bool tn_part = tn_part_env;                // (decided below, once use_side is known)
@@ -561,7 +561,9 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     auto pp = [&](size_t off, int l) { return (void*)(ws + off + (size_t)(l & 1) * W.pp_stride); };
     // (side_wanted, below, decides whether the side stream of this caller stream is looked up - and created - at all)
     static const int side_env = [] { const char* e = getenv("MFVIT_WGRAD_STREAM"); return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1; }();
-    // (never inside a stream capture: forking the library's side stream into a hipGraph capture crashed capture_end on ROCm 7.2 - tests/test_graph_gpu.py)
+    // (never inside a caller's stream capture: the library-owned side stream is not part of the caller's capture, and its last weight gradients are joined by the
+    // NEXT call's fork, not before this one returns - a capture ending in between would hold unjoined work.  The package itself no longer captures steps:
+    // the whole-step HIP graph of round 5 gained nothing, 8.22 vs 8.12 ms, and was removed in round 6)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
     const bool side_wanted = (side_env == 1 || (side_env < 0 && d.M >= 1024 && d.M <= 4096)) && g_wgrad_stream.load(std::memory_order_relaxed) != 0 && !(d.p_resid > 0.f) &&

@@ -84,7 +84,6 @@ SIGNATURES = {
     "mfvit_ema_update": (I, [P, P, F, L, P]),
     "mfvit_lars_step": (I, [P, I, I, P, F, F, F, F, P]),
     "mfvit_adam_step": (I, [P, I, F, F, F, F, F, I, P]),
-    "mfvit_adam_step_dev": (I, [P, I, P, I, P]),
     "mfvit_sgd_step": (I, [P, I, F, F, F, I, P]),
     "mfvit_amp_unscale": (I, [P, I, F, P, P]),
     "mfvit_prenorm_xattn_forward": (I, [POINTER(FusionCfg), P, P, P, P, P, P]),

@@ -172,50 +172,12 @@ class LARS(_TableOptimizer):
 
 
 class Adam(_TableOptimizer):
-    """torch.optim.Adam semantics (L2 weight decay folded into the gradient).
-
-    ``capturable=True`` (torch.optim.Adam's flag of the same name): the step count and the hyper-parameters of every param group live in a device
-    tensor (``group["_hyper"]``: lr, beta1, beta2, eps, weight_decay, step) that the kernels read - what a train step captured into a HIP graph
-    (mfvit.graph.GraphedStep) needs, where values passed at launch are frozen into the graph.  The host mirrors lr / weight_decay from the param
-    group into that tensor whenever they change (outside the graph: one small copy), so schedulers keep working between replays.  All parameters
-    of a group share one step count in this mode."""
+    """torch.optim.Adam semantics (L2 weight decay folded into the gradient)."""
     state_names = ("exp_avg", "exp_avg_sq")
     decoupled = False
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, capturable=False):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable))
-
-    # ---- capturable mode
-    def _hyper(self, gi, g, device):
-        c = self._cache().setdefault("hyper", {})
-        want = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
-        h = c.get(gi)
-        if h is None:
-            step0 = 0.0
-            for p in g["params"]:
-                t = self.state.get(p, {}).get("step")
-                if t is not None:
-                    step0 = max(step0, float(t))
-            h = c[gi] = [torch.tensor(list(want) + [step0, 0.0, 0.0], dtype=torch.float32, device=device), want]
-        elif h[1] != want:            # a scheduler changed lr / weight decay: mirror it (never inside a capture - the values are read on the device)
-            if torch.cuda.is_current_stream_capturing():
-                raise _lib.MfvitError("hyper-parameters of a capturable optimizer changed inside a graph capture")
-            h[0][:5].copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
-            h[1] = want
-        return h[0]
-
-    def sync_hyper(self):
-        """Mirror the param groups' lr / betas / eps / weight_decay into the device tensors (call after a scheduler step, between graph replays)."""
-        for gi, g in enumerate(self.param_groups):
-            if g.get("capturable"):
-                ps = [p for p in g["params"] if p.is_cuda]
-                if ps:
-                    self._hyper(gi, g, ps[0].device)
-
-    def step_count(self, gi=0):
-        """Optimizer steps taken by param group gi (capturable mode: read back from the device)."""
-        h = self._cache().get("hyper", {}).get(gi)
-        return int(h[0][5].item()) if h is not None else 0
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
     def _flag(self, p, group):
         return 1 if self.decoupled else 0
@@ -254,11 +216,6 @@ class Adam(_TableOptimizer):
             table, nt, live = self._table(gi, g)
             if table is None:
                 continue
-            if g.get("capturable"):
-                hyper = self._hyper(gi, g, table.device)
-                check(lib().mfvit_adam_step_dev(ptr(table), table.shape[0], ptr(hyper), 1, stream()), "mfvit_adam_step_dev")
-                _bump_versions(live)
-                continue
             # per-parameter 'step' like torch.optim (f32 scalar tensors on the host).  One kernel launch serves one step number (bias
             # correction): normally every parameter of the group agrees and the whole table goes out in one launch; otherwise (a parameter
             # whose first gradient arrived later, an unfrozen layer, a loaded torch state dict with mixed steps) the table rows - laid out
@@ -287,8 +244,8 @@ class AdamW(Adam):
     """torch.optim.AdamW semantics (decoupled weight decay; default 1e-2 like torch)."""
     decoupled = True
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False):
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable)
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
 
 
 class SGD(_TableOptimizer):

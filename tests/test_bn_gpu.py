@@ -90,3 +90,37 @@ def test_batchnorm_eval_mode_uses_the_running_statistics(prec):
     k = bn.weight.detach().cpu().double() / torch.sqrt(bn.running_var.cpu().double() + bn.eps)
     y_ref = (x.double() - bn.running_mean.cpu().double()) * k + bn.bias.detach().cpu().double()
     assert rel(y, y_ref) < TOL[prec] and rel(xg.grad, k.expand(n, C)) < TOL[prec]
+
+
+@pytest.mark.parametrize("counts", [[16] * 8, [3, 40, 1, 16, 16, 7, 25, 20]], ids=["equal", "ragged"])
+def test_chan_combine_of_eight_partial_statistics(counts):
+    """SyncBatchNorm at world size 8 (configs[3] / [4]; MAIN_MOCO:297 over BLD:62-78) without 8 GPUs: mfvit_bn_stats on each of 8 row slices (what each
+    rank computes), the triples laid out as the all-gather delivers them, mfvit_bn_combine with W = 8 - against float64 BatchNorm statistics of the
+    concatenated batch and against the oracle's restatement of the combine (oracle/ref_moco.py::bn_chan_combine, which the 8-rank gloo test runs on the CPU)."""
+    from mfvit._lib import check, lib, ptr, stream
+    from mfvit import ops
+    from oracle import ref_moco
+    C, W = 512, len(counts)
+    g = torch.Generator().manual_seed(11)
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + c)
+    x = torch.randn(offs[-1], C, generator=g) * torch.linspace(0.3, 4.0, C) + torch.repeat_interleave(torch.arange(W).float(), torch.tensor(counts))[:, None] * 0.9
+    xd = x.to(DEV)
+    means, m2s = torch.empty(W, C, device=DEV), torch.empty(W, C, device=DEV)
+    for w in range(W):
+        part = xd[offs[w]:offs[w + 1]].contiguous()
+        check(lib().mfvit_bn_stats(ops._code_of(part), ptr(part), part.shape[0], C, ptr(means[w]), ptr(m2s[w]), stream()), "mfvit_bn_stats")
+    cnt = torch.tensor(counts, dtype=torch.float32, device=DEV)
+    mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    check(lib().mfvit_bn_combine(ptr(means), ptr(m2s), ptr(cnt), W, C, 1e-5, 0.1, ptr(mean), ptr(invstd), ptr(rm), ptr(rv), stream()), "mfvit_bn_combine")
+    x64 = x.double()
+    mu_ref, var_ref = x64.mean(0), x64.var(0, unbiased=False)
+    e = {"mean": rel(mean, mu_ref), "invstd": rel(invstd, 1 / torch.sqrt(var_ref + 1e-5)), "run_mean": rel(rm, 0.1 * mu_ref),
+         "run_var": rel(rv, 0.9 + 0.1 * x64.var(0, unbiased=True))}
+    stats = torch.cat([torch.cat([ref_moco.bn_partial_stats(x[offs[w]:offs[w + 1]])]) for w in range(W)])
+    o_mu, o_var, o_invstd, _ = ref_moco.bn_chan_combine(stats, C)
+    e["vs_oracle_mean"], e["vs_oracle_invstd"] = rel(mean, o_mu), rel(invstd, o_invstd)
+    log(f"Chan combine[W = 8, counts {counts}] " + " ".join(f"{k} {v:.2e}" for k, v in e.items()))
+    assert all(v < 2e-5 for v in e.values()), e

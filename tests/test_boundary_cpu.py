@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(h, s), f"{s} declared in include/mfvit.h but not exported"
     assert sorted(_lib.SIGNATURES.keys()) == syms, "ctypes table and header disagree"
-    assert h.mfvit_abi_version() == 4
+    assert h.mfvit_abi_version() == 5
     assert b"gfx950" in h.mfvit_build_info()
 
 

@@ -160,6 +160,125 @@ def test_two_rank_gloo_paths():
         assert ok1 and ok2 and ok3 and ok4, (rank, ok1, ok2, ok3, ok4)
 
 
+def _worker8(rank, world, port, q):
+    """The N > 1 host paths at the world size configs[3] / [4] run at (8 ranks; VERDICT r5 task 6): every rank-count-dependent piece of
+    arithmetic - shard sizes, remainders, pointer wrap, permutation slices, the order of Chan's combine - with W = 8 instead of 2."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mfvit.ddp import GradSync
+        bld, m = _moco()
+        ok, notes = {}, {}
+        vit = m.base_encoder
+        n_arena = vit.flat_parameters().numel()
+        mean_of_ranks = (world + 1) / 2.0                       # ranks hold rank + 1
+        # (1) all-reduce and reduce-scatter + all-gather, f32 and bf16 buckets, one block per bucket and everything in one bucket;
+        #     bucket sizes that do NOT divide over 8 ranks (the arena slices of a block: 1,774,464 = 8 x 221,808 does; the embedding / head
+        #     groups and the explicit odd tensors below do not)
+        for exch in ("allreduce", "rs_ag"):
+            for bdt in (None, torch.bfloat16):
+                for layers in (1, 4):
+                    sy = GradSync(exchange=exch, bucket_dtype=bdt)
+                    sy.attach(vit, bucket_layers=layers)
+                    gen = torch.Generator().manual_seed(100 + rank)
+                    gflat = torch.randn(n_arena, generator=gen)
+                    want = gflat.clone()
+                    dist.all_reduce(want)
+                    want /= world
+                    if layers == 1:
+                        for s in range(vit.depth, -2, -1):
+                            vit._grad_stage_hook(vit, s, s, gflat)
+                    else:
+                        vit._grad_stage_hook(vit, vit.depth, -1, gflat)
+                    pend = sy.pending(vit)
+                    other = torch.nn.Linear(1, 1)
+                    sy.finish(other)                              # joins are per owner: somebody else's join leaves these on the links
+                    held = sy.pending(vit) == pend and pend > 0
+                    sy.finish(vit)
+                    e = float((gflat - want).abs().max() / want.abs().max())
+                    # bf16 buckets: each of the 8 terms is rounded to bf16 (2^-9 of ITS size) before the sum, the mean once more
+                    ok[f"{exch}/{'bf16' if bdt else 'f32'}/{layers}"] = held and sy.pending() == 0 and e < (2e-6 if bdt is None else 1.6e-2)
+                    notes[f"{exch}/{'bf16' if bdt else 'f32'}/{layers}"] = e
+        vit._grad_stage_hook = None
+        for n in (5, 13, 8 * 3 + 7, 64):                          # fewer elements than ranks; 8 + 5 remainder; 24 + 7; divisible
+            for bdt in (torch.float32, torch.bfloat16):
+                t = (torch.arange(n, dtype=torch.float32) * (rank + 1)).to(bdt)
+                for h in GradSync(exchange="rs_ag")._reduce_async(t):
+                    h.wait()
+                ok[f"odd{n}/{bdt}"] = bool(torch.allclose(t.float(), torch.arange(n, dtype=torch.float32) * mean_of_ranks, rtol=1e-2 if bdt is torch.bfloat16 else 1e-6))
+        ps = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))]
+        for i, p in enumerate(ps):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        GradSync().reduce_grads(ps)
+        ok["flat"] = all(torch.allclose(p.grad, torch.full_like(p, mean_of_ranks * (i + 1))) for i, p in enumerate(ps))
+        # (2) SyncBN: the product's rank-local triple, its all-gather layout (mfvit/mlp.py::_BNFn.forward) and Chan's combine over 8 partial
+        #     statistics in rank order against float64 BatchNorm on the concatenated batch.  Unequal means per rank (what shuffle-BN exists for).
+        n, C = 16, 24
+        gen = torch.Generator().manual_seed(7)
+        xall = torch.randn(world * n, C, generator=gen, dtype=torch.float64) * torch.linspace(0.5, 3.0, C, dtype=torch.float64) \
+            + torch.arange(world, dtype=torch.float64).repeat_interleave(n)[:, None] * 0.7
+        st = ref_moco.bn_partial_stats(xall[rank * n:(rank + 1) * n].float())
+        flat = torch.empty(world * (2 * C + 1))
+        dist.all_gather_into_tensor(flat, st)
+        mu, var, invstd, uvar = ref_moco.bn_chan_combine(flat, C)
+        y_ref, mu_ref, var_ref = ref_moco.batchnorm_train(xall, None, None)
+        e_bn = max(float((mu.double() - mu_ref).abs().max() / mu_ref.abs().max()), float((var.double() - var_ref).abs().max() / var_ref.abs().max()),
+                   float((uvar.double() - xall.var(0, unbiased=True)).abs().max() / var_ref.abs().max()))
+        ok["syncbn"] = e_bn < 5e-6 and float(flat.view(world, -1)[:, 2 * C].sum()) == world * n
+        notes["syncbn"] = e_bn
+        # (3) concat_all_gather order, enqueue of N_all = 8 n keys with a pointer that wraps, and a pointer in the middle (BLD:91-105, 229-240)
+        nk = 4
+        keys = torch.nn.functional.normalize(torch.full((nk, 256), float(rank + 1)) + torch.arange(nk).float()[:, None], dim=1)
+        allk = bld.concat_all_gather(keys)
+        ok["gather"] = allk.shape == (world * nk, 256) and torch.equal(allk[rank * nk:(rank + 1) * nk], keys)
+        q0 = m.queue.clone()
+        m.queue_ptr[0] = m.K - world * nk
+        m._dequeue_and_enqueue(keys)
+        ok["enqueue_wrap"] = int(m.queue_ptr) == 0 and torch.equal(m.queue[:, m.K - world * nk:], allk.t()) and \
+            torch.equal(m.queue[:, :m.K - world * nk], q0[:, :m.K - world * nk])
+        m._dequeue_and_enqueue(keys * 0.5)
+        ok["enqueue_next"] = int(m.queue_ptr) == world * nk and torch.equal(m.queue[:, :world * nk], allk.t() * 0.5)
+        # (4) shuffle / unshuffle (BLD:107-152) at W = 8: rank 0's permutation everywhere, every sample exactly once, the round trip is the identity
+        x = torch.arange(rank * nk, (rank + 1) * nk, dtype=torch.float32)[:, None].repeat(1, 3)
+        torch.manual_seed(1000 + rank)                             # different local RNG states: the broadcast must win
+        xs, idx_un = m._batch_shuffle_ddp(x)
+        seen = bld.concat_all_gather(xs)[:, 0].long()
+        back = m._batch_unshuffle_ddp(xs, idx_un)
+        idx0 = idx_un.clone()
+        dist.broadcast(idx0, src=0)
+        ok["shuffle"] = xs.shape == x.shape and sorted(seen.tolist()) == list(range(world * nk)) and torch.equal(back, x) and torch.equal(idx0, idx_un) \
+            and seen.tolist() != list(range(world * nk))
+        q.put((rank, ok, notes, None))
+    except Exception as e:   # noqa: BLE001 - reported to the parent, which fails the test
+        import traceback
+        q.put((rank, None, None, traceback.format_exc() + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_paths():
+    """World size 8 (configs[3] / [4]; BLD:91-152,229-240): GradSync all-reduce and rs_ag in f32 and bf16 buckets with bucket sizes that do not
+    divide by 8 and per-owner joins, SyncBN's Chan combine over 8 partial statistics against float64 BatchNorm on the concatenated batch, the MoCo
+    enqueue with N_all = 8 n including the wrap, the shuffle / unshuffle permutation round trip."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + os.getpid() % 100
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    for rank, ok, notes, err in res:
+        assert err is None, f"rank {rank}: {err}"
+        assert all(ok.values()), (rank, {k: v for k, v in ok.items() if not v}, notes)
+
+
 def test_checkpoint_layouts_and_pretrained_load(tmp_path):
     """the dict layouts the drivers save (MAIN_MOCO:461-467, MAIN_SS:567-575, MAIN_CA:712-720, 1002-1011) and the
     key surgery that loads a MoCo pretraining checkpoint into a finetune backbone (MAIN_SS:326-337), on this package's modules."""

@@ -40,6 +40,19 @@ def rel_err(got, ref):
     return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
 
 
+ELEM_FLOOR = 0.05      # elementwise-relative checks: |ref| is floored at this fraction of the tensor's largest |ref|
+
+
+def elem_rel_err(got, ref, floor_frac=ELEM_FLOOR):
+    """ELEMENTWISE relative error max_i |got_i - ref_i| / max(|ref_i|, floor), floor = floor_frac x max|ref| (an element closer to zero than the
+    floor is judged against the floor: relative error of a number that cancels to ~0 is not defined by any float32 implementation either).
+    Returns (error, fraction of elements above the floor).  The scale-relative norm rel_err() is this with floor_frac = 1."""
+    ref = ref.detach().double().cpu()
+    got = got.detach().double().cpu()
+    floor = floor_frac * ref.abs().max().clamp_min(1e-30)
+    return float(((got - ref).abs() / ref.abs().clamp_min(floor)).max()), float((ref.abs() >= floor).double().mean())
+
+
 def rnd(shape, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -473,8 +486,12 @@ def test_bf16x3_ca_step_meets_the_1e3_gate():
     k = "multi_scale_transformers.0.cross_attn_layers.0.0.fn.wk.weight"
     e_f = rel_err(dict(model.named_parameters())[k].grad, fpd[k].grad)
     e_b = max(rel_err(backs[i].blocks[j].attn.qkv.weight.grad, vpd[i][f"blocks.{j}.attn.qkv.weight"].grad) for i in (0, 1) for j in (0, 11))
-    log(f"CA step[bf16x3, depth 12] logits {e_out:.2e} fusion-grad {e_f:.2e} backbone-grad {e_b:.2e} loss {float(loss):.6f} vs {float(r_loss):.6f}")
-    assert e_out < 1e-3 and e_f < 2e-3 and e_b < 2e-3
+    e_el, above = elem_rel_err(out, r_out)
+    log(f"CA step[bf16x3, depth 12] logits {e_out:.2e} (elementwise, |ref| floored at {ELEM_FLOOR} max|ref|: {e_el:.2e}, {100 * above:.0f} % of the logits above the floor) "
+        f"fusion-grad {e_f:.2e} backbone-grad {e_b:.2e} loss {float(loss):.6f} vs {float(r_loss):.6f}")
+    # forward: the north star's 1e-3, scale-relative AND elementwise; gradients: bf16x3 carries fp16-grade parts in the backward (gelu', P / dS: measured
+    # 2.2e-4 ... 5.7e-4) - asserted at 1e-3 since round 6 (2e-3 before)
+    assert e_out < 1e-3 and e_el < 1e-3 and e_f < 1e-3 and e_b < 1e-3
     assert preds.cpu().tolist() == r_preds.tolist()
     assert abs(float(loss) - float(r_loss)) < 1e-4 * max(1.0, abs(float(r_loss)))
 
@@ -521,7 +538,9 @@ def test_bf16x3_ca_step_at_the_bench_shape_against_the_oracle():
         e_b = max(e_b, rel_err(backs[i].patch_embed.proj.weight.grad, vpd[i]["patch_embed.proj.weight"].grad))
     log(f"CA step[bf16x3, depth 12, B = {B}: the bench shape] logits {e_out:.2e} fusion-grad {e_f:.2e} backbone-grads {e_b:.2e} "
         f"loss {float(loss):.6f} vs {float(r_loss):.6f}")
-    assert e_out < 1e-3 and e_f < 2e-3 and e_b < 2e-3
+    e_el, above = elem_rel_err(out, r_out)
+    log(f"  the same {B} x 3 logits ELEMENTWISE (|ref| floored at {ELEM_FLOOR} max|ref|): {e_el:.2e}, {100 * above:.0f} % of them above the floor")
+    assert e_out < 1e-3 and e_el < 1e-3 and e_f < 1e-3 and e_b < 1e-3
     assert preds.cpu().tolist() == r_preds.tolist()
     assert abs(float(loss) - float(r_loss)) < 1e-4 * max(1.0, abs(float(r_loss)))
 

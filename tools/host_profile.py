@@ -14,7 +14,6 @@ import bench  # noqa: E402
 
 args = bench.parse()
 args.batch = int(os.environ.get("HOSTPROF_B", 16))
-args.use_graph = False
 run = bench.CaRun(args, torch.device("cuda:0"), 0, "bf16x3", "T")
 for _ in range(5):
     run.step()

@@ -8,7 +8,6 @@ import bench
 from torch.profiler import profile, ProfilerActivity
 args = bench.parse() if hasattr(bench, "parse") else None
 args.batch = int(os.environ.get("CENSUS_B", 16))
-args.use_graph = False
 run = bench.CaRun(args, torch.device("cuda:0"), 0, "bf16x3", "T")
 for _ in range(3):
     run.step()
