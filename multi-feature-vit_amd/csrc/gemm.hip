@@ -1209,6 +1209,7 @@ template <int REPI> static int row_by_dtype(int dtype, const GemmP& p, hipStream
 static int tn_by_dtype(int dtype, const GemmP& p, hipStream_t st) { MFVIT_BY_DTYPE(dtype, (launch_tn<TT>(p, st))) }
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st) {
+    if (gemm_nt_pp_supported(dtype, epi, p)) return gemm_nt_pp(dtype, epi, p, st);   // gemm_pp.hip: 16-bit types at large M (round 6)
     if (epi == EPI_GELU_BWD && p.cpart && p.cs0) {
         const int rc = tile_by_dtype<EPI_GELU_BWD>(dtype, p, st);
         if (rc != MFVIT_OK) return rc;

@@ -1,0 +1,389 @@
+// Tile GEMM, round 6:  C[M][N] = epi(A[M][K] W[N][K]^T)  for the 16-bit operand types (split bf16, bf16, fp16) at large M - the Linear forward / data-gradient
+// products of the ViT block that gemm.hip::gemm_nt_tile_kernel served alone until round 5 (timm Block: qkv, fc1 + GELU, fc2 data gradient x gelu', proj data gradient;
+// call sites of the reference: moco_pretraining/moco/model/crossvit_2vits_..._std002_sum.py:128-135 through `vits.vit_small`).
+//
+// Why a second tile kernel.  The round-5 ablation of the 128 x 128 / two-workgroups-per-CU structure (profiles/r05_gemm_format_prototype.txt) found its three phases -
+// matrix work, operand staging through registers into LDS, output stores - ADDING instead of overlapping, and every scheduling experiment on it moved nothing: the
+// launches sit at the package power cap, where time follows ENERGY, not stalls.  This kernel removes work and pairs what is left (prototype against the old structure on
+// one box: 120 -> 88 - 92 us for the fc1 shape, profiles/r06_pp_proto_*.txt):
+//   * ONE persistent 512-thread workgroup per CU walks 256 x 128 output tiles (3/4 of the L2 -> LDS bytes of 128 x 128 tiles: the W tile is shared by both halves).
+//     Waves 0-3 (group 0) own rows 0..127 of the tile, waves 4-7 (group 1) rows 128..255, each wave a 64 x 64 quadrant; every SIMD hosts one wave of each group.
+//   * operands go global -> LDS by LDS-DMA (no VGPR round trip, no ds_write_b128 - the 13-cycle-per-instruction path that set the old loop's pace) into a 3-slot ring of
+//     whole 128-byte row pieces (one 32-wide k group of a split tensor, 64 k of a plain one): A 32 KB + W 16 KB per stage, two stages in flight, counted vmcnt.  The 16-byte
+//     chunks of LDS row r sit XOR-swizzled by (r >> 1) & 7 - applied on the SOURCE address of the DMA and on the fragment reads (conflict-free ds_read_b128).
+//   * the two groups run HALF A STAGE apart ("ping-pong", MI355X_MICROARCH.md 'Two waves per SIMD'): while one group issues the 24 (split; plain: 16) MFMAs of a stage,
+//     the other reads its 16 fragments of the next stage and issues its 6 LDS-DMA pieces; two s_barrier per stage separate the phases.
+//   * the stage stream runs ACROSS tile boundaries: the next tile's first two stages are in flight during the epilogue, and the epilogue's stores stay in flight behind
+//     counted waits (they are older than the stage issued after them, so the first load phase of the next tile waits for `its stage + the stores` only).
+//   * the epilogue needs no workgroup barrier (the other group goes on with its phases): every wave turns its accumulators into whole 128-byte output lines through a
+//     PRIVATE 2 KB LDS patch - 16 rows at a time - and stores 16 bytes per lane; per-element math as in gemm.hip (bias | bias + GELU / ReLU with the saved derivative |
+//     x act' + column sums | none | bias with split-fp16 output for the attention core).
+// Synchronisation (stage g, ring slot g % 3; group 0's load phase L(g) and compute phase C(g) are the barrier intervals 2g+1 and 2g+2, group 1's 2g+2 and 2g+3):
+//   RAW  a wave waits for ITS pieces of stage g+1 (vmcnt) at the end of L(g) and then passes a barrier; stage g+1 is first read in L(g+1), i.e. after every wave of both
+//        groups has waited and passed a barrier.
+//   WAR  L(g) refills the slot of stage g-1.  Its fragment reads were issued in L(g-1) and RETIRED (lgkmcnt(0)) before the barrier that ends L(g-1) - for group 1 that is
+//        interval 2g, over before group 0's L(g) starts.
+#include "kernels.h"
+#include "prof.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+
+namespace mfvit {
+
+namespace {
+
+constexpr int PP_BM = 256, PP_BN = 128;
+constexpr int PP_SROW = 128;                                   // bytes per row and stage
+constexpr int PP_A = PP_BM * PP_SROW, PP_W = PP_BN * PP_SROW;  // 32 KB + 16 KB
+constexpr int PP_SLOT = PP_A + PP_W;
+constexpr int PP_NSLOT = 3, PP_AHEAD = 2;
+constexpr int PP_RING = PP_NSLOT * PP_SLOT;                    // 144 KB
+constexpr int PP_PATCH = 16 * 128;                             // per-wave epilogue patch: 16 rows of 128 B
+constexpr int PP_LDS = PP_RING + 8 * PP_PATCH;                 // 160 KB: the whole LDS of a CU
+constexpr int PP_NDA = 4, PP_NDW = 2, PP_NDMA = PP_NDA + PP_NDW;   // LDS-DMA instructions (1 KB = 8 rows) per wave and stage
+
+template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// 16 bytes per lane global -> LDS: source = sbase + voff (per lane), destination = LDS byte address lds_dst + 16 * lane (M0 carries the base, saved and restored)
+__device__ __forceinline__ void pp_glds16(unsigned voff, const char* sbase, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+// Epilogue operands (bias, the saved activation derivative) are fetched by inline-asm loads issued in the LAST stage's load phase and waited for by hand: a load the
+// compiler knows about would get ITS wait - a vmcnt(0) that also drains the LDS-DMA stages in flight (the compiler cannot count asm loads).  The destination registers
+// must not be touched before the wait: the issuing block is straight-line code up to pp_landed() (no branch, hence no phi copy, in between).
+typedef unsigned int pp_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pp_gload16(pp_u32x4& dst, const char* sbase, unsigned voff) { asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory"); }
+__device__ __forceinline__ void pp_gload4(float& dst, const char* sbase, unsigned voff) { asm volatile("global_load_dword %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory"); }
+__device__ __forceinline__ void pp_landed(pp_u32x4& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ void pp_landed(float& r) { asm volatile("" : "+v"(r)); }
+
+// T = sbf16 | bf16 | f16
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles) {
+    constexpr bool SPLIT = is_split<T>::value;
+    constexpr int EP = elems_per<T>::value;
+    constexpr int NMF = SPLIT ? 24 : 16;                       // MFMAs per wave and stage
+    constexpr int KPS = SPLIT ? 32 : 64;                       // logical k per stage
+    typedef typename MmaTraits<T>::frag_t frag_t;
+    typedef typename act_grad_type<T>::type AX;                // saved activation derivative: fp16 for split tensors, T otherwise (2 bytes either way)
+    typedef pp_u32x4 u32x4;
+    constexpr bool ACT = EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU;
+    constexpr bool HAS_BIAS = EPI == EPI_BIAS || ACT || EPI == EPI_BIAS_X3F16;
+    // stores of one wave's epilogue that the counted waits of the next tile's first load phase ASSUME (an undercount is safe: the wait only gets stricter)
+    constexpr int NSTORE = SPLIT ? 16 : 8;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3, wm = wq >> 1, wn = wq & 1;
+    const int ntn = p.N / PP_BN;
+    const int nst = p.K / KPS;                                 // stages per tile
+    const unsigned lda_b = (unsigned)p.lda * 2u, ldw_b = (unsigned)p.ldw * 2u;      // bytes per operand row
+    const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    const int G = gridDim.x;
+    const int my = xcd_remap(blockIdx.x, G);                   // each XCD walks a contiguous run of the tile order (n fastest: its workgroups share the A rows in L2)
+    const int ntl = my < ntiles ? (ntiles - my + G - 1) / G : 0;
+    if (ntl == 0) return;
+    const char* gA = (const char*)p.A;
+    const char* gW = (const char*)p.W;
+
+    // ---- LDS-DMA addressing: piece q of an operand = rows 8 q .. 8 q + 7; A pieces wave + 8 i, W pieces wave + 8 i.  Lane l: row l >> 3 of the piece, LDS chunk l & 7,
+    // which holds source chunk (l & 7) ^ swizzle(row)
+    unsigned va[PP_NDA], vw[PP_NDW];
+    int ld_t = 0, ld_s = 0, ld_slot = 0;                       // position of the DMA stream: tile (of this workgroup), stage, ring slot
+    auto set_tile_offsets = [&](int t) {
+        const int tile = my + t * G;
+        const int m0 = (tile / ntn) * PP_BM, n0 = (tile % ntn) * PP_BN;
+#pragma unroll
+        for (int i = 0; i < PP_NDA; ++i) {
+            const int row = 8 * (wave + 8 * i) + (lane >> 3);
+            int gm = m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;                      // rows past the end replicate row M - 1 (finite data; their outputs are identical duplicates)
+            va[i] = (unsigned)gm * lda_b + 16u * (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+        }
+#pragma unroll
+        for (int i = 0; i < PP_NDW; ++i) {
+            const int row = 8 * (wave + 8 * i) + (lane >> 3);
+            vw[i] = (unsigned)(n0 + row) * ldw_b + 16u * (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+        }
+    };
+    set_tile_offsets(0);
+    auto dma_stage = [&]() {
+        const unsigned soff = (unsigned)ld_s * PP_SROW;
+        const unsigned dst = lbase + (unsigned)ld_slot * PP_SLOT + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int i = 0; i < PP_NDA; ++i) pp_glds16(va[i], gA + soff, dst + i * 8 * 1024);
+#pragma unroll
+        for (int i = 0; i < PP_NDW; ++i) pp_glds16(vw[i], gW + soff, dst + PP_A + i * 8 * 1024);
+        ld_slot = ld_slot == PP_NSLOT - 1 ? 0 : ld_slot + 1;
+        if (++ld_s == nst) {           // next tile (past the end: the last tile again - harmless refills of free slots, and the waits keep their counts)
+            ld_s = 0;
+            if (ld_t + 1 < ntl) { ++ld_t; set_tile_offsets(ld_t); }
+        }
+    };
+    // fragment addresses inside a slot (constant per lane): chunk pair c (= k step for plain types; k step + 2 x (lo part) for split ones) at address ^ (32 c)
+    unsigned fa[2], fw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = grp * 128 + (wm * 2 + i) * 32 + (lane & 31), rw = (wn * 2 + i) * 32 + (lane & 31);
+        fa[i] = (unsigned)(ra * PP_SROW + 16 * (h ^ ((ra >> 1) & 7)));
+        fw[i] = (unsigned)(PP_A + rw * PP_SROW + 16 * (h ^ ((rw >> 1) & 7)));
+    }
+    char* patch = lds + PP_RING + wave * PP_PATCH;
+
+#pragma unroll
+    for (int d = 0; d < PP_AHEAD; ++d) dma_stage();
+    pp_wait_vm<PP_NDMA*(PP_AHEAD - 1)>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();                // group 1 runs half a stage behind
+    int slot = 0;
+    frag_t af[4][2], bf[4][2];
+    // epilogue operands, loaded in the last stage of every tile (E1 asm loads per lane)
+    constexpr int E1 = EPI == EPI_GELU_BWD ? 8 : (HAS_BIAS ? 2 : 0);
+    constexpr int KEEP = PP_NDMA * (PP_AHEAD - 1);
+    float bj[2] = {0.f, 0.f};
+    u32x4 ax[4][2];
+    for (int t = 0; t < ntl; ++t) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int tile = my + t * G;
+        const int mw = (tile / ntn) * PP_BM + grp * 128 + wm * 64;     // first row / first LOGICAL column of this wave's 64 x 64 quadrant
+        const int nw = (tile % ntn) * PP_BN + wn * 64;
+        const int c31 = lane & 31;
+        auto stage = [&](auto last_c, bool behind_epilogue) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(last_c)::value;
+            // ---- load phase (the other group computes)
+            const char* sl = lds + slot * PP_SLOT;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[c][i] = *(const frag_t*)(sl + (fa[i] ^ (32u * c)));
+                    bf[c][i] = *(const frag_t*)(sl + (fw[i] ^ (32u * c)));
+                }
+            if constexpr (LAST && EPI == EPI_GELU_BWD) {
+                // aux = act'(pre-activation) saved by the forward, [M][N] of AX: per 16-row unit 64 columns = 128 B per row, 16 bytes per lane
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        int m = mw + u * 16 + 8 * q + (lane >> 3);
+                        m = m < p.M ? m : p.M - 1;
+                        pp_gload16(ax[u][q], (const char*)p.aux, (unsigned)m * (unsigned)(p.ldaux * (long)sizeof(AX)) + (unsigned)(nw * (int)sizeof(AX) + 16 * (lane & 7)));
+                    }
+            } else if constexpr (LAST && HAS_BIAS) {
+                const char* bsrc = p.bias ? (const char*)p.bias : (const char*)p.W;     // (no bias: a load from valid memory whose result is discarded - the counts stay fixed)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pp_gload4(bj[j], bsrc, (unsigned)(nw + j * 32 + c31) * 4u);
+            }
+            dma_stage();
+            // the NEXT stage must have landed before the next load phase.  This wave's queue, oldest first: [stage + 1][epilogue operands, last stage only][stage + 2, just
+            // issued] - and behind an epilogue its stores sit between the two stages: counted, so that they stay in flight until the stage issued after them is needed
+            if constexpr (LAST) pp_wait_vm<KEEP + E1>();
+            else if (behind_epilogue) pp_wait_vm<KEEP + NSTORE>();
+            else pp_wait_vm<KEEP>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads are retired: the slot may be refilled once the barrier is passed
+            __builtin_amdgcn_s_barrier();
+            // ---- compute phase
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (SPLIT) {
+                // per 16-wide k step  acc += a_lo b_hi + a_hi b_lo + a_hi b_hi  (chunk pairs: k step ks = hi part, ks + 2 = lo part)
+#pragma unroll
+                for (int tt = 0; tt < NMF; ++tt) {
+                    const int ks = tt / 12, term = (tt % 12) >> 2, i = (tt >> 1) & 1, j = tt & 1;
+                    acc[i][j] = MmaTraits<T>::mma(af[term == 0 ? ks + 2 : ks][i], bf[term == 1 ? ks + 2 : ks][j], acc[i][j]);
+                }
+            } else {
+#pragma unroll
+                for (int tt = 0; tt < NMF; ++tt) {
+                    const int ks = tt >> 2, i = (tt >> 1) & 1, j = tt & 1;
+                    acc[i][j] = MmaTraits<T>::mma(af[ks][i], bf[ks][j], acc[i][j]);
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            slot = slot == PP_NSLOT - 1 ? 0 : slot + 1;
+        };
+        for (int s = 0; s < nst - 1; ++s) stage(std::false_type(), t > 0 && s == 0);
+        stage(std::true_type(), false);                        // (nst >= 2: the last stage is never the first behind an epilogue)
+#ifdef MFVIT_PP_JOINT_EPI
+        // EXPERIMENT: both groups run their epilogues at the same time (two waves per SIMD share the vector pipe) instead of one behind the other:
+        // group 0 waits for group 1's last compute phase here, group 1 waits for group 0's next load phase behind its epilogue
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+#endif
+
+        // ---- epilogue of this wave's 64 x 64 quadrant: no workgroup barrier (the other group goes on with its phases)
+        if constexpr (E1 > 0) {                                 // the epilogue operands have landed (the stage issued behind them stays in flight)
+            pp_wait_vm<KEEP>();
+            if constexpr (EPI == EPI_GELU_BWD) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { pp_landed(ax[u][0]); pp_landed(ax[u][1]); }
+            } else {
+                pp_landed(bj[0]); pp_landed(bj[1]);
+                if (!p.bias) bj[0] = bj[1] = 0.f;
+            }
+        }
+        // patch row of accumulator register r inside a 16-row half of a 32 x 32 tile (r and r + 1 are neighbouring rows)
+        auto prow = [&](int r) -> char* { return patch + ((r & 3) + 8 * ((r >> 2) & 1) + 4 * h) * 128; };
+        // the 16 x 128-byte patch -> global rows row0 .. row0 + 15 (clamped: duplicates of row M - 1 carry identical bytes), 16 bytes per lane.  No wait between the patch
+        // writes and these reads, nor before the next unit's writes: the LDS executes one wave's operations in order (the compiler waits for the read DATA only)
+        auto flush = [&](char* gcol, long ld_bytes, int row0, auto stream_c) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int row = 8 * q + (lane >> 3);
+                const u32x4 v = *(const u32x4*)(patch + row * 128 + 16 * (lane & 7));
+                int m = row0 + row;
+                m = m < p.M ? m : p.M - 1;
+                u32x4* gp = (u32x4*)(gcol + (long)m * ld_bytes + 16 * (lane & 7));
+                if constexpr (decltype(stream_c)::value) store16_stream(gp, v);      // system-scope streaming store: no write-allocate fetch (common.cuh)
+                else *gp = v;                                                      // qkv: the attention core reads it next - keep the lines in cache (gemm.hip, round 5)
+            }
+        };
+        if constexpr (EPI == EPI_GELU_BWD) {
+            // the aux rows (in registers since the last load phase) go through the patch, and every lane multiplies its accumulators in place; the column sums of the
+            // product (the bias gradient of the Linear in front) leave as float atomics
+            float csum[2] = {0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = u >> 1, hf = u & 1;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) *(u32x4*)(patch + (8 * q + (lane >> 3)) * 128 + 16 * (lane & 7)) = ax[u][q];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 8 * hf; r < 8 * hf + 8; ++r) {
+                        const float v = acc[i][j][r] * load_elem<AX>((const AX*)prow(r), j * 32 + c31);
+                        acc[i][j][r] = v;
+                        csum[j] += mw + i * 32 + acc_row(r, lane) < p.M ? v : 0.f;
+                    }
+            }
+            if (p.cs0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float c = csum[j] + __shfl_xor(csum[j], 32, 64);
+                    if (lane < 32) atomicAdd(p.cs0 + nw + j * 32 + lane, c);
+                }
+            }
+        }
+        const bool want_grad = p.out0 != nullptr;               // GELU / ReLU epilogues: no-grad forwards pass out0 = NULL and skip the derivative
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = u >> 1, hf = u & 1;
+            const int row0 = mw + i * 32 + hf * 16;
+            if constexpr (ACT) {
+                // out0 = act'(pre) in AX (both 32-column tiles of the quadrant: 64 x 2 B = one line per row), the activation stays in the accumulators
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 8 * hf; r < 8 * hf + 8; r += 2) {
+                        const float v0 = acc[i][j][r] + bj[j], v1 = acc[i][j][r + 1] + bj[j];
+                        float g0, g1, d0, d1;
+                        if constexpr (EPI == EPI_BIAS_GELU) {
+                            gelu_both_t<T>(v0, g0, d0);                 // one erf / exp evaluation for both outputs
+                            gelu_both_t<T>(v1, g1, d1);
+                        } else {                                       // fuseattention.py:69: nn.ReLU
+                            g0 = fmaxf(v0, 0.f); g1 = fmaxf(v1, 0.f);
+                            d0 = v0 > 0.f ? 1.f : 0.f; d1 = v1 > 0.f ? 1.f : 0.f;
+                        }
+                        acc[i][j][r] = g0;
+                        acc[i][j][r + 1] = g1;
+                        if (want_grad) store_elem_pair<AX>((AX*)prow(r), (AX*)prow(r + 1), j * 32 + c31, d0, d1);
+                    }
+                if (want_grad) flush((char*)p.out0 + (long)nw * (long)sizeof(AX), p.ldo0 * (long)sizeof(AX), row0, std::true_type());
+            }
+            void* out = ACT ? p.out1 : p.out0;
+            const long ldo_b = (ACT ? p.ldo1 : p.ldo0) * (long)sizeof(T);
+            constexpr bool STREAM = !(EPI == EPI_BIAS || EPI == EPI_BIAS_X3F16);
+            if constexpr (SPLIT) {
+                // one 32-column tile = one 128-byte line per row: [hi x 32 | lo x 32]
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                    for (int r = 8 * hf; r < 8 * hf + 8; r += 2) {
+                        const float v0 = ACT ? acc[i][j][r] : acc[i][j][r] + bj[j], v1 = ACT ? acc[i][j][r + 1] : acc[i][j][r + 1] + bj[j];
+                        if constexpr (EPI == EPI_BIAS_X3F16) store_elem_pair<sf16>((sf16*)prow(r), (sf16*)prow(r + 1), c31, v0, v1);   // the attention core's operand format
+                        else store_elem_pair<T>((T*)prow(r), (T*)prow(r + 1), c31, v0, v1);
+                    }
+                    flush((char*)out + (long)(nw + j * 32) * 4, ldo_b, row0, std::integral_constant<bool, STREAM>());
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 8 * hf; r < 8 * hf + 8; r += 2) {
+                        const float v0 = ACT ? acc[i][j][r] : acc[i][j][r] + bj[j], v1 = ACT ? acc[i][j][r + 1] : acc[i][j][r + 1] + bj[j];
+                        store_elem_pair<T>((T*)prow(r), (T*)prow(r + 1), j * 32 + c31, v0, v1);
+                    }
+                flush((char*)out + (long)nw * 2, ldo_b, row0, std::integral_constant<bool, STREAM>());
+            }
+        }
+#ifdef MFVIT_PP_JOINT_EPI
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+#endif
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    pp_wait_vm<0>();
+}
+
+template <typename T, int EPI> int launch_pp(const GemmP& p, hipStream_t st) {
+    const int ntiles = (p.N / PP_BN) * ((p.M + PP_BM - 1) / PP_BM);
+    int grid = device_cus();
+    if (grid > ntiles) grid = ntiles;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
+    ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K, 0, st);
+    MFVIT_LAUNCH((gemm_nt_pp_kernel<T, EPI>), dim3(grid), dim3(512), PP_LDS, st, p, ntiles);
+    MFVIT_CHECK_LAUNCH();
+    return MFVIT_OK;
+}
+template <typename T> int pp_by_epi(int epi, const GemmP& p, hipStream_t st) {
+    switch (epi) {
+        case EPI_BIAS: return launch_pp<T, EPI_BIAS>(p, st);
+        case EPI_BIAS_GELU: return launch_pp<T, EPI_BIAS_GELU>(p, st);
+        case EPI_GELU_BWD: return launch_pp<T, EPI_GELU_BWD>(p, st);
+        case EPI_NONE: return launch_pp<T, EPI_NONE>(p, st);
+        case EPI_BIAS_RELU: return launch_pp<T, EPI_BIAS_RELU>(p, st);
+        case EPI_BIAS_X3F16:
+            if constexpr (is_split<T>::value) return launch_pp<T, EPI_BIAS_X3F16>(p, st);
+            return MFVIT_EINVAL;
+    }
+    return MFVIT_EINVAL;
+}
+
+}  // namespace
+
+// MFVIT_PP: 1 (default) the ping-pong kernel wherever it applies, 0 never (the round-5 tile kernel everywhere); MFVIT_PP_MINROWS: smallest M it takes
+bool gemm_nt_pp_supported(int dtype, int epi, const GemmP& p) {
+    static int c_on = INT_MIN, c_min = INT_MIN;
+    if (!env_switch("MFVIT_PP", 1, c_on)) return false;
+    if (dtype != MFVIT_BF16X3 && dtype != MFVIT_BF16 && dtype != MFVIT_F16) return false;
+    if (epi == EPI_BIAS_X3F16 && dtype != MFVIT_BF16X3) return false;
+    const int kps = dtype == MFVIT_BF16X3 ? 32 : 64;
+    if (p.nb > 1 || p.M < env_switch("MFVIT_PP_MINROWS", 2048, c_min) || p.N % PP_BN || p.K % kps || p.K < 2 * kps) return false;
+    if (p.cs0 && p.cpart) return false;                         // per-tile partial column sums: the round-5 kernel's layout
+    if ((p.lda * 2) % 16 || (p.ldw * 2) % 16) return false;
+    // 32-bit byte offsets inside both operands
+    if ((unsigned long long)(p.M - 1) * p.lda * 2 + 4096 >= (1ull << 32) || (unsigned long long)(p.N - 1) * p.ldw * 2 + 4096 >= (1ull << 32)) return false;
+    if (epi == EPI_GELU_BWD && (!p.aux || (p.ldaux * 2) % 16 || (unsigned long long)(p.M - 1) * p.ldaux * 2 + (unsigned long long)p.N * 2 + 4096 >= (1ull << 32))) return false;
+    return true;
+}
+int gemm_nt_pp(int dtype, int epi, const GemmP& p, hipStream_t st) {
+    switch (dtype) {
+        case MFVIT_BF16X3: return pp_by_epi<sbf16>(epi, p, st);
+        case MFVIT_BF16: return pp_by_epi<bf16>(epi, p, st);
+        case MFVIT_F16: return pp_by_epi<f16>(epi, p, st);
+    }
+    return MFVIT_EINVAL;
+}
+
+}  // namespace mfvit

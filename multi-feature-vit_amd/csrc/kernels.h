@@ -9,6 +9,8 @@ enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_GELU_BWD = 2, EPI_NONE = 3, EPI_BIAS
 enum { REPI_RES_LN = 0, REPI_LNBWD_RES = 1 };
 
 int gemm_nt_tile(int dtype, int epi, const GemmP& p, hipStream_t st);
+bool gemm_nt_pp_supported(int dtype, int epi, const GemmP& p);     // gemm_pp.hip (round 6): persistent 256 x 128 ping-pong tile kernel, 16-bit types, large M
+int gemm_nt_pp(int dtype, int epi, const GemmP& p, hipStream_t st);
 int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st);
 bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p);   // gemm_rowp.hip: one tall row-complete tile per CU (split bf16)
 int gemm_nt_rowp(int dtype, int repi, const GemmP& p, hipStream_t st);

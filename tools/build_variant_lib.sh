@@ -6,7 +6,7 @@ R=$(cd $(dirname $0)/.. && pwd); C=$R/multi-feature-vit_amd/csrc; V=$R/multi-fea
 mkdir -p $V
 for f in $C/*.hip; do
   b=$(basename $f .hip); x=""
-  case $b in attention_mfma|attention_tiled|gemm_rowp) x="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize";; esac
+  case $b in attention_mfma|attention_tiled|gemm_rowp|gemm_pp) x="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize";; esac
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value $x "$@" -c $f -o $V/$b.o &
 done
 wait
