@@ -15,7 +15,7 @@
 //     the other reads its 16 fragments of the next stage and issues its 6 LDS-DMA pieces; two s_barrier per stage separate the phases.
 //   * the stage stream runs ACROSS tile boundaries: the next tile's first two stages are in flight during the epilogue, and the epilogue's stores stay in flight behind
 //     counted waits (they are older than the stage issued after them, so the first load phase of the next tile waits for `its stage + the stores` only).
-//   * the epilogue needs no workgroup barrier (the other group goes on with its phases): every wave turns its accumulators into whole 128-byte output lines through a
+//   * the epilogue needs no workgroup barrier INSIDE (two extra ones around it line the groups up, so that both run it at the same time): every wave turns its accumulators into whole 128-byte output lines through a
 //     PRIVATE 2 KB LDS patch - 16 rows at a time - and stores 16 bytes per lane; per-element math as in gemm.hip (bias | bias + GELU / ReLU with the saved derivative |
 //     x act' + column sums | none | bias with split-fp16 output for the attention core).
 // Synchronisation (stage g, ring slot g % 3; group 0's load phase L(g) and compute phase C(g) are the barrier intervals 2g+1 and 2g+2, group 1's 2g+2 and 2g+3):
@@ -216,13 +216,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
         };
         for (int s = 0; s < nst - 1; ++s) stage(std::false_type(), t > 0 && s == 0);
         stage(std::true_type(), false);                        // (nst >= 2: the last stage is never the first behind an epilogue)
-#ifdef MFVIT_PP_JOINT_EPI
-        // EXPERIMENT: both groups run their epilogues at the same time (two waves per SIMD share the vector pipe) instead of one behind the other:
-        // group 0 waits for group 1's last compute phase here, group 1 waits for group 0's next load phase behind its epilogue
+        // both groups run their epilogues at the SAME time (two waves per SIMD share the vector pipe: the epilogue is bound by vector issue, and one wave alone leaves
+        // most issue slots empty) instead of one behind the other: group 0 waits here for group 1's last compute phase, group 1 waits behind its epilogue for group 0's
+        // next load phase.  Same box, in the step: tile class 82.3 -> 77.0 us (profiles/r06_pp_step_ab.txt)
         if (grp == 0) __builtin_amdgcn_s_barrier();
-#endif
 
-        // ---- epilogue of this wave's 64 x 64 quadrant: no workgroup barrier (the other group goes on with its phases)
+        // ---- epilogue of this wave's 64 x 64 quadrant (no workgroup barrier inside)
         if constexpr (E1 > 0) {                                 // the epilogue operands have landed (the stage issued behind them stays in flight)
             pp_wait_vm<KEEP>();
             if constexpr (EPI == EPI_GELU_BWD) {
@@ -327,9 +326,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
                 flush((char*)out + (long)nw * 2, ldo_b, row0, std::integral_constant<bool, STREAM>());
             }
         }
-#ifdef MFVIT_PP_JOINT_EPI
         if (grp == 1) __builtin_amdgcn_s_barrier();
-#endif
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
     pp_wait_vm<0>();
