@@ -368,6 +368,13 @@ bool gemm_nt_pp_supported(int dtype, int epi, const GemmP& p) {
     const int kps = dtype == MFVIT_BF16X3 ? 32 : 64;
     if (p.nb > 1 || p.M < env_switch("MFVIT_PP_MINROWS", 2048, c_min) || p.N % PP_BN || p.K % kps || p.K < 2 * kps) return false;
     if (p.cs0 && p.cpart) return false;                         // per-tile partial column sums: the round-5 kernel's layout
+    {   // enough tiles to fill the persistent grid's rounds: 256 x 128 tiles on one workgroup per CU quantise coarsely (proj data gradient at the bench shape:
+        // 297 tiles = 2 rounds at 58 % - 35.3 us against 31.7 us of the 128 x 128 kernel on two workgroups per CU; qkv 891 tiles = 4 rounds at 87 %)
+        const int cus = device_cus();
+        const long ntiles = (long)(p.N / PP_BN) * ((p.M + PP_BM - 1) / PP_BM);
+        const long rounds = (ntiles + cus - 1) / cus;
+        if (ntiles < cus || ntiles * 100 < rounds * cus * 75) return false;
+    }
     if ((p.lda * 2) % 16 || (p.ldw * 2) % 16) return false;
     // 32-bit byte offsets inside both operands
     if ((unsigned long long)(p.M - 1) * p.lda * 2 + 4096 >= (1ull << 32) || (unsigned long long)(p.N - 1) * p.ldw * 2 + 4096 >= (1ull << 32)) return false;
