@@ -461,6 +461,8 @@ def main():
     torch.cuda.synchronize()
     solo_ms_per_step = 1e3 * (time.perf_counter() - t1) / 3
     lib.mfvit_prof_collect(solo, NCLS)
+    tags = (ctypes.c_double * 9)()
+    lib.mfvit_prof_collect_tags(tags, 3)
     lib.mfvit_prof_enable(0)
     if not args.serialize_streams:
         lib.mfvit_set_wgrad_stream(1)
@@ -507,6 +509,22 @@ def main():
             pass
         roof["serialized_pass"] = dict(note="3-step attribution pass after the timed region: one stream, no wgrad side stream",
                                        ms_per_step=round(solo_ms_per_step, 3), per_class=per)
+        # The fused multi-head self-attention figure of BASELINE.json's metric / SURVEY.md 8d (Attention.forward, model/module.py:52-64: qkv projection +
+        # softmax(q k^T) v + output projection, 292.0 MFLOP per image and layer at 224^2): here three launches - the qkv tile GEMM, the attention core, the
+        # output projection with its residual + LayerNorm epilogue - so the figure is their summed algorithmic FLOPs over their summed time, beside the
+        # core alone.  MFMA-busy % of the core from the PMC passes: profiles/pmc/.
+        if tags[1 * 3] > 0 and tags[2 * 3] > 0 and solo[4 * 4] > 0:
+            fl = tags[1 * 3 + 2] + tags[2 * 3 + 2] + solo[4 * 4 + 2]
+            ms_f = tags[1 * 3 + 1] + tags[2 * 3 + 1] + solo[4 * 4 + 1]
+            roof["fused_mhsa"] = dict(
+                note="forward MHSA = qkv projection + attention core + output projection (+ residual + LayerNorm), three launches: summed algorithmic "
+                     "FLOPs / summed time of the serialized pass",
+                parts_avg_us=dict(qkv=round(1e3 * tags[4] / tags[3], 2), core=round(1e3 * solo[4 * 4 + 1] / solo[4 * 4], 2),
+                                  proj_res_ln=round(1e3 * tags[7] / tags[6], 2)),
+                tflops=round(fl / (ms_f * 1e-3) / 1e12, 1), frac_of_mfma_peak=round(fl / (ms_f * 1e-3) / 1e12 / peak_t, 4),
+                core_only=dict(tflops=round(solo[4 * 4 + 2] / (solo[4 * 4 + 1] * 1e-3) / 1e12, 1),
+                               frac_of_mfma_peak=round(solo[4 * 4 + 2] / (solo[4 * 4 + 1] * 1e-3) / 1e12 / peak_t, 4)),
+                target="BASELINE.json: >= 60 % MFMA on the fused-attention kernel - not met; the ceiling at head_dim 32 is stated in DESIGN.md 5")
         out = dict(metric="images/sec (two-stream 224^2 vit_small MF-CA train step)", value=B * world * args.steps / dt,
                    unit="images/sec", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * dt / args.steps,
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=ARITH[args.precision], data="synthetic",

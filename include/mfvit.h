@@ -306,6 +306,10 @@ int mfvit_set_wgrad_stream(int enabled);
  * kernels run beside each other.  A hint only: results do not depend on it beyond the summation order of the weight-gradient splits. */
 int mfvit_set_stream_share(int n);
 int mfvit_prof_collect(double* out, int ncls);
+/* Sub-attribution of the records the last mfvit_prof_collect call consumed: out[tag*3 + {0 launches, 1 ms, 2 algorithmic flops}] for tag 1 = the qkv
+ * projections and tag 2 = the output projections (+ residual + LayerNorm) of the encoder FORWARD - with class attention_fwd the three parts of the
+ * fused multi-head self-attention figure BASELINE.json's metric names (Attention.forward, moco_pretraining/moco/model/module.py:52-64). */
+int mfvit_prof_collect_tags(double* out, int ntags);
 const char* mfvit_prof_class_name(int cls);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 // every launch goes to the caller's stream, all memory (parameters, shadows, workspace) is caller-owned.
 #include "../../include/mfvit.h"
 #include "kernels.h"
+#include "prof.h"
 
 #include <atomic>
 #include <stdlib.h>
@@ -410,6 +411,7 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
             p.M = d.M; p.N = 3 * d.D; p.K = d.D;
             p.bias = pb + L.qkv_b;
             p.out0 = b + W.qkv; p.ldo0 = 3 * D * e;
+            ProfTag tag(PROF_TAG_MHSA_QKV);
             MFVIT_TRY(gemm_nt_tile(d.dtype, qdt == MFVIT_X3F16 ? EPI_BIAS_X3F16 : EPI_BIAS, p, st));
         }
         if (d.p_attn > 0.f) {
@@ -449,6 +451,7 @@ static int encoder_forward(const mfvit_vit_cfg* cfg, const float* params, const 
                                       p.gamma, p.beta, eps, p.mean, p.rstd, d.M, st));
             } else {
                 p.kpart = (float*)(ws + W.kpart);
+                ProfTag tag(PROF_TAG_MHSA_PROJ);
                 MFVIT_TRY(gemm_nt_row(d.dtype, REPI_RES_LN, p, st));
             }
         }

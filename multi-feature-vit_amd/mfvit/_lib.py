@@ -96,6 +96,7 @@ SIGNATURES = {
     "mfvit_set_wgrad_stream": (I, [I]),
     "mfvit_set_stream_share": (I, [I]),
     "mfvit_prof_collect": (I, [POINTER(ctypes.c_double), I]),
+    "mfvit_prof_collect_tags": (I, [POINTER(ctypes.c_double), I]),
     "mfvit_prof_class_name": (c_char_p, [I]),
     "mfvit_fusion_backward": (I, [POINTER(FusionCfg), P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
 }

@@ -53,7 +53,8 @@ __device__ __forceinline__ void glds16(unsigned voff, const char* sbase, unsigne
 // ABL (timing only): 1 no MFMAs, 2 no LDS-DMA after the prologue, 4 no epilogue, 8 no fragment reads after the first stage
 // NC: LDS-DMA pieces of a stage issued inside the COMPUTE phase (between its MFMAs) instead of the load phase
 // PRIO: 1 s_setprio 1 around the MFMAs (default), 0 none, 2 around the load phase, 3 static: waves 4 - 7 at priority 1;  DFIRST: LDS-DMA pieces before the fragment reads
-template <bool FULL, int ABL, int NC = 0, int PRIO = 1, bool DFIRST = false>
+// M16 (whole-group stages only): v_mfma_f32_16x16x32_bf16 (one k group = one MFMA K; 48 per stage at 16 cycles) instead of 32x32x16 (24 at 32 cycles)
+template <bool FULL, int ABL, int NC = 0, int PRIO = 1, bool DFIRST = false, bool M16 = false>
 __global__ __launch_bounds__(512, 1) void gemm_pp(const char* __restrict__ A, const char* __restrict__ W, float* __restrict__ C, int M, int N, int K, int ntiles) {
     typedef Geo<FULL> G_;
     constexpr int SROW = G_::SROW, A_BYTES = G_::A_BYTES, SLOT = G_::SLOT, NSLOT = G_::NSLOT, AHEAD = G_::AHEAD, NDMA = G_::NDMA, KS = G_::KS;
@@ -125,6 +126,16 @@ __global__ __launch_bounds__(512, 1) void gemm_pp(const char* __restrict__ A, co
         fa[i] = (unsigned)(ra * SROW + 16 * (h ^ swz(ra)));
         fw[i] = (unsigned)(A_BYTES + rw * SROW + 16 * (h ^ swz(rw)));
     }
+    // 16 x 16 x 32: lane = (row lane & 15, k quarter lane >> 4); hi part = chunk kq, lo part = chunk 4 + kq (address ^ 64); four 16-row tiles per wave and operand
+    unsigned ga[4], gw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = grp * 128 + wm * 64 + i * 16 + (lane & 15), rw = wn * 64 + i * 16 + (lane & 15);
+        ga[i] = (unsigned)(ra * SROW + 16 * ((lane >> 4) ^ swz(ra)));
+        gw[i] = (unsigned)(A_BYTES + rw * SROW + 16 * ((lane >> 4) ^ swz(rw)));
+    }
+    bf16x8 a16[2][4], b16[2][4];
+    f32x4 c16[4][4];
     constexpr unsigned LO = FULL ? 64u : 32u;
     char* epi = lds + G_::RING + wave * G_::EPI_ROWS * 128;
 
@@ -156,6 +167,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp(const char* __restrict__ A, co
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        if (M16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         for (int s = 0; s < nst; ++s) {
             // ---- load phase (the other group computes)
             const char* sl = lds + slot * SLOT;
@@ -165,7 +182,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp(const char* __restrict__ A, co
 #pragma unroll
                 for (int q = 0; q < NDMA - NC; ++q) dma_piece(q);
             }
-            if (!(ABL & 8) || (t == 0 && s == 0)) {
+            if (M16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a16[0][i] = *(const bf16x8*)(sl + ga[i]);
+                    a16[1][i] = *(const bf16x8*)(sl + (ga[i] ^ 64u));
+                    b16[0][i] = *(const bf16x8*)(sl + gw[i]);
+                    b16[1][i] = *(const bf16x8*)(sl + (gw[i] ^ 64u));
+                }
+            } else if (!(ABL & 8) || (t == 0 && s == 0)) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -192,7 +217,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp(const char* __restrict__ A, co
             if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---- compute phase
-            if (!(ABL & 1)) {
+            if (M16) {
+                if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int tt = 0; tt < 48; ++tt) {
+                    const int term = tt >> 4, i = (tt >> 2) & 3, j = tt & 3;
+                    c16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a16[term == 0 ? 1 : 0][i], b16[term == 1 ? 1 : 0][j], c16[i][j], 0, 0, 0);
+                }
+                if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            } else if (!(ABL & 1)) {
                 if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int tt = 0; tt < NMF; ++tt) {
@@ -222,7 +255,29 @@ __global__ __launch_bounds__(512, 1) void gemm_pp(const char* __restrict__ A, co
             slot = slot == NSLOT - 1 ? 0 : slot + 1;
         }
         // ---- epilogue (no workgroup barrier inside: the other group goes on with its phases); EPI_ROWS rows of a 32 x 32 accumulator tile at a time
-        if (!(ABL & 4)) {
+        if (M16 && !(ABL & 4)) {
+            // C / D map of 16 x 16 x 32: column lane & 15, rows 4 (lane >> 4) + register.  Unit = 16 rows x 32 columns (two column tiles) through the 16 x 128-byte patch
+            const int tile = my + t * G;
+            const int m0 = (tile / ntn) * BM + grp * 128 + wm * 64, n0 = (tile % ntn) * BN + wn * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) *(float*)(epi + (4 * (lane >> 4) + r) * 128 + 4 * (jj * 16 + (lane & 15))) = c16[i][2 * jp + jj][r];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int row = 8 * q + (lane >> 3);
+                        const f32x4 v = *(const f32x4*)(epi + row * 128 + 16 * (lane & 7));
+                        int m = m0 + i * 16 + row;
+                        m = m < M ? m : M - 1;
+                        *(f32x4*)(C + (long)m * N + n0 + jp * 32 + 4 * (lane & 7)) = v;
+                    }
+                }
+        }
+        if (!M16 && !(ABL & 4)) {
             const int tile = my + t * G;
             const int m0 = (tile / ntn) * BM + grp * 128 + wm * 64, n0 = (tile % ntn) * BN + wn * 64;
             constexpr int ER = G_::EPI_ROWS, NP = 32 / ER;                  // patch rows, passes per accumulator tile
@@ -257,6 +312,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp(const char* __restrict__ A, co
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+            if (M16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum += c16[i][j][0] + c16[i][j][1] + c16[i][j][2] + c16[i][j][3];
+            }
             if (sum == 12345.678f) C[tid] = sum;
         }
     }
@@ -334,6 +395,11 @@ int main(int argc, char** argv) {
     constexpr int LH = Geo<false>::LDS_TOTAL, LF = Geo<true>::LDS_TOTAL;
     timeit(gemm_pp<false, 0>, LH, "half-group stages (12 MFMAs per phase, 5 slots): full kernel", true);
     timeit(gemm_pp<true, 0>, LF, "whole-group stages (24 MFMAs per phase, 3 slots): full kernel", true);
+    timeit(gemm_pp<true, 0, 0, 1, false, true>, LF, "whole-group stages, 16 x 16 x 32 MFMAs (48 per phase)", true);
+    timeit(gemm_pp<true, 4, 0, 1, false, true>, LF, "whole-group stages, 16 x 16 x 32 MFMAs: no epilogue", false);
+    timeit(gemm_pp<true, 4>, LF, "whole-group stages, 32 x 32 x 16 MFMAs: no epilogue", false);
+    timeit(gemm_pp<true, 0, 0, 1, false, true>, LF, "whole-group stages, 16 x 16 x 32 MFMAs again", false);
+    timeit(gemm_pp<true, 0>, LF, "whole-group stages, 32 x 32 x 16 again", false);
     timeit(gemm_pp<true, 0, 0, 0>, LF, "whole-group stages, no s_setprio", true);
     timeit(gemm_pp<true, 0, 0, 2>, LF, "whole-group stages, s_setprio 1 around the LOAD phase", true);
     timeit(gemm_pp<true, 0, 0, 3>, LF, "whole-group stages, static priority 1 for waves 4 - 7", true);
