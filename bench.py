@@ -38,6 +38,7 @@ PEAK_NOTE = {"bf16": "dense bf16 MFMA", "fp16": "dense fp16 MFMA", "fp32": "dens
 ARITH = {"bf16": "bf16", "fp16": "f16", "fp32": "f32", "bf16x3": "bf16x3 (split bf16 hi+lo operands, 3 MFMAs per product, f32 accumulate)"}
 PEAK_HBM_GBS = 8000.0
 NCLS = 10
+TRAFFIC_FILE = "r06_hbm_traffic_by_class.json"      # newest PMC traffic summary (tools/profile_bench.sh), used only when its source hash matches the tree
 
 
 def parse():
@@ -497,11 +498,11 @@ def main():
                             "are under profiles/")
         # HBM bytes per launch from the committed PMC passes: only when they were measured on THESE kernel sources at this precision
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r05_hbm_traffic_by_class.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
             if (tj.get("source_hash") == _lib.source_hash() and tj.get("precision") == args.precision and args.batch == 128
                     and args.img == 224 and name in tj["per_class"]):
                 roof["traffic"] = tj["per_class"][name]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = ("profiles/r05_hbm_traffic_by_class.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                roof["traffic_source"] = (f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                                           f"kernel sources {tj['source_hash'][:12]})")
             else:
                 roof["traffic_note"] = "committed PMC traffic was measured on other kernel sources / another precision: not reported"

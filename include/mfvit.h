@@ -48,7 +48,8 @@ typedef void* mfvit_stream_t; /* hipStream_t */
 
 /* ABI history: 3 = rounds 3 - 4.  4 (round 5, BREAKING): mfvit_linear_fwd_persistent / mfvit_linear_fwd_ws (dropped in round 4 without a
  * version bump) and mfvit_mhsa_fused_fwd are gone; MFVIT_X3F16, linear epilogue 5, mfvit_attention_qkv_dtype and mfvit_adam_step_dev are new.
- * 5 (round 6, BREAKING): mfvit_adam_step_dev is gone (the whole-step HIP graph it served was removed). */
+ * 5 (round 6, BREAKING): mfvit_adam_step_dev is gone (the whole-step HIP graph it served was removed); mfvit_vit_cfg grew `stream_share` (the per-call form of
+ * mfvit_set_stream_share); mfvit_prof_collect_tags is new. */
 int mfvit_abi_version(void);
 const char* mfvit_build_info(void);
 
@@ -80,6 +81,10 @@ typedef struct mfvit_vit_cfg {
      * 16 l + 3 = after proj, 16 l + 4 = after the MLP).  The caller draws a fresh seed per forward. */
     float p_embd, p_attn, p_resid;
     uint32_t seed_lo, seed_hi;
+    /* ---- launch-geometry hint of THIS call (round 6; ABI 5): how many independent kernel streams run side by side on the GPU while the call's kernels run
+     * (the two-stream CA model: 2).  0 = the process-wide default of mfvit_set_stream_share.  Per call and thread-local inside the library: two models in one
+     * process no longer share a setting.  Results do not depend on it beyond the summation order of the weight-gradient splits. */
+    int stream_share;
 } mfvit_vit_cfg;
 
 /* Parameter arena: one contiguous f32 buffer, tensors in timm registration order

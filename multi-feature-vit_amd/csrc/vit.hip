@@ -13,7 +13,16 @@ using namespace mfvit;
 
 namespace mfvit {
 static std::atomic<int> g_stream_share{1};
-int stream_share() { return g_stream_share.load(std::memory_order_relaxed); }
+// the hint of the encoder call this thread is inside of (mfvit_vit_cfg::stream_share), or 0: the process-wide default
+static thread_local int t_stream_share = 0;
+int stream_share() { return t_stream_share > 0 ? t_stream_share : g_stream_share.load(std::memory_order_relaxed); }
+namespace {
+struct ShareScope {
+    int prev;
+    explicit ShareScope(const mfvit_vit_cfg* cfg) : prev(t_stream_share) { if (cfg && cfg->stream_share > 0) t_stream_share = cfg->stream_share > 8 ? 8 : cfg->stream_share; }
+    ~ShareScope() { t_stream_share = prev; }
+};
+}  // namespace
 }  // namespace mfvit
 
 namespace {
@@ -811,19 +820,23 @@ extern "C" {
 
 int mfvit_vit_forward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, const float* img, void* workspace,
                       float* features, mfvit_stream_t stream) {
+    ShareScope share(cfg);
     return encoder_forward(cfg, params, shadow, img, workspace, features, stream, false);
 }
 int mfvit_vit_backward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, void* workspace, const float* dfeatures,
                        float* dparams, int stage_hi, int stage_lo, mfvit_stream_t stream) {
+    ShareScope share(cfg);
     return encoder_backward(cfg, params, shadow, workspace, dfeatures, dparams, nullptr, stage_hi, stage_lo, stream, false);
 }
 int mfvit_gpt_forward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, const float* tokens, void* workspace, float* out,
                       mfvit_stream_t stream) {
+    ShareScope share(cfg);
     return encoder_forward(cfg, params, shadow, tokens, workspace, out, stream, true);
 }
 int mfvit_gpt_backward(const mfvit_vit_cfg* cfg, const float* params, const void* shadow, void* workspace, const float* dout, float* dparams,
                        float* dtokens, mfvit_stream_t stream) {
     if (!cfg || !dtokens || !dout) return MFVIT_EINVAL;
+    ShareScope share(cfg);
     return encoder_backward(cfg, params, shadow, workspace, dout, dparams, dtokens, cfg->depth, -1, stream, true);
 }
 

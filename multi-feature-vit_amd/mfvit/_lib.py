@@ -22,7 +22,8 @@ class VitCfg(Structure):
     _fields_ = [("dtype", c_int), ("batch", c_int), ("img_h", c_int), ("img_w", c_int), ("dim", c_int), ("depth", c_int),
                 ("heads", c_int), ("mlp_dim", c_int), ("save_for_backward", c_int), ("stop_grad_conv1", c_int),
                 ("ln_eps", c_float), ("token_input", c_int), ("tokens", c_int), ("use_pos", c_int), ("act", c_int),
-                ("p_embd", c_float), ("p_attn", c_float), ("p_resid", c_float), ("seed_lo", c_uint32), ("seed_hi", c_uint32)]
+                ("p_embd", c_float), ("p_attn", c_float), ("p_resid", c_float), ("seed_lo", c_uint32), ("seed_hi", c_uint32),
+                ("stream_share", c_int)]
 
 
 class FusionCfg(Structure):

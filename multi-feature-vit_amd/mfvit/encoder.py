@@ -279,6 +279,7 @@ class VisionTransformerMoCo(nn.Module):
         c.save_for_backward = int(bool(save))
         c.stop_grad_conv1 = int(not self.patch_embed.proj.weight.requires_grad)
         c.ln_eps = 1e-6
+        c.stream_share = int(getattr(self, "_stream_share", 0))     # launch-geometry hint of the model that drives this encoder (0: the library default)
         return c
 
     def _param_version(self):

@@ -96,8 +96,11 @@ class Fus_CrossViT(nn.Module):
 
     def forward(self, vit_cxr, vit_enh, img_cxr, img_enh):
         two = bool(self._two_streams and img_enh is not None and img_enh.is_cuda)
-        if img_cxr is not None and img_cxr.is_cuda:
-            _lib.lib().mfvit_set_stream_share(2 if two else 1)     # grid-size hint for small batches: two encoders side by side (include/mfvit.h)
+        # grid-size hint for small batches - two encoders side by side - travels in the encoders' own call configuration (mfvit_vit_cfg.stream_share), not in a
+        # process-wide setting: two models in one process do not fight over it
+        for enc in (getattr(self.vit_features_cxr, "__self__", None), getattr(self.vit_features_enh, "__self__", None)):
+            if enc is not None:
+                enc._stream_share = 2 if two else 1
         if two:
             # the two encoders are independent: run the ENH stream's ~100 kernels on a second HIP stream so that its
             # MFMA phases overlap the CXR stream's HBM-bound epilogues (and vice versa); autograd replays each

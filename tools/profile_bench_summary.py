@@ -18,7 +18,7 @@ def klass(name):
     if "gemm_nt_row_kernel" in name:
         # first template argument = element type, second = the epilogue (0: residual + LayerNorm forward, 1: LayerNorm backward)
         return "gemm_nt_row_res_ln" if re.search(r"gemm_nt_row_kernelI(DF16b|DF16_|f|NS_5sbf16E)Li0E", name) or re.search(r"gemm_nt_row_kernel<[^,]+, 0,", name) else "gemm_nt_row_lnbwd"
-    if "gemm_nt_tile_kernel" in name or "gemm_nt_pers_kernel" in name:
+    if "gemm_nt_tile_kernel" in name or "gemm_nt_pp_kernel" in name:
         return "gemm_nt_tile"
     if "attn_fwd" in name:
         return "attention_fwd"
