@@ -11,8 +11,8 @@
 //   * operands go global -> LDS by LDS-DMA (no VGPR round trip, no ds_write_b128 - the 13-cycle-per-instruction path that set the old loop's pace) into a 3-slot ring of
 //     whole 128-byte row pieces (one 32-wide k group of a split tensor, 64 k of a plain one): A 32 KB + W 16 KB per stage, two stages in flight, counted vmcnt.  The 16-byte
 //     chunks of LDS row r sit XOR-swizzled by (r >> 1) & 7 - applied on the SOURCE address of the DMA and on the fragment reads (conflict-free ds_read_b128).
-//   * the two groups run HALF A STAGE apart ("ping-pong", MI355X_MICROARCH.md 'Two waves per SIMD'): while one group issues the 24 (split; plain: 16) MFMAs of a stage,
-//     the other reads its 16 fragments of the next stage and issues its 6 LDS-DMA pieces; two s_barrier per stage separate the phases.
+//   * the two groups run HALF A STAGE apart ("ping-pong", MI355X_MICROARCH.md 'Two waves per SIMD'): while one group issues the MFMAs of a stage,
+//     the other reads its 16 fragments of the next stage and issues its 6 LDS-DMA pieces (v_mfma_f32_16x16x32: 48 / 32 per stage at 16 cycles); two s_barrier per stage separate the phases.
 //   * the stage stream runs ACROSS tile boundaries: the next tile's first two stages are in flight during the epilogue, and the epilogue's stores stay in flight behind
 //     counted waits (they are older than the stage issued after them, so the first load phase of the next tile waits for `its stage + the stores` only).
 //   * the epilogue needs no workgroup barrier INSIDE (two extra ones around it line the groups up, so that both run it at the same time): every wave turns its accumulators into whole 128-byte output lines through a
@@ -63,22 +63,48 @@ __device__ __forceinline__ void pp_gload4(float& dst, const char* sbase, unsigne
 __device__ __forceinline__ void pp_landed(pp_u32x4& r) { asm volatile("" : "+v"(r)); }
 __device__ __forceinline__ void pp_landed(float& r) { asm volatile("" : "+v"(r)); }
 
+// v_mfma_f32_16x16x32 (one 128-byte row piece of a split tensor = one K step): under the package power cap this shape sustains 12 - 15 % more FLOP/s than
+// 32x32x16 at the same cycles per FLOP (MI355X_MICROARCH.md 'DVFS give-back' (7); on this loop: 87.2 -> 83.3 us for the fc1 shape, profiles/r06_pp_proto_v3_mfma_shape.txt)
+template <typename T> struct PpMma;
+template <> struct PpMma<sbf16> { static __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); } };
+template <> struct PpMma<bf16> { static __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); } };
+template <> struct PpMma<f16> { static __device__ __forceinline__ f32x4 mma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); } };
+
+// four f32 -> four 16-bit elements (8 bytes); split tensors: the hi parts and the lo parts
+template <typename E> __device__ __forceinline__ uint2 pp_pack4(f32x4 v) {
+    typedef E e4 __attribute__((ext_vector_type(4)));
+    const e4 o = __builtin_convertvector(v, e4);
+    return __builtin_bit_cast(uint2, o);
+}
+template <typename E> __device__ __forceinline__ void pp_split4(f32x4 v, uint2& hi, uint2& lo) {
+    typedef E e4 __attribute__((ext_vector_type(4)));
+    const e4 h = __builtin_convertvector(v, e4);
+    const e4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), e4);
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+
 // T = sbf16 | bf16 | f16
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles) {
     constexpr bool SPLIT = is_split<T>::value;
-    constexpr int EP = elems_per<T>::value;
-    constexpr int NMF = SPLIT ? 24 : 16;                       // MFMAs per wave and stage
+    constexpr int NMF = SPLIT ? 48 : 32;                       // MFMAs per wave and stage (16 cycles each)
     constexpr int KPS = SPLIT ? 32 : 64;                       // logical k per stage
-    typedef typename MmaTraits<T>::frag_t frag_t;
+    typedef typename Vec8<T>::type frag_t;
+    typedef typename Vec4<T>::elem E16;
     typedef typename act_grad_type<T>::type AX;                // saved activation derivative: fp16 for split tensors, T otherwise (2 bytes either way)
     typedef pp_u32x4 u32x4;
     constexpr bool ACT = EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU;
     constexpr bool HAS_BIAS = EPI == EPI_BIAS || ACT || EPI == EPI_BIAS_X3F16;
+    // Accumulator layout.  SWAP (every epilogue but x act'): MFMA operands swapped (W fragment first), so a lane owns ONE row (lane & 15) of a 16 x 16 tile and FOUR
+    // CONSECUTIVE columns 4 (lane >> 4) .. + 3 - the bias enters as the accumulators' initial value (4 registers per column tile, fetched once per tile), the 16-bit
+    // outputs leave the lane as 8-byte pieces (one ds_write_b64 per part instead of eight ds_write_b16).  Not swapped (x act' + column sums): a lane owns one COLUMN
+    // and rows 4 (lane >> 4) .. + 3, so the column sums are in-lane adds + two shuffles.
+    constexpr bool SWAP = EPI != EPI_GELU_BWD;
     // stores of one wave's epilogue that the counted waits of the next tile's first load phase ASSUME (an undercount is safe: the wait only gets stricter)
     constexpr int NSTORE = SPLIT ? 16 : 8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wq = wave & 3, wm = wq >> 1, wn = wq & 1;
     const int ntn = p.N / PP_BN;
@@ -97,19 +123,21 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
     unsigned va[PP_NDA], vw[PP_NDW];
     int ld_t = 0, ld_s = 0, ld_slot = 0;                       // position of the DMA stream: tile (of this workgroup), stage, ring slot
     auto set_tile_offsets = [&](int t) {
+        int ln = tid & 63;                                     // (laundered: the per-lane terms are recomputed once per tile instead of living in registers across the loops)
+        asm volatile("" : "+v"(ln));
         const int tile = my + t * G;
         const int m0 = (tile / ntn) * PP_BM, n0 = (tile % ntn) * PP_BN;
 #pragma unroll
         for (int i = 0; i < PP_NDA; ++i) {
-            const int row = 8 * (wave + 8 * i) + (lane >> 3);
+            const int row = 8 * (wave + 8 * i) + (ln >> 3);
             int gm = m0 + row;
             gm = gm < p.M ? gm : p.M - 1;                      // rows past the end replicate row M - 1 (finite data; their outputs are identical duplicates)
-            va[i] = (unsigned)gm * lda_b + 16u * (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+            va[i] = (unsigned)gm * lda_b + 16u * (unsigned)((ln & 7) ^ ((row >> 1) & 7));
         }
 #pragma unroll
         for (int i = 0; i < PP_NDW; ++i) {
-            const int row = 8 * (wave + 8 * i) + (lane >> 3);
-            vw[i] = (unsigned)(n0 + row) * ldw_b + 16u * (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+            const int row = 8 * (wave + 8 * i) + (ln >> 3);
+            vw[i] = (unsigned)(n0 + row) * ldw_b + 16u * (unsigned)((ln & 7) ^ ((row >> 1) & 7));
         }
     };
     set_tile_offsets(0);
@@ -126,65 +154,81 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
             if (ld_t + 1 < ntl) { ++ld_t; set_tile_offsets(ld_t); }
         }
     };
-    // fragment addresses inside a slot (constant per lane): chunk pair c (= k step for plain types; k step + 2 x (lo part) for split ones) at address ^ (32 c)
-    unsigned fa[2], fw[2];
+    // fragment addresses inside a slot (constant per lane): 16-row tile i of an operand, lane = (row lane & 15, 16-byte chunk lane >> 4); chunk + 4 (address ^ 64) is
+    // the lo part of a split tensor / the second K step of a plain one
+    unsigned fa[4], fw[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = grp * 128 + (wm * 2 + i) * 32 + (lane & 31), rw = (wn * 2 + i) * 32 + (lane & 31);
-        fa[i] = (unsigned)(ra * PP_SROW + 16 * (h ^ ((ra >> 1) & 7)));
-        fw[i] = (unsigned)(PP_A + rw * PP_SROW + 16 * (h ^ ((rw >> 1) & 7)));
+    for (int i = 0; i < 4; ++i) {
+        const int ra = grp * 128 + wm * 64 + i * 16 + l15, rw = wn * 64 + i * 16 + l15;
+        fa[i] = (unsigned)(ra * PP_SROW + 16 * (q4 ^ ((ra >> 1) & 7)));
+        fw[i] = (unsigned)(PP_A + rw * PP_SROW + 16 * (q4 ^ ((rw >> 1) & 7)));
     }
     char* patch = lds + PP_RING + wave * PP_PATCH;
 
+    // epilogue operands fetched by asm loads (E1 per lane and tile): the NEXT tile's bias (SWAP: 4 columns per column tile, the accumulators' initial value) in the
+    // last load phase of a tile, or this tile's act' rows
+    constexpr int E1 = EPI == EPI_GELU_BWD ? 8 : (HAS_BIAS ? 4 : 0);
+    constexpr int KEEP = PP_NDMA * (PP_AHEAD - 1);
+    u32x4 bn[4];                                               // bias of the tile about to start, as loaded
+    u32x4 ax[4][2];
+    auto bias_loads = [&](int t) __attribute__((always_inline)) {
+        const int tile = my + (t < ntl ? t : ntl - 1) * G;
+        const unsigned nq = (unsigned)((tile % ntn) * PP_BN + wn * 64);
+        const char* bsrc = p.bias ? (const char*)p.bias : (const char*)p.W;     // (no bias: loads from valid memory whose results are discarded - the counts stay fixed)
+        int lq = tid >> 4 & 3;
+        asm volatile("" : "+v"(lq));
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) pp_gload16(bn[jt], bsrc, (nq + jt * 16 + 4 * lq) * 4u);
+    };
+    if constexpr (SWAP && HAS_BIAS) bias_loads(0);
 #pragma unroll
     for (int d = 0; d < PP_AHEAD; ++d) dma_stage();
     pp_wait_vm<PP_NDMA*(PP_AHEAD - 1)>();
+    if constexpr (SWAP && HAS_BIAS) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) pp_landed(bn[jt]);
+    }
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();                // group 1 runs half a stage behind
     int slot = 0;
-    frag_t af[4][2], bf[4][2];
-    // epilogue operands, loaded in the last stage of every tile (E1 asm loads per lane)
-    constexpr int E1 = EPI == EPI_GELU_BWD ? 8 : (HAS_BIAS ? 2 : 0);
-    constexpr int KEEP = PP_NDMA * (PP_AHEAD - 1);
-    float bj[2] = {0.f, 0.f};
-    u32x4 ax[4][2];
+    frag_t af[2][4], bf[2][4];                                 // [part / K step][16-row tile]
     for (int t = 0; t < ntl; ++t) {
-        f32x16 acc[2][2];
+        f32x4 acc[4][4];                                       // [row tile][column tile]
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (SWAP && HAS_BIAS) acc[i][j] = p.bias ? __builtin_bit_cast(f32x4, bn[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
+                else acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         const int tile = my + t * G;
         const int mw = (tile / ntn) * PP_BM + grp * 128 + wm * 64;     // first row / first LOGICAL column of this wave's 64 x 64 quadrant
         const int nw = (tile % ntn) * PP_BN + wn * 64;
-        const int c31 = lane & 31;
         auto stage = [&](auto last_c, bool behind_epilogue) __attribute__((always_inline)) {
             constexpr bool LAST = decltype(last_c)::value;
             // ---- load phase (the other group computes)
             const char* sl = lds + slot * PP_SLOT;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[c][i] = *(const frag_t*)(sl + (fa[i] ^ (32u * c)));
-                    bf[c][i] = *(const frag_t*)(sl + (fw[i] ^ (32u * c)));
+                for (int i = 0; i < 4; ++i) {
+                    af[c][i] = *(const frag_t*)(sl + (fa[i] ^ (64u * c)));
+                    bf[c][i] = *(const frag_t*)(sl + (fw[i] ^ (64u * c)));
                 }
             if constexpr (LAST && EPI == EPI_GELU_BWD) {
-                // aux = act'(pre-activation) saved by the forward, [M][N] of AX: per 16-row unit 64 columns = 128 B per row, 16 bytes per lane
+                // aux = act'(pre-activation) saved by the forward, [M][N] of AX: per 16-row tile 64 columns = 128 B per row, 16 bytes per lane
+                int ln = tid & 63;
+                asm volatile("" : "+v"(ln));
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        int m = mw + u * 16 + 8 * q + (lane >> 3);
+                        int m = mw + u * 16 + 8 * q + (ln >> 3);
                         m = m < p.M ? m : p.M - 1;
-                        pp_gload16(ax[u][q], (const char*)p.aux, (unsigned)m * (unsigned)(p.ldaux * (long)sizeof(AX)) + (unsigned)(nw * (int)sizeof(AX) + 16 * (lane & 7)));
+                        pp_gload16(ax[u][q], (const char*)p.aux, (unsigned)m * (unsigned)(p.ldaux * (long)sizeof(AX)) + (unsigned)(nw * (int)sizeof(AX) + 16 * (ln & 7)));
                     }
-            } else if constexpr (LAST && HAS_BIAS) {
-                const char* bsrc = p.bias ? (const char*)p.bias : (const char*)p.W;     // (no bias: a load from valid memory whose result is discarded - the counts stay fixed)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) pp_gload4(bj[j], bsrc, (unsigned)(nw + j * 32 + c31) * 4u);
+            } else if constexpr (LAST && SWAP && HAS_BIAS) {
+                bias_loads(t + 1);
             }
             dma_stage();
             // the NEXT stage must have landed before the next load phase.  This wave's queue, oldest first: [stage + 1][epilogue operands, last stage only][stage + 2, just
@@ -194,21 +238,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
             else pp_wait_vm<KEEP>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragment reads are retired: the slot may be refilled once the barrier is passed
             __builtin_amdgcn_s_barrier();
-            // ---- compute phase
+            // ---- compute phase: split tensors  acc += a_lo w_hi + a_hi w_lo + a_hi w_hi  per 16 x 16 tile; plain ones the two K steps
             __builtin_amdgcn_s_setprio(1);
-            if constexpr (SPLIT) {
-                // per 16-wide k step  acc += a_lo b_hi + a_hi b_lo + a_hi b_hi  (chunk pairs: k step ks = hi part, ks + 2 = lo part)
 #pragma unroll
-                for (int tt = 0; tt < NMF; ++tt) {
-                    const int ks = tt / 12, term = (tt % 12) >> 2, i = (tt >> 1) & 1, j = tt & 1;
-                    acc[i][j] = MmaTraits<T>::mma(af[term == 0 ? ks + 2 : ks][i], bf[term == 1 ? ks + 2 : ks][j], acc[i][j]);
-                }
-            } else {
-#pragma unroll
-                for (int tt = 0; tt < NMF; ++tt) {
-                    const int ks = tt >> 2, i = (tt >> 1) & 1, j = tt & 1;
-                    acc[i][j] = MmaTraits<T>::mma(af[ks][i], bf[ks][j], acc[i][j]);
-                }
+            for (int tt = 0; tt < NMF; ++tt) {
+                const int term = tt >> 4, i = (tt >> 2) & 3, j = tt & 3;
+                const frag_t a = af[SPLIT ? (term == 0 ? 1 : 0) : term][i], w = bf[SPLIT ? (term == 1 ? 1 : 0) : term][j];
+                acc[i][j] = SWAP ? PpMma<T>::mma(w, a, acc[i][j]) : PpMma<T>::mma(a, w, acc[i][j]);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
@@ -228,19 +264,19 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { pp_landed(ax[u][0]); pp_landed(ax[u][1]); }
             } else {
-                pp_landed(bj[0]); pp_landed(bj[1]);
-                if (!p.bias) bj[0] = bj[1] = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) pp_landed(bn[jt]);
             }
         }
-        // patch row of accumulator register r inside a 16-row half of a 32 x 32 tile (r and r + 1 are neighbouring rows)
-        auto prow = [&](int r) -> char* { return patch + ((r & 3) + 8 * ((r >> 2) & 1) + 4 * h) * 128; };
         // the 16 x 128-byte patch -> global rows row0 .. row0 + 15 (clamped: duplicates of row M - 1 carry identical bytes), 16 bytes per lane.  No wait between the patch
         // writes and these reads, nor before the next unit's writes: the LDS executes one wave's operations in order (the compiler waits for the read DATA only)
         auto flush = [&](char* gcol, long ld_bytes, int row0, auto stream_c) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int row = 8 * q + (lane >> 3);
-                const u32x4 v = *(const u32x4*)(patch + row * 128 + 16 * (lane & 7));
+                // (SWAP: the 16-byte pieces of patch row r sit XOR-swizzled by r & 7 - the lanes of an 8-byte patch write are 16 ROWS of one column slot, which
+                // without the swizzle all land on the same two banks: a 16-way conflict that cost the fc1 epilogue 18 us per launch)
+                const u32x4 v = *(const u32x4*)(patch + row * 128 + 16 * (SWAP ? (lane & 7) ^ (lane >> 3) : (lane & 7)));
                 int m = row0 + row;
                 m = m < p.M ? m : p.M - 1;
                 u32x4* gp = (u32x4*)(gcol + (long)m * ld_bytes + 16 * (lane & 7));
@@ -248,82 +284,106 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
                 else *gp = v;                                                      // qkv: the attention core reads it next - keep the lines in cache (gemm.hip, round 5)
             }
         };
-        if constexpr (EPI == EPI_GELU_BWD) {
-            // the aux rows (in registers since the last load phase) go through the patch, and every lane multiplies its accumulators in place; the column sums of the
-            // product (the bias gradient of the Linear in front) leave as float atomics
-            float csum[2] = {0.f, 0.f};
+        void* out = ACT ? p.out1 : p.out0;
+        const long ldo_b = (ACT ? p.ldo1 : p.ldo0) * (long)sizeof(T);
+        constexpr bool STREAM = !(EPI == EPI_BIAS || EPI == EPI_BIAS_X3F16);
+        if constexpr (SWAP) {
+            // this lane's row of the patch; 8-byte slot s (= 4 x column tile + lane >> 4) of the row sits at s ^ 2 (row & 7): pieces of 16 bytes stay whole
+            char* prow_ = patch + l15 * 128;
+            auto pslot = [&](int s4) -> uint2* { return (uint2*)(prow_ + 8 * ((4 * s4 + q4) ^ (2 * (l15 & 7)))); };
+            const bool want_grad = p.out0 != nullptr;           // GELU / ReLU epilogues: no-grad forwards pass out0 = NULL and skip the derivative
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = u >> 1, hf = u & 1;
+            for (int i = 0; i < 4; ++i) {
+                const int row0 = mw + i * 16;
+                if constexpr (ACT) {
+                    // out0 = act'(pre) in AX (the four column tiles of the quadrant: 64 x 2 B = one line per row), the activation replaces the accumulators
 #pragma unroll
-                for (int q = 0; q < 2; ++q) *(u32x4*)(patch + (8 * q + (lane >> 3)) * 128 + 16 * (lane & 7)) = ax[u][q];
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 g, d;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = acc[i][j][r];
+                            if constexpr (EPI == EPI_BIAS_GELU) {
+                                float gg, dd;
+                                gelu_both_t<T>(v, gg, dd);      // one erf / exp evaluation for both outputs
+                                g[r] = gg; d[r] = dd;
+                            } else {                            // fuseattention.py:69: nn.ReLU
+                                g[r] = fmaxf(v, 0.f); d[r] = v > 0.f ? 1.f : 0.f;
+                            }
+                        }
+                        acc[i][j] = g;
+                        if (want_grad) *pslot(j) = pp_pack4<AX>(d);
+                    }
+                    if (want_grad) flush((char*)p.out0 + (long)nw * (long)sizeof(AX), p.ldo0 * (long)sizeof(AX), row0, std::true_type());
+                }
+                if constexpr (SPLIT) {
+                    // two column tiles = 32 columns = one 128-byte line per row: [hi x 32 | lo x 32]
 #pragma unroll
-                    for (int r = 8 * hf; r < 8 * hf + 8; ++r) {
-                        const float v = acc[i][j][r] * load_elem<AX>((const AX*)prow(r), j * 32 + c31);
+                    for (int jp = 0; jp < 2; ++jp) {
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            uint2 hi, lo;
+                            if constexpr (EPI == EPI_BIAS_X3F16) pp_split4<f16>(acc[i][2 * jp + jj], hi, lo);     // the attention core's operand format
+                            else pp_split4<E16>(acc[i][2 * jp + jj], hi, lo);
+                            *pslot(jj) = hi;
+                            *pslot(2 + jj) = lo;
+                        }
+                        flush((char*)out + (long)(nw + jp * 32) * 4, ldo_b, row0, std::integral_constant<bool, STREAM>());
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) *pslot(j) = pp_pack4<E16>(acc[i][j]);
+                    flush((char*)out + (long)nw * 2, ldo_b, row0, std::integral_constant<bool, STREAM>());
+                }
+            }
+        } else {
+            // x act' + column sums: a lane owns column 16 j + (lane & 15) and rows 4 (lane >> 4) .. + 3 of every tile.  The aux rows (in registers since the last load
+            // phase) go through the patch, every lane multiplies its accumulators in place; the column sums of the product (the bias gradient of the Linear in front)
+            // leave as float atomics
+            float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) *(u32x4*)(patch + (8 * q + (lane >> 3)) * 128 + 16 * (lane & 7)) = ax[i][q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[i][j][r] * load_elem<AX>((const AX*)(patch + (4 * q4 + r) * 128), j * 16 + l15);
                         acc[i][j][r] = v;
-                        csum[j] += mw + i * 32 + acc_row(r, lane) < p.M ? v : 0.f;
+                        csum[j] += mw + i * 16 + 4 * q4 + r < p.M ? v : 0.f;
                     }
             }
             if (p.cs0) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float c = csum[j] + __shfl_xor(csum[j], 32, 64);
-                    if (lane < 32) atomicAdd(p.cs0 + nw + j * 32 + lane, c);
+                for (int j = 0; j < 4; ++j) {
+                    float c = csum[j] + __shfl_xor(csum[j], 16, 64);
+                    c += __shfl_xor(c, 32, 64);
+                    if (lane < 16) atomicAdd(p.cs0 + nw + j * 16 + lane, c);
                 }
             }
-        }
-        const bool want_grad = p.out0 != nullptr;               // GELU / ReLU epilogues: no-grad forwards pass out0 = NULL and skip the derivative
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = u >> 1, hf = u & 1;
-            const int row0 = mw + i * 32 + hf * 16;
-            if constexpr (ACT) {
-                // out0 = act'(pre) in AX (both 32-column tiles of the quadrant: 64 x 2 B = one line per row), the activation stays in the accumulators
+            for (int i = 0; i < 4; ++i) {
+                const int row0 = mw + i * 16;
+                if constexpr (SPLIT) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int jp = 0; jp < 2; ++jp) {
 #pragma unroll
-                    for (int r = 8 * hf; r < 8 * hf + 8; r += 2) {
-                        const float v0 = acc[i][j][r] + bj[j], v1 = acc[i][j][r + 1] + bj[j];
-                        float g0, g1, d0, d1;
-                        if constexpr (EPI == EPI_BIAS_GELU) {
-                            gelu_both_t<T>(v0, g0, d0);                 // one erf / exp evaluation for both outputs
-                            gelu_both_t<T>(v1, g1, d1);
-                        } else {                                       // fuseattention.py:69: nn.ReLU
-                            g0 = fmaxf(v0, 0.f); g1 = fmaxf(v1, 0.f);
-                            d0 = v0 > 0.f ? 1.f : 0.f; d1 = v1 > 0.f ? 1.f : 0.f;
-                        }
-                        acc[i][j][r] = g0;
-                        acc[i][j][r + 1] = g1;
-                        if (want_grad) store_elem_pair<AX>((AX*)prow(r), (AX*)prow(r + 1), j * 32 + c31, d0, d1);
+                        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                            for (int r = 0; r < 4; r += 2)
+                                store_elem_pair<T>((T*)(patch + (4 * q4 + r) * 128), (T*)(patch + (4 * q4 + r + 1) * 128), jj * 16 + l15, acc[i][2 * jp + jj][r],
+                                                   acc[i][2 * jp + jj][r + 1]);
+                        flush((char*)out + (long)(nw + jp * 32) * 4, ldo_b, row0, std::integral_constant<bool, STREAM>());
                     }
-                if (want_grad) flush((char*)p.out0 + (long)nw * (long)sizeof(AX), p.ldo0 * (long)sizeof(AX), row0, std::true_type());
-            }
-            void* out = ACT ? p.out1 : p.out0;
-            const long ldo_b = (ACT ? p.ldo1 : p.ldo0) * (long)sizeof(T);
-            constexpr bool STREAM = !(EPI == EPI_BIAS || EPI == EPI_BIAS_X3F16);
-            if constexpr (SPLIT) {
-                // one 32-column tile = one 128-byte line per row: [hi x 32 | lo x 32]
+                } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 8 * hf; r < 8 * hf + 8; r += 2) {
-                        const float v0 = ACT ? acc[i][j][r] : acc[i][j][r] + bj[j], v1 = ACT ? acc[i][j][r + 1] : acc[i][j][r + 1] + bj[j];
-                        if constexpr (EPI == EPI_BIAS_X3F16) store_elem_pair<sf16>((sf16*)prow(r), (sf16*)prow(r + 1), c31, v0, v1);   // the attention core's operand format
-                        else store_elem_pair<T>((T*)prow(r), (T*)prow(r + 1), c31, v0, v1);
-                    }
-                    flush((char*)out + (long)(nw + j * 32) * 4, ldo_b, row0, std::integral_constant<bool, STREAM>());
+                        for (int r = 0; r < 4; r += 2)
+                            store_elem_pair<T>((T*)(patch + (4 * q4 + r) * 128), (T*)(patch + (4 * q4 + r + 1) * 128), j * 16 + l15, acc[i][j][r], acc[i][j][r + 1]);
+                    flush((char*)out + (long)nw * 2, ldo_b, row0, std::integral_constant<bool, STREAM>());
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 8 * hf; r < 8 * hf + 8; r += 2) {
-                        const float v0 = ACT ? acc[i][j][r] : acc[i][j][r] + bj[j], v1 = ACT ? acc[i][j][r + 1] : acc[i][j][r + 1] + bj[j];
-                        store_elem_pair<T>((T*)prow(r), (T*)prow(r + 1), j * 32 + c31, v0, v1);
-                    }
-                flush((char*)out + (long)nw * 2, ldo_b, row0, std::integral_constant<bool, STREAM>());
             }
         }
         if (grp == 1) __builtin_amdgcn_s_barrier();
@@ -359,16 +419,17 @@ template <typename T> int pp_by_epi(int epi, const GemmP& p, hipStream_t st) {
 
 }  // namespace
 
-// MFVIT_PP: 1 (default) the ping-pong kernel wherever it applies, 0 never (the round-5 tile kernel everywhere); MFVIT_PP_MINROWS: smallest M it takes
+// MFVIT_PP: 1 (default) the ping-pong kernel wherever it pays, 0 never (the round-5 tile kernel everywhere), 2 wherever it CAN run (tests); MFVIT_PP_MINROWS: smallest M it takes
 bool gemm_nt_pp_supported(int dtype, int epi, const GemmP& p) {
     static int c_on = INT_MIN, c_min = INT_MIN;
-    if (!env_switch("MFVIT_PP", 1, c_on)) return false;
+    const int on = env_switch("MFVIT_PP", 1, c_on);            // 2: wherever the kernel CAN run (tests: small shapes, few tiles)
+    if (!on) return false;
     if (dtype != MFVIT_BF16X3 && dtype != MFVIT_BF16 && dtype != MFVIT_F16) return false;
     if (epi == EPI_BIAS_X3F16 && dtype != MFVIT_BF16X3) return false;
     const int kps = dtype == MFVIT_BF16X3 ? 32 : 64;
-    if (p.nb > 1 || p.M < env_switch("MFVIT_PP_MINROWS", 2048, c_min) || p.N % PP_BN || p.K % kps || p.K < 2 * kps) return false;
+    if (p.nb > 1 || (on != 2 && p.M < env_switch("MFVIT_PP_MINROWS", 2048, c_min)) || p.M < 1 || p.N % PP_BN || p.K % kps || p.K < 2 * kps) return false;
     if (p.cs0 && p.cpart) return false;                         // per-tile partial column sums: the round-5 kernel's layout
-    {   // enough tiles to fill the persistent grid's rounds: 256 x 128 tiles on one workgroup per CU quantise coarsely (proj data gradient at the bench shape:
+    if (on != 2) {   // enough tiles to fill the persistent grid's rounds: 256 x 128 tiles on one workgroup per CU quantise coarsely (proj data gradient at the bench shape:
         // 297 tiles = 2 rounds at 58 % - 35.3 us against 31.7 us of the 128 x 128 kernel on two workgroups per CU; qkv 891 tiles = 4 rounds at 87 %)
         const int cus = device_cus();
         const long ntiles = (long)(p.N / PP_BN) * ((p.M + PP_BM - 1) / PP_BM);

@@ -64,8 +64,7 @@ def test_forward_epilogues(monkeypatch, name, split, dt, tol, tol16, M, N, K, ta
     ref0 = f.val(x) @ f.val(w).T
     ref = ref0 + b.double()
     out = {}
-    monkeypatch.setenv("MFVIT_PP_MINROWS", "256")          # (default 2,048: below it the round-5 kernel runs)
-    for pp in ("1", "0"):
+    for pp in ("2", "0"):                                  # 2: the new kernel wherever it CAN run (1, the default, leaves small M / few tiles to the round-5 kernel)
         monkeypatch.setenv("MFVIT_PP", pp)
         y = ops.linear_fwd(x, w, b, split=split)
         y0 = ops.linear_fwd(x, w, None, split=split)
@@ -75,20 +74,20 @@ def test_forward_epilogues(monkeypatch, name, split, dt, tol, tol16, M, N, K, ta
         if split:
             out[pp].append(ops.linear_fwd(x, w, b, split=True, qkv_f16=True))
         assert none is None
-    y, y0, dact, act, act2 = out["1"][:5]
+    y, y0, dact, act, act2 = out["2"][:5]
     rg = ref.clone().requires_grad_(True)
     torch.nn.functional.gelu(rg).sum().backward()
     e = dict(bias=rel(f.val(y), ref), none=rel(f.val(y0), ref0), gelu=rel(f.val(act), torch.nn.functional.gelu(ref)),
              gelu_nograd=rel(f.val(act2), torch.nn.functional.gelu(ref)), dgelu=rel(dact.double(), rg.grad))
     if split:
-        q = out["1"][5]
+        q = out["2"][5]
         assert q.dtype == torch.float16 and q.shape == y.shape
         qv = q.view(M, N // 32, 2, 32).double().sum(2).reshape(M, N)        # I32 layout: [hi x 32 | lo x 32] per 32 columns
         e["qkv_f16"] = rel(qv, ref)
     # against the round-5 kernel: the same products in the same k order - differences are summation-order roundings of the f32 accumulators
     def vals(r):
         return [f.val(r[0]), f.val(r[1]), r[2].double(), f.val(r[3]), f.val(r[4])]
-    vs_old = max(rel(a, o) for a, o in zip(vals(out["1"]), vals(out["0"])))
+    vs_old = max(rel(a, o) for a, o in zip(vals(out["2"]), vals(out["0"])))
     log(f"gemm_pp forward[{name}, M={M}, N={N}, K={K}: {tag}] " + " ".join(f"{k} {v:.2e}" for k, v in e.items()) + f"  vs round-5 kernel {vs_old:.2e}")
     assert max(e["bias"], e["none"], e["gelu"], e["gelu_nograd"]) < tol, e
     assert e["dgelu"] < (1e-3 if dact.dtype == torch.float16 else tol16), e           # the saved derivative is fp16 (split, fp16) or bf16
@@ -107,11 +106,10 @@ def test_dgrad_times_saved_derivative(monkeypatch, name, split, dt, tol, tol16, 
     ag = (torch.rand(M, N, device=DEV, generator=g) * 1.2 - 0.1).to(torch.float16 if split else dt)          # gelu' lives in [-0.13, 1.13]
     ref = (f.val(dy) @ f.val(wt).T) * ag.double()
     res = {}
-    monkeypatch.setenv("MFVIT_PP_MINROWS", "256")
-    for pp in ("1", "0"):
+    for pp in ("2", "0"):
         monkeypatch.setenv("MFVIT_PP", pp)
         res[pp] = ops.linear_dgrad_act(dy, wt, ag, split=split)
-    e, vs_old = rel(f.val(res["1"]), ref), rel(f.val(res["1"]), f.val(res["0"]))
+    e, vs_old = rel(f.val(res["2"]), ref), rel(f.val(res["2"]), f.val(res["0"]))
     log(f"gemm_pp dgrad x act'[{name}, M={M}, N={N}, K={K}: {tag}] {e:.2e}  vs round-5 kernel {vs_old:.2e}")
     assert e < tol and vs_old < 2 * tol, (e, vs_old)
 
