@@ -70,18 +70,23 @@ template <> struct PpMma<sbf16> { static __device__ __forceinline__ f32x4 mma(bf
 template <> struct PpMma<bf16> { static __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); } };
 template <> struct PpMma<f16> { static __device__ __forceinline__ f32x4 mma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); } };
 
-// four f32 -> four 16-bit elements (8 bytes); split tensors: the hi parts and the lo parts
-template <typename E> __device__ __forceinline__ uint2 pp_pack4(f32x4 v) {
-    typedef E e4 __attribute__((ext_vector_type(4)));
-    const e4 o = __builtin_convertvector(v, e4);
-    return __builtin_bit_cast(uint2, o);
+// four f32 -> four 16-bit elements (8 bytes); split tensors: the hi parts and the lo parts.  TWO-element conversions (one packed instruction each: v_cvt_pk_bf16_f32 /
+// v_cvt_pk_f16_f32) - a four-element convertvector is lowered element by element (128 instead of 64 conversions per wave and tile in the first build)
+template <typename E> __device__ __forceinline__ unsigned pp_pk2(float a, float b) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef E e2 __attribute__((ext_vector_type(2)));
+    const f2 x = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(x, e2));
 }
+template <typename E> __device__ __forceinline__ uint2 pp_pack4(f32x4 v) { return make_uint2(pp_pk2<E>(v[0], v[1]), pp_pk2<E>(v[2], v[3])); }
 template <typename E> __device__ __forceinline__ void pp_split4(f32x4 v, uint2& hi, uint2& lo) {
-    typedef E e4 __attribute__((ext_vector_type(4)));
-    const e4 h = __builtin_convertvector(v, e4);
-    const e4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), e4);
-    hi = __builtin_bit_cast(uint2, h);
-    lo = __builtin_bit_cast(uint2, l);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef E e2 __attribute__((ext_vector_type(2)));
+    const f2 x0 = {v[0], v[1]}, x1 = {v[2], v[3]};
+    const e2 h0 = __builtin_convertvector(x0, e2), h1 = __builtin_convertvector(x1, e2);
+    const e2 l0 = __builtin_convertvector(x0 - __builtin_convertvector(h0, f2), e2), l1 = __builtin_convertvector(x1 - __builtin_convertvector(h1, f2), e2);
+    hi = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+    lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
 }
 
 // T = sbf16 | bf16 | f16
