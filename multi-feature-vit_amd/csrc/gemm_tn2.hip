@@ -171,7 +171,9 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
     frag_t ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (E16)1.0f;
-    const bool do_cs = CS && !second && k0 == 0 && wn == 0;             // column sums of A (= bias gradient): k-tile 0, wn 0 waves (each k half its own rows)
+    // column sums of A (= bias gradient): the workgroups of k-tile 0; the two waves that hold the same A fragments (wn = 0 / 1) take one 32-row block each
+    // (round 6: until then wn = 0 summed both - a third more MFMAs on half the waves of those workgroups, and the launch waits for its slowest workgroup)
+    const bool do_cs = CS && !second && k0 == 0;
 
     // the bias-column-sum MFMAs are selected ONCE per wave (template flag), not per k-step: a branch inside the hot loop splits it
     // into basic blocks and serialises the ds_read -> MFMA pipeline (measured: 72 vs 52 us on the kernels that carry a bias sum)
@@ -233,11 +235,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
             }
             if constexpr (WITH_CS) {
                 constexpr int SET = decltype(set_tag)::value;
-#pragma unroll
-                for (int i = 0; i < NL; ++i) {
-                    bacc[i] = MmaTraits<T>::mma(fa[SET][2 * i], ones, bacc[i]);
-                    bacc[i] = MmaTraits<T>::mma(fa[SET][2 * i + 1], ones, bacc[i]);
-                }
+                // (wave-uniform select of this wave's row block: both candidates are in registers, no branch in the MFMA stream)
+                const frag_t ch = wn ? fa[SET][2] : fa[SET][0], cl = wn ? fa[SET][3] : fa[SET][1];
+                bacc[0] = MmaTraits<T>::mma(ch, ones, bacc[0]);
+                bacc[0] = MmaTraits<T>::mma(cl, ones, bacc[0]);
             }
         };
 #pragma unroll
@@ -313,13 +314,14 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
                     }
                 }
                 if constexpr (WITH_CS) {
-#pragma unroll
-                    for (int i = 0; i < NL; ++i) {
+                    {   // this wave's 32-row block (wn = 0 / 1), selected without a branch
                         if constexpr (SPLIT) {
-                            bacc[i] = MmaTraits<T>::mma(a[s & 1][2 * i], ones, bacc[i]);
-                            bacc[i] = MmaTraits<T>::mma(a[s & 1][2 * i + 1], ones, bacc[i]);
+                            const frag_t ch = wn ? a[s & 1][2] : a[s & 1][0], cl = wn ? a[s & 1][3] : a[s & 1][1];
+                            bacc[0] = MmaTraits<T>::mma(ch, ones, bacc[0]);
+                            bacc[0] = MmaTraits<T>::mma(cl, ones, bacc[0]);
                         } else {
-                            bacc[i] = MmaTraits<T>::mma(a[s & 1][i], ones, bacc[i]);
+                            const frag_t ch = wn ? a[s & 1][1] : a[s & 1][0];
+                            bacc[0] = MmaTraits<T>::mma(ch, ones, bacc[0]);
                         }
                     }
                 }
@@ -399,9 +401,7 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
     if (CS) {
         if (do_cs && (lane & 31) == 0) {
 #pragma unroll
-            for (int i = 0; i < NL; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + nw + i * 32 + acc_row(r, lane), bacc[i][r]);
+            for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + nw + wn * 32 + acc_row(r, lane), bacc[0][r]);
         }
     }
 }
