@@ -43,6 +43,9 @@ constexpr int PP_RING = PP_NSLOT * PP_SLOT;                    // 144 KB
 constexpr int PP_PATCH = 16 * 128;                             // per-wave epilogue patch: 16 rows of 128 B
 constexpr int PP_LDS = PP_RING + 8 * PP_PATCH;                 // 160 KB: the whole LDS of a CU
 constexpr int PP_NDA = 4, PP_NDW = 2, PP_NDMA = PP_NDA + PP_NDW;   // LDS-DMA instructions (1 KB = 8 rows) per wave and stage
+#ifndef PP_NC_PLAIN
+#define PP_NC_PLAIN 0                                           // plain 16-bit types: pieces of a stage issued inside the compute phase (A/B builds; 3 measured: no change)
+#endif
 
 template <int N> __device__ __forceinline__ void pp_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // 16 bytes per lane global -> LDS: source = sbase + voff (per lane), destination = LDS byte address lds_dst + 16 * lane (M0 carries the base, saved and restored)
@@ -146,18 +149,33 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
         }
     };
     set_tile_offsets(0);
-    auto dma_stage = [&]() {
-        const unsigned soff = (unsigned)ld_s * PP_SROW;
-        const unsigned dst = lbase + (unsigned)ld_slot * PP_SLOT + (unsigned)wave * 1024u;
+    // the six pieces of a stage: d = 0 .. 3 A, 4 .. 5 W.  NC of them can go out inside the COMPUTE phase, between its MFMAs (A/B builds -DPP_NC_PLAIN=n, plain 16-bit
+    // types: a stage has a third fewer MFMA cycles than a split one and the load phase with all six pieces is the longer one - three pieces moved changed NOTHING in the
+    // 16-bit configs: tile class 26.3 / 39.1 / 40.7 us either way, profiles/r06_pp_step_ab.txt 5; the split prototype had said the same)
+    constexpr int NC = PP_NC_PLAIN > 0 && !SPLIT ? PP_NC_PLAIN : 0;
+    unsigned dma_soff = 0, dma_dst = 0;
+    auto dma_piece = [&](int d) __attribute__((always_inline)) {
+        if (d < PP_NDA) pp_glds16(va[d], gA + dma_soff, dma_dst + d * 8 * 1024);
+        else pp_glds16(vw[d - PP_NDA], gW + dma_soff, dma_dst + PP_A + (d - PP_NDA) * 8 * 1024);
+    };
+    auto dma_begin = [&]() __attribute__((always_inline)) {      // the pieces of the load phase
+        dma_soff = (unsigned)ld_s * PP_SROW;
+        dma_dst = lbase + (unsigned)ld_slot * PP_SLOT + (unsigned)wave * 1024u;
 #pragma unroll
-        for (int i = 0; i < PP_NDA; ++i) pp_glds16(va[i], gA + soff, dst + i * 8 * 1024);
-#pragma unroll
-        for (int i = 0; i < PP_NDW; ++i) pp_glds16(vw[i], gW + soff, dst + PP_A + i * 8 * 1024);
+        for (int d = 0; d < PP_NDMA - NC; ++d) dma_piece(d);
+    };
+    auto dma_end = [&]() __attribute__((always_inline)) {
         ld_slot = ld_slot == PP_NSLOT - 1 ? 0 : ld_slot + 1;
         if (++ld_s == nst) {           // next tile (past the end: the last tile again - harmless refills of free slots, and the waits keep their counts)
             ld_s = 0;
             if (ld_t + 1 < ntl) { ++ld_t; set_tile_offsets(ld_t); }
         }
+    };
+    auto dma_stage = [&]() {           // a whole stage at once (prologue)
+        dma_begin();
+#pragma unroll
+        for (int d = PP_NDMA - NC; d < PP_NDMA; ++d) dma_piece(d);
+        dma_end();
     };
     // fragment addresses inside a slot (constant per lane): 16-row tile i of an operand, lane = (row lane & 15, 16-byte chunk lane >> 4); chunk + 4 (address ^ 64) is
     // the lo part of a split tensor / the second K step of a plain one
@@ -173,7 +191,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
     // epilogue operands fetched by asm loads (E1 per lane and tile): the NEXT tile's bias (SWAP: 4 columns per column tile, the accumulators' initial value) in the
     // last load phase of a tile, or this tile's act' rows
     constexpr int E1 = EPI == EPI_GELU_BWD ? 8 : (HAS_BIAS ? 4 : 0);
-    constexpr int KEEP = PP_NDMA * (PP_AHEAD - 1);
+    constexpr int KEEP = PP_NDMA * (PP_AHEAD - 1) - NC;         // pieces of the stage just (partly) issued that may stay in flight at the end of a load phase
     u32x4 bn[4];                                               // bias of the tile about to start, as loaded
     u32x4 ax[4][2];
     auto bias_loads = [&](int t) __attribute__((always_inline)) {
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
             } else if constexpr (LAST && SWAP && HAS_BIAS) {
                 bias_loads(t + 1);
             }
-            dma_stage();
+            dma_begin();
             // the NEXT stage must have landed before the next load phase.  This wave's queue, oldest first: [stage + 1][epilogue operands, last stage only][stage + 2, just
             // issued] - and behind an epilogue its stores sit between the two stages: counted, so that they stay in flight until the stage issued after them is needed
             if constexpr (LAST) pp_wait_vm<KEEP + E1>();
@@ -250,7 +268,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
                 const int term = tt >> 4, i = (tt >> 2) & 3, j = tt & 3;
                 const frag_t a = af[SPLIT ? (term == 0 ? 1 : 0) : term][i], w = bf[SPLIT ? (term == 1 ? 1 : 0) : term][j];
                 acc[i][j] = SWAP ? PpMma<T>::mma(w, a, acc[i][j]) : PpMma<T>::mma(a, w, acc[i][j]);
+                if constexpr (NC > 0) {
+                    constexpr int GAP = NMF / (NC + 1);
+                    if ((tt + 1) % GAP == 0 && (tt + 1) / GAP <= NC) { dma_piece(PP_NDMA - NC + (tt + 1) / GAP - 1); __builtin_amdgcn_sched_barrier(0); }
+                }
             }
+            dma_end();
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             slot = slot == PP_NSLOT - 1 ? 0 : slot + 1;
@@ -264,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
 
         // ---- epilogue of this wave's 64 x 64 quadrant (no workgroup barrier inside)
         if constexpr (E1 > 0) {                                 // the epilogue operands have landed (the stage issued behind them stays in flight)
-            pp_wait_vm<KEEP>();
+            pp_wait_vm<PP_NDMA*(PP_AHEAD - 1)>();
             if constexpr (EPI == EPI_GELU_BWD) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { pp_landed(ax[u][0]); pp_landed(ax[u][1]); }

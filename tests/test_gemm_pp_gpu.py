@@ -21,7 +21,9 @@ REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))
 # (name, split, torch dtype, GEMM tolerance vs float64 on the rounded operands (scale-relative), tolerance of a 2-byte output)
 MODES = [("bf16x3", True, torch.bfloat16, 3e-5, 3e-5), ("fp16", False, torch.float16, 1e-3, 1e-3), ("bf16", False, torch.bfloat16, 8e-3, 8e-3)]
 SHAPES = [(128 * 197, 1536, 384, "fc1"), (128 * 197, 1152, 384, "qkv"), (128 * 197, 384, 384, "proj dgrad"), (128 * 197 - 57, 1536, 384, "ragged M"),
-          (2048 + 40, 384, 1536, "threshold M, K = 1536"), (6 * 256 + 130, 256, 64, "12 + 2 tiles, two stages"), (64 * 197, 1152, 384, "B = 64")]
+          (2048 + 40, 384, 1536, "threshold M, K = 1536"), (6 * 256 + 130, 256, 64, "12 + 2 tiles, two stages"), (64 * 197, 1152, 384, "B = 64"),
+          (256 * 197, 1152, 384, "B = 256: seven tiles per workgroup"), (3000, 128, 384, "one column tile, fewer tiles than CUs"),
+          (128 * 197, 384, 1536, "48 stages at the bench M")]
 
 
 def log(msg):
