@@ -2,7 +2,8 @@
 compiler does not know those registers are in flight, so a register copy, spill or reuse it places between a load and the wait that
 covers it reads or clobbers garbage.  This scans the device assembly (hipcc -S) of every matching kernel linearly from its entry to its
 last MFMA, keeps the in-order queue of outstanding vector-memory operations (gfx9: loads and stores share vmcnt), retires entries at
-each `s_waitcnt vmcnt(N)`, and fails if any other instruction names a VGPR that is still the destination of an outstanding load.
+each `s_waitcnt vmcnt(N)`, and fails if any other instruction names a VGPR that is still the destination of an outstanding load (past the last MFMA the scan
+continues until no inline-asm load is in flight any more).
 Only loads issued from INLINE ASM (between the `;;#ASMSTART` / `;;#ASMEND` markers of hipcc -S) are tracked as hazards: the compiler
 counts its own loads itself, and a linear scan of a loop it generated would report them falsely; they still occupy their slot in the
 vmcnt queue, as stores do.
@@ -33,7 +34,11 @@ def check_kernel(name, lines):
     last = max((i for i, l in enumerate(lines) if l.startswith("v_mfma")), default=-1)
     queue, bad = [], []
     in_asm = False
-    for i, l in enumerate(lines[:last + 1]):
+    for i, l in enumerate(lines):
+        # past the last MFMA the scan goes on only while an inline-asm load is still in flight (gemm_pp.hip: the epilogue operands are fetched in the last load
+        # phase of a tile and waited for behind its last MFMA)
+        if i > last and not any(queue):
+            break
         if l == "#ASMSTART":
             in_asm = True
             continue
