@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -325,6 +326,196 @@ __global__ __launch_bounds__(512, 1) void gemm_pp(const char* __restrict__ A, co
     wait_vm<0>();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------------
+// Second experiment (round 6, after the first production kernel): can the EPILOGUE be hidden?  gemm_pp2 = the same main loop with
+//   HEAVY   : a GELU on every output element (the vector load of the real fc1 epilogue: ~17 instructions per element)
+//   EPIMODE : 0 both groups run the epilogue at the tile end, at the same time (what ships);
+//             2 DEFERRED: the accumulators of tile t move to a second register set and its epilogue runs in 16 pieces (4 registers of one 32 x 32 tile: 8 rows x 32
+//               columns through a 1 KB patch, one 16-byte store per lane) inside the COMPUTE phases of the first 16 stages of tile t + 1, interleaved with their
+//               MFMAs (sched_group_barrier).  Half-k-group stages only: whole-stage fragments (64 registers) + two accumulator sets (128) do not fit 256.
+__device__ __forceinline__ float gelu_heavy(float x) {
+    const float z = fabsf(x) * 0.70710678f, t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f)), e = __builtin_amdgcn_exp2f(x * x * -0.72134752f);
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f); pl = fmaf(pl, t, -0.284496736f); pl = fmaf(pl, t, 0.254829592f);
+    const float cdf = 0.5f * (1.0f + copysignf(fmaf(-pl * t, e, 1.0f), x));
+    return fmaf(x * 0.3989422804f, e, cdf) * 1e-30f + x * cdf;      // (gelu' rides along at no weight: both are computed, as in the real epilogue)
+}
+template <bool FULL, int EPIMODE, bool HEAVY>
+__global__ __launch_bounds__(512, 1) void gemm_pp2(const char* __restrict__ A, const char* __restrict__ W, float* __restrict__ C, int M, int N, int K, int ntiles) {
+    typedef Geo<FULL> G_;
+    constexpr int SROW = G_::SROW, A_BYTES = G_::A_BYTES, SLOT = G_::SLOT, NSLOT = G_::NSLOT, AHEAD = G_::AHEAD, NDMA = G_::NDMA, KS = G_::KS;
+    constexpr int NDA = NDMA * 2 / 3, NDW = NDMA / 3, RPP = 1024 / SROW, CPR = SROW / 16, NMF = 12 * KS;
+    static_assert(EPIMODE == 0 || !FULL, "deferred epilogue: half-group stages");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3, wm = wq >> 1, wn = wq & 1;
+    const int ntn = N / BN;
+    const unsigned ldb = (unsigned)K * 4u;
+    const int nst = FULL ? K / 32 : K / 16;
+    const unsigned lbase = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)lds);
+    const int G = gridDim.x;
+    const int my = (blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;
+    const int ntl = my < ntiles ? (ntiles - my + G - 1) / G : 0;
+    if (ntl == 0) return;
+    auto swz = [](int row) { return FULL ? (row >> 1) & 7 : (row >> 2) & 3; };
+    unsigned va[NDA], vw[NDW];
+    int ld_t = 0, ld_s = 0, ld_slot = 0;
+    auto set_tile_offsets = [&](int t) {
+        int ln = tid & 63;
+        asm volatile("" : "+v"(ln));
+        const int tile = my + t * G;
+        const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+#pragma unroll
+        for (int i = 0; i < NDA; ++i) {
+            const int row = RPP * (wave + 8 * i) + ln / CPR, c = (ln % CPR) ^ swz(row);
+            int gm = m0 + row;
+            gm = gm < M ? gm : M - 1;
+            va[i] = (unsigned)gm * ldb + (unsigned)(FULL ? 16 * c : (c >> 1) * 64 + (c & 1) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NDW; ++i) {
+            const int row = RPP * (wave + 8 * i) + ln / CPR, c = (ln % CPR) ^ swz(row);
+            vw[i] = (unsigned)(n0 + row) * ldb + (unsigned)(FULL ? 16 * c : (c >> 1) * 64 + (c & 1) * 16);
+        }
+    };
+    set_tile_offsets(0);
+    auto dma_stage = [&]() {
+        const unsigned soff = FULL ? (unsigned)ld_s * 128u : (unsigned)(ld_s >> 1) * 128u + (unsigned)(ld_s & 1) * 32u;
+        const unsigned dst = lbase + (unsigned)ld_slot * SLOT + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int d = 0; d < NDA; ++d) glds16(va[d], A + soff, dst + d * 8 * 1024);
+#pragma unroll
+        for (int d = 0; d < NDW; ++d) glds16(vw[d], W + soff, dst + A_BYTES + d * 8 * 1024);
+        ld_slot = ld_slot == NSLOT - 1 ? 0 : ld_slot + 1;
+        if (++ld_s == nst) { ld_s = 0; if (ld_t + 1 < ntl) { ++ld_t; set_tile_offsets(ld_t); } }
+    };
+    unsigned fa[2], fw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = grp * 128 + (wm * 2 + i) * 32 + (lane & 31), rw = (wn * 2 + i) * 32 + (lane & 31);
+        fa[i] = (unsigned)(ra * SROW + 16 * (h ^ swz(ra)));
+        fw[i] = (unsigned)(A_BYTES + rw * SROW + 16 * (h ^ swz(rw)));
+    }
+    constexpr unsigned LO = FULL ? 64u : 32u;
+    char* patch = lds + G_::RING + wave * 1024;
+#pragma unroll
+    for (int d = 0; d < AHEAD; ++d) dma_stage();
+    wait_vm<NDMA*(AHEAD - 1)>();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    bf16x8 ah[KS][2], al[KS][2], bh[KS][2], bl[KS][2];
+    f32x16 acc[2][2], accp[2][2];
+    int mp = 0, np = 0;                                    // quadrant origin of the tile whose epilogue is pending
+    // one piece: registers 4 q .. 4 q + 3 of tile (i, j) of `src` = 8 rows x 32 columns
+    auto piece = [&](auto kc, f32x16 (&src)[2][2], int m0q, int n0q) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value, i = k >> 3, j = (k >> 2) & 1, q = k & 3;
+        int ln = tid & 63;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = src[i][j][4 * q + r];
+            if (HEAVY) v = gelu_heavy(v);
+            *(float*)(patch + (r + 4 * (ln >> 5)) * 128 + 4 * (ln & 31)) = v;
+        }
+        const int row = ln >> 3;
+        const f32x4 v4 = *(const f32x4*)(patch + row * 128 + 16 * (ln & 7));
+        int m = m0q + i * 32 + 8 * q + row;
+        m = m < M ? m : M - 1;
+        *(f32x4*)(C + (long)m * N + n0q + j * 32 + 4 * (ln & 7)) = v4;
+    };
+    auto all_pieces = [&](f32x16 (&src)[2][2], int m0q, int n0q) __attribute__((always_inline)) {
+        piece(std::integral_constant<int, 0>(), src, m0q, n0q); piece(std::integral_constant<int, 1>(), src, m0q, n0q); piece(std::integral_constant<int, 2>(), src, m0q, n0q);
+        piece(std::integral_constant<int, 3>(), src, m0q, n0q); piece(std::integral_constant<int, 4>(), src, m0q, n0q); piece(std::integral_constant<int, 5>(), src, m0q, n0q);
+        piece(std::integral_constant<int, 6>(), src, m0q, n0q); piece(std::integral_constant<int, 7>(), src, m0q, n0q); piece(std::integral_constant<int, 8>(), src, m0q, n0q);
+        piece(std::integral_constant<int, 9>(), src, m0q, n0q); piece(std::integral_constant<int, 10>(), src, m0q, n0q); piece(std::integral_constant<int, 11>(), src, m0q, n0q);
+        piece(std::integral_constant<int, 12>(), src, m0q, n0q); piece(std::integral_constant<int, 13>(), src, m0q, n0q); piece(std::integral_constant<int, 14>(), src, m0q, n0q);
+        piece(std::integral_constant<int, 15>(), src, m0q, n0q);
+    };
+    constexpr int KEEP = NDMA * (AHEAD - 1);
+    for (int t = 0; t < ntl; ++t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int tile = my + t * G;
+        const int m0q = (tile / ntn) * BM + grp * 128 + wm * 64, n0q = (tile % ntn) * BN + wn * 64;
+        for (int s = 0; s < nst; ++s) {
+            const char* sl = lds + slot * SLOT;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[ks][i] = *(const bf16x8*)(sl + (fa[i] ^ (32u * ks)));
+                    al[ks][i] = *(const bf16x8*)(sl + (fa[i] ^ (32u * ks) ^ LO));
+                    bh[ks][i] = *(const bf16x8*)(sl + (fw[i] ^ (32u * ks)));
+                    bl[ks][i] = *(const bf16x8*)(sl + (fw[i] ^ (32u * ks) ^ LO));
+                }
+            dma_stage();
+            if (EPIMODE == 2) {
+                // queue, oldest first: [stage +1][store of piece s - 2][stage +2][store of piece s - 1][stage +3, just issued]   (AHEAD = 3, one store per piece)
+                const int st = t == 0 ? 0 : (s >= 1 && s <= 16 ? 1 : 0) + (s >= 2 && s <= 17 ? 1 : 0);
+                if (st == 2) wait_vm<KEEP + 2>(); else if (st == 1) wait_vm<KEEP + 1>(); else wait_vm<KEEP>();
+            } else {
+                if (t == 0 || s >= AHEAD - 1) wait_vm<KEEP>(); else wait_vm<KEEP + 16>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            auto mfmas = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int tt = 0; tt < NMF; ++tt) {
+                    const int ks = tt / 12, term = (tt % 12) >> 2, i = (tt >> 1) & 1, j = tt & 1;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 0 ? al[ks][i] : ah[ks][i], term == 1 ? bl[ks][j] : bh[ks][j], acc[i][j], 0, 0, 0);
+                }
+            };
+            if (EPIMODE == 2 && t > 0 && s < 16) {
+                auto both = [&](auto kc) __attribute__((always_inline)) {
+                    mfmas();
+                    piece(kc, accp, mp, np);
+#pragma unroll
+                    for (int n = 0; n < NMF; ++n) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, HEAVY ? 7 : 2, 0);
+                    }
+                };
+                switch (s) {
+                    case 0: both(std::integral_constant<int, 0>()); break;   case 1: both(std::integral_constant<int, 1>()); break;
+                    case 2: both(std::integral_constant<int, 2>()); break;   case 3: both(std::integral_constant<int, 3>()); break;
+                    case 4: both(std::integral_constant<int, 4>()); break;   case 5: both(std::integral_constant<int, 5>()); break;
+                    case 6: both(std::integral_constant<int, 6>()); break;   case 7: both(std::integral_constant<int, 7>()); break;
+                    case 8: both(std::integral_constant<int, 8>()); break;   case 9: both(std::integral_constant<int, 9>()); break;
+                    case 10: both(std::integral_constant<int, 10>()); break; case 11: both(std::integral_constant<int, 11>()); break;
+                    case 12: both(std::integral_constant<int, 12>()); break; case 13: both(std::integral_constant<int, 13>()); break;
+                    case 14: both(std::integral_constant<int, 14>()); break; default: both(std::integral_constant<int, 15>()); break;
+                }
+            } else {
+                __builtin_amdgcn_s_setprio(1);
+                mfmas();
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __builtin_amdgcn_s_barrier();
+            slot = slot == NSLOT - 1 ? 0 : slot + 1;
+        }
+        if (EPIMODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accp[i][j] = acc[i][j];
+            mp = m0q; np = n0q;
+        } else {
+            if (grp == 0) __builtin_amdgcn_s_barrier();      // both groups' epilogues at the same time
+            all_pieces(acc, m0q, n0q);
+            if (grp == 1) __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    if (EPIMODE == 2) all_pieces(accp, mp, np);
+    wait_vm<0>();
+}
+
 static uint16_t f2bf(float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
 static float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
 
@@ -392,6 +583,18 @@ int main(int argc, char** argv) {
         return best;
     };
     printf("M %d N %d K %d: %d tiles of 256 x 128 on %d workgroups\n", M, N, K, ntiles, grid);
+    if (argc > 4 && argv[4][0] == 'e') {           // the epilogue experiment only
+        constexpr int LH2 = Geo<false>::LDS_TOTAL, LF2 = Geo<true>::LDS_TOTAL;
+        for (int rep = 0; rep < 2; ++rep) {
+            timeit(gemm_pp2<true, 0, false>, LF2, "whole-group stages, joint epilogue, plain stores", rep == 0);
+            timeit(gemm_pp2<true, 0, true>, LF2, "whole-group stages, joint epilogue, GELU on every element", false);
+            timeit(gemm_pp2<false, 0, false>, LH2, "half-group stages, joint epilogue, plain stores", rep == 0);
+            timeit(gemm_pp2<false, 0, true>, LH2, "half-group stages, joint epilogue, GELU on every element", false);
+            timeit(gemm_pp2<false, 2, false>, LH2, "half-group stages, DEFERRED epilogue (16 pieces in the next tile's compute phases), plain", rep == 0);
+            timeit(gemm_pp2<false, 2, true>, LH2, "half-group stages, DEFERRED epilogue, GELU on every element", false);
+        }
+        return 0;
+    }
     constexpr int LH = Geo<false>::LDS_TOTAL, LF = Geo<true>::LDS_TOTAL;
     timeit(gemm_pp<false, 0>, LH, "half-group stages (12 MFMAs per phase, 5 slots): full kernel", true);
     timeit(gemm_pp<true, 0>, LF, "whole-group stages (24 MFMAs per phase, 3 slots): full kernel", true);
