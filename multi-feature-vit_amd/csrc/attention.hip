@@ -275,7 +275,7 @@ int attn_bwd_exact(int dtype, const void* qkv, const void* out, const void* dout
 bool attn_mfma_supported(int dtype, int Tn, int HDim, bool backward);
 int attn_fwd_mfma(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, hipStream_t st);
 int attn_bwd_mfma(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
-                  hipStream_t st);
+                  hipStream_t st, const unsigned* domax = nullptr);
 bool attn_tiled_supported(int dtype, int Tn, int HDim);      // attention_tiled.hip: streaming kernels, any T, head_dim 32 / 64 / 96
 int attn_fwd_tiled(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HDim, hipStream_t st);
 int attn_bwd_tiled(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int Tn, int H, int HDim,
@@ -304,9 +304,9 @@ int attn_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, i
     return attn_fwd_exact(dtype, qkv, out, lse, B, Tn, H, HDim, st);
 }
 int attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
-             int HDim, hipStream_t st) {
+             int HDim, hipStream_t st, const unsigned* domax) {
     if (dtype == MFVIT_X3F16)
-        return attn_mfma_supported(dtype, Tn, HDim, true) ? attn_bwd_mfma(dtype, qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st) : MFVIT_ENOSYS;
+        return attn_mfma_supported(dtype, Tn, HDim, true) ? attn_bwd_mfma(dtype, qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st, domax) : MFVIT_ENOSYS;
     const bool exact = force_exact() && dtype != MFVIT_BF16X3;
     if (!exact && !force_tiled() && attn_mfma_supported(dtype, Tn, HDim, true))
         return attn_bwd_mfma(dtype, qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);

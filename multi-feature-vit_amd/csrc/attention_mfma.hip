@@ -551,6 +551,17 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
             asm("v_max_f32 %0, %1, %2" : "=v"(cm) : "v"(cm), "v"(sc[15]));
             return cm;
         };
+        // The same for tile 0, whose score MFMAs are the instructions right in front of it: compiler-visible reads.  The hazard recogniser counts the
+        // MFMA -> VALU wait states (11 behind an 8-pass MFMA) for its own instructions only - inline asm gets none, and max16 here read accumulator
+        // registers the last MFMA had not written yet (round 6: a reference maximum from partial scores - the softmax stays correct for any reference,
+        // so results moved by roundings only, ~2 % of the rows, differently from run to run; found by tools/attn_fwd_det_probe.py).  In the steps the
+        // tile's last score MFMA is four or more MFMAs (>= 128 cycles) ahead of max16.
+        auto max16_first = [&](const f32x16& sc) __attribute__((always_inline)) {
+            float cm = fmaxf(sc[0], sc[1]);
+#pragma unroll
+            for (int r = 2; r < 16; ++r) cm = fmaxf(cm, sc[r]);
+            return cm;
+        };
         auto mask_tile = [&](f32x16& sc, int kt) __attribute__((always_inline)) {
             const int lim = Tn - kt * 32;                              // (uniform) valid keys of this tile
             if (lim < 32) {                                            // keys past Tn: whatever bytes the image overrun holds
@@ -720,7 +731,7 @@ __global__ __launch_bounds__(512) void attn_fwd_pp_kernel(const typename Vec4<T>
 #pragma unroll
             for (int i = 0; i < NQK; ++i) mma_i(i, kf, qf, ql, sA);
             mask_tile(sA, 0);
-            cmax = max16(sA);
+            cmax = max16_first(sA);
         }
         ATTN_STAMP(2);
         // (nt >= 4: checked by the launcher)
@@ -1149,10 +1160,11 @@ template <typename T> struct SpGeo {
 };
 
 // NT: row tiles of a pair (= computing waves): 7 (T = 193 .. 224); other lengths stay with the two-phase kernels
-template <typename T, int NT, int NPX>
+template <typename T, int NT, int NPX, bool DM = false>     // DM: the pairs' |dO| maxima come from the producer of dO (domax)
 __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>::elem* __restrict__ qkv, const typename AttnT<T>::OE* __restrict__ out,
                                                           const typename AttnT<T>::OE* __restrict__ dout, const float* __restrict__ lse,
-                                                          typename AttnT<T>::OE* __restrict__ dqkv, int Tn, int H, float scale, int npair) {
+                                                          typename AttnT<T>::OE* __restrict__ dqkv, int Tn, int H, float scale, int npair,
+                                                          const unsigned* __restrict__ domax) {
     typedef AttnT<T> A;
     typedef SpGeo<T> G;
     typedef typename A::E E;
@@ -1308,6 +1320,8 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
     // magnitude in the head of the next pair and publishes it in Mx[wave] in front of barrier X; behind X everybody (the helper too) reads the seven
     // maxima: no extra barrier, nobody waits for the late rows.  consts_x: D of query tile `wave` as above, times 2^E, and the row goes back into the
     // dO image as split FP16 of dO 2^E (same chunk positions) - every tile by the wave of the same number, the last one behind the first step barrier.
+    // Round 6: when the PRODUCER of dO hands the pairs' maxima over (domax[image * H + head], f32 bits of the largest |dO|: the proj data gradient's
+    // epilogue, gemm.hip) none of that happens - no prefetch, nothing published - and pair_scale is one scalar load per pair.
     uint4 dpf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     // (lane-derived values of these helpers come from a laundered copy of the lane id handed in by the caller: derived from `lane` itself they are
     // loop invariants, which the compiler keeps across the pair loop in scratch - and every reload is a drain of the vector-memory queue)
@@ -1315,12 +1329,14 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
 #ifdef MFVIT_SP_NOPF
         return;
 #endif
+        if constexpr (DM) return;
         const int q = wave * 32 + (lane_ & 31), qc = q < Tn ? q : Tn - 1;
         const OE* dp_ = dosrc + (long)qc * os + 16 * (lane_ >> 5);
         dpf[0] = *(const uint4*)dp_;
         dpf[1] = *(const uint4*)(dp_ + 8);
     };
     auto publish_max = [&]() __attribute__((always_inline)) {
+        if constexpr (DM) return;
         // 16 bf16 magnitudes as 15-bit integers (monotonic in |x|): packed 16-bit maxima, then the wave's maximum without touching LDS
         const unsigned w[8] = {dpf[0].x, dpf[0].y, dpf[0].z, dpf[0].w, dpf[1].x, dpf[1].y, dpf[1].z, dpf[1].w};
         unsigned m = 0;
@@ -1339,9 +1355,17 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
         const unsigned mw = max(max(r0, r1), max(r2, r3));
         if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) Mx[wave] = __builtin_bit_cast(float, mw << 16);
     };
-    auto pair_scale = [&]() __attribute__((always_inline)) {
-        const float4 m0 = *(const float4*)Mx, m1 = *(const float4*)(Mx + 4);
-        const float mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+    auto pair_scale = [&](int bid_) __attribute__((always_inline)) {
+        float mx;
+        if constexpr (DM) {
+            // the producer's maximum is of the f32 values; the prefetch path sees their hi parts (bf16, round to nearest even): round the same way, so
+            // that a maximum just below a power of two picks the same exponent on both paths
+            const unsigned u = domax[bid_];
+            mx = __builtin_bit_cast(float, (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+        } else {
+            const float4 m0 = *(const float4*)Mx, m1 = *(const float4*)(Mx + 4);
+            mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+        }
         float s_, si_;
         pow2_scale(mx, s_, si_);
         sE = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s_)));
@@ -1506,7 +1530,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
 #pragma unroll
                     for (int e = 0; e < 8; ++e)
                         if ((nt - 1) * 32 + 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3) >= Tn) ktr[nt - 1][s][part][e] = (E)0.0f;
-            if constexpr (A::X) pair_scale();                          // (the tiles' |dO| maxima were published in front of X)
+            if constexpr (A::X) pair_scale(bid);                       // (the tiles' |dO| maxima were published in front of X)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                              // Z: K / V are dead
             ATTN_SB();
@@ -1575,7 +1599,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
         };
         // head of a pair: barrier X, this wave's K / V fragments, the row constants D of query tile `wave` (O rows requested a tail ago), barrier Z
         frag_t kfB[2][2], vfB[2][2];
-        auto head = [&]() __attribute__((always_inline)) {
+        auto head = [&](int hbid) __attribute__((always_inline)) {
             if constexpr (A::X) publish_max();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             ++rnd_no;
@@ -1594,7 +1618,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             if constexpr (A::X) {
                 int lane_h = lane;
                 asm volatile("" : "+v"(lane_h));
-                pair_scale();
+                pair_scale(hbid);
                 if (wave + 1 < nt) consts_x(lane_h);
             } else {
                 if (wave + 1 < nt) consts();                               // (the last query tile's: behind the first step barrier, see the helper)
@@ -1609,7 +1633,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             v_fetch(vfB, qkv + (long)(bid0 / H) * Tn * rs + (bid0 % H) * HD * EP + 2 * hs);
             if constexpr (A::X) do_prefetch(dout + (long)(bid0 / H) * Tn * os + (bid0 % H) * HD * EP, lane);
         }
-        head();
+        head(pair_bid(0));
         for (int kp = 0; kp < npl; ++kp) {
             const int bid = pair_bid(kp);
             const int b = bid / H, h = bid % H;
@@ -1765,7 +1789,7 @@ __global__ __launch_bounds__(512) void attn_bwd_sp_kernel(const typename Vec4<T>
             }
             ATTN_STAMP(11);
             wait_vm<0>();                                                  // this wave's pieces have landed (the stores above have left)
-            if (more) head();                                          // (the pair loop is rotated: the O rows requested above die inside this iteration)
+            if (more) head(bidn);                                      // (the pair loop is rotated: the O rows requested above die inside this iteration)
         }
     };
     if (wave < 3) key_role(std::true_type{});
@@ -1837,7 +1861,7 @@ template <typename T, int NPX> int launch_fwd_t(const void* qkv, void* out, floa
     return MFVIT_OK;
 }
 template <typename T, int NPX> int launch_bwd_t(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
-                                                int H, hipStream_t st) {
+                                                int H, hipStream_t st, const unsigned* domax = nullptr) {
     typedef typename Vec4<T>::elem E;
     typedef typename AttnT<T>::OE OE;
     typedef typename AttnT<T>::OT OT;
@@ -1865,11 +1889,24 @@ template <typename T, int NPX> int launch_bwd_t(const void* qkv, const void* out
         const int b3 = SpGeo<T>::lds_bytes(Tn);
         if (env_switch("MFVIT_ATTN_BWD_SP", 1, sws) != 0 && B * H >= 2 * cus3 && nt == 7 && b3 <= 160 * 1024) {
             static PerDeviceOnce attr_sp;
-            if (attr_sp.first()) (void)hipFuncSetAttribute((const void*)attn_bwd_sp_kernel<T, 7, NPX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (attr_sp.first()) {
+                (void)hipFuncSetAttribute((const void*)attn_bwd_sp_kernel<T, 7, NPX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if constexpr (AttnT<T>::X)
+                    (void)hipFuncSetAttribute((const void*)attn_bwd_sp_kernel<T, 7, NPX, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
             {
                 ProfScope ps(PROF_ATTN_BWD, 8.0 * B * H * (double)Tn * Tn * HD, 0, st);
-                MFVIT_LAUNCH((attn_bwd_sp_kernel<T, 7, NPX>), dim3(cus3), dim3(512), b3, st, (const E*)qkv, (const OE*)out, (const OE*)dout, lse, (OE*)dqkv, Tn, H,
-                             1.0f / sqrtf((float)HD), B * H);
+                bool done = false;
+                if constexpr (AttnT<T>::X) {
+                    if (domax) {
+                        MFVIT_LAUNCH((attn_bwd_sp_kernel<T, 7, NPX, true>), dim3(cus3), dim3(512), b3, st, (const E*)qkv, (const OE*)out, (const OE*)dout, lse,
+                                     (OE*)dqkv, Tn, H, 1.0f / sqrtf((float)HD), B * H, domax);
+                        done = true;
+                    }
+                }
+                if (!done)
+                    MFVIT_LAUNCH((attn_bwd_sp_kernel<T, 7, NPX>), dim3(cus3), dim3(512), b3, st, (const E*)qkv, (const OE*)out, (const OE*)dout, lse, (OE*)dqkv,
+                                 Tn, H, 1.0f / sqrtf((float)HD), B * H, (const unsigned*)nullptr);
                 MFVIT_CHECK_LAUNCH();
             }
             return colsum();
@@ -1921,13 +1958,13 @@ int attn_fwd_mfma(int dtype, const void* qkv, void* out, float* lse, int B, int 
     return MFVIT_EINVAL;
 }
 int attn_bwd_mfma(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn, int H,
-                  hipStream_t st) {
+                  hipStream_t st, const unsigned* domax) {
     if (dtype == MFVIT_BF16) return launch_bwd_t<bf16, 2>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
     if (dtype == MFVIT_BF16X3) return launch_bwd_t<sbf16, 2>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
     if (dtype == MFVIT_F16) return launch_bwd_t<f16, 2>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
     if (dtype == MFVIT_X3F16)
-        return parts_bwd() == 1 ? launch_bwd_t<sf16, 1>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st)
-                                : launch_bwd_t<sf16, 2>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st);
+        return parts_bwd() == 1 ? launch_bwd_t<sf16, 1>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st, domax)
+                                : launch_bwd_t<sf16, 2>(qkv, out, dout, lse, dqkv, dbias, B, Tn, H, st, domax);
     return MFVIT_EINVAL;
 }
 

@@ -207,6 +207,20 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// The wave's maximum of NON-NEGATIVE values as a scalar, without LDS permutes: four DPP steps inside the rows of 16 lanes, then the four rows by readlane.
+__device__ __forceinline__ float wave_max_nonneg_dpp(float v) {
+    auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}));     // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}));     // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}));    // row_half_mirror
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>{}));    // row_mirror: every lane of a row of 16 holds the row's maximum
+    const int b = __builtin_bit_cast(int, v);
+    const int r0 = __builtin_amdgcn_readlane(b, 0), r1 = __builtin_amdgcn_readlane(b, 16), r2 = __builtin_amdgcn_readlane(b, 32), r3 = __builtin_amdgcn_readlane(b, 48);
+    const int m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;   // (bit patterns of non-negative floats order like integers)
+    return __builtin_bit_cast(float, m01 > m23 ? m01 : m23);
+}
 
 // Block-wide sum for blockDim.x == NT (multiple of 64); scratch must hold NT/64 floats. All threads get the result.
 template <int NT> __device__ __forceinline__ float block_sum(float v, float* scratch) {

@@ -221,6 +221,8 @@ struct GemmP {
     float* kpart;      // gemm_rowp with K splits: scratch for the partial accumulator tiles ([workgroup][MF * 12 * 512] floats), see gemm_rowp.hip
     unsigned* kcnt;    // ... and one arrival counter per row tile (zero between launches: the last arrival resets it)
     int rows_per_wg;   // row kernels: token rows owned by one workgroup (<= its tile height; 0 = the tile height), see launch_row
+    unsigned* omax;    // tile kernel, EPI_NONE: largest |out| per (image, head) as f32 bits, [M / omax_rows][N / omax_hd], by atomicMax onto a zeroed buffer;
+    int omax_rows, omax_hd;   // token rows per image (>= 64), columns per head (32 or 64) - the proj data gradient: the attention backward's dO scale
     // two-level batch over blockIdx.z = zo * nbi + zi (element offsets; bias/out0 only)
     int nb, nbi;
     long sAo, sAi, sWo, sWi, sOo, sOi, sBo, sBi;

@@ -125,6 +125,45 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_tile_kernel(GemmP p) {   // 2 
         }
         __syncthreads();
     }
+    if constexpr (EPI == EPI_NONE) {
+        // The proj data gradient is the attention backward's dO, and its split-fp16 core scales every (image, head) by a power of two taken from the
+        // largest |dO| of the pair (attention_mfma.hip, pow2_scale): that maximum leaves HERE, where the values are in registers - a wave owns 64 rows x
+        // two 32-column slices (one head each, or the halves of a 64-wide head), its rows belong to at most two images - instead of a prefetch of all of
+        // dO's hi parts by the consumer in front of each pair.
+        if (p.omax) {
+            const int r0 = m0 + wm * (Loop::TM * 32);
+            const int img = r0 / p.omax_rows;
+            const int mb = (img + 1) * p.omax_rows - r0;          // rows of this wave at and past mb belong to the next image (or repeat row M - 1: dropped)
+            const int nimg = p.M / p.omax_rows, nh = p.N / p.omax_hd;
+            const bool two = mb < Loop::TM * 32;                    // (wave-uniform: two of three waves lie inside one image and skip the row tests)
+#pragma unroll
+            for (int j = 0; j < Loop::TN; ++j) {
+                float mx0 = 0.f, mx1 = 0.f;
+                if (two) {
+#pragma unroll
+                    for (int i = 0; i < Loop::TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float a = fabsf(acc[i][j][r]);
+                            if (i * 32 + acc_row(r, lane) < mb) mx0 = fmaxf(mx0, a);
+                            else mx1 = fmaxf(mx1, a);
+                        }
+                    mx1 = wave_max_nonneg_dpp(mx1);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < Loop::TM; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) mx0 = fmaxf(mx0, fmaxf(fabsf(acc[i][j][r]), fabsf(acc[i][j][r + 1])));
+                }
+                mx0 = wave_max_nonneg_dpp(mx0);
+                const int head = (n0 + (wn * Loop::TN + j) * 32) / p.omax_hd;
+                if (lane == 0) {
+                    if (img < nimg) atomicMax(p.omax + img * nh + head, __builtin_bit_cast(unsigned, mx0));
+                    if (two && img + 1 < nimg) atomicMax(p.omax + (img + 1) * nh + head, __builtin_bit_cast(unsigned, mx1));
+                }
+            }
+        }
+    }
     const bool want_grad = p.out0 != nullptr;           // GELU / ReLU epilogues: no-grad forwards pass out0 = NULL and skip the derivative
     if ((EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) ? want_grad : true) {
 #pragma unroll
@@ -968,6 +1007,7 @@ template <typename T, int EPI> static int launch_tile(const GemmP& pin, hipStrea
     GemmP p = pin;
     constexpr int EP = elems_per<T>::value;
     if (p.N % 128 || p.K * EP % Loop::BK || p.M <= 0) return MFVIT_EINVAL;
+    if (p.omax && (EPI != EPI_NONE || p.omax_rows < 64 || p.M % p.omax_rows || (p.omax_hd != 32 && p.omax_hd != 64) || p.nb > 1)) return MFVIT_EINVAL;   // (a wave's 64 rows: at most two images)
     // (output tiles leave through common.cuh::store16_stream: system-scope streaming stores)
     const int nwg = (p.N / 128) * ((p.M + 127) / 128);
     constexpr int epi_bytes = 128 * (128 * (int)sizeof(T) * EP + 16);

@@ -457,6 +457,7 @@ bool gemm_nt_pp_supported(int dtype, int epi, const GemmP& p) {
     const int kps = dtype == MFVIT_BF16X3 ? 32 : 64;
     if (p.nb > 1 || (on != 2 && p.M < env_switch("MFVIT_PP_MINROWS", 2048, c_min)) || p.M < 1 || p.N % PP_BN || p.K % kps || p.K < 2 * kps) return false;
     if (p.cs0 && p.cpart) return false;                         // per-tile partial column sums: the round-5 kernel's layout
+    if (p.omax) return false;                                   // per-(image, head) output maxima: the round-5 kernel's epilogue (proj data gradient)
     if (on != 2) {   // enough tiles to fill the persistent grid's rounds: 256 x 128 tiles on one workgroup per CU quantise coarsely (proj data gradient at the bench shape:
         // 297 tiles = 2 rounds at 58 % - 35.3 us against 31.7 us of the 128 x 128 kernel on two workgroups per CU; qkv 891 tiles = 4 rounds at 87 %)
         const int cus = device_cus();

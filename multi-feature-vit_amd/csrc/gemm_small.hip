@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(GemmP p) {
 }
 
 bool plain(const GemmP& p) {
-    return !p.out1 && !p.aux && !p.res && !p.res_t && !p.orow_in && !p.gamma && !p.cs0 && !p.cs1 && !p.cs2 && !p.cpart && p.out0 && p.A && p.W;
+    return !p.out1 && !p.aux && !p.res && !p.res_t && !p.orow_in && !p.gamma && !p.cs0 && !p.cs1 && !p.cs2 && !p.cpart && !p.omax && p.out0 && p.A && p.W;
 }
 bool small_switch() { return true; }   // (round 4 A/B: 27 - 36 us -> 6 - 9 us per launch against the 128 x 128 tile kernels)
 

@@ -50,8 +50,9 @@ int attn_bwd_exact(int dtype, const void* qkv, const void* out, const void* dout
 // dtype of the qkv tensor the attention kernels want for activations of `dtype` (MFVIT_X3F16 for split bf16 where the whole-head kernels apply)
 int attn_qkv_dtype(int dtype, int Tn, int HD);
 int attn_fwd(int dtype, const void* qkv, void* out, float* lse, int B, int Tn, int H, int HD, hipStream_t st);
+// domax (optional, MFVIT_X3F16 only): the largest |dout| of every (image, head) as f32 bits, [B][H], when the producer of dout has it (GemmP::omax)
 int attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* dbias, int B, int Tn,
-             int H, int HD, hipStream_t st);
+             int H, int HD, hipStream_t st, const unsigned* domax = nullptr);
 
 int im2col16(int dtype, const float* img, void* P, int B, int H, int W, hipStream_t st);
 int ln_rows(int dtype, int N, const float* in0, long ld0, const float* in1, long ld1, int mod1, float* xout, long ldx, void* y, long ldy,

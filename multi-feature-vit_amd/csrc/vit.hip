@@ -167,6 +167,7 @@ struct WsLayout {
     size_t dtmp;                // token-input mode with residual dropout: [M][D] of the operand type (branch output before the dropout; masked dY)
     size_t kpart;               // gemm_rowp with K splits (small M): partial accumulator tiles, 264 workgroups x 7 x 12 x 512 floats (gemm_rowp.hip)
     size_t utmp;                // unfused path: [M][D] of the operand type (output of the plain tile GEMM in front of a LayerNorm / LayerNorm-backward row pass)
+    size_t domax;               // backward: the largest |d attn| of every (image, head) of every block, f32 bits [depth][B][H] (proj data gradient -> attention backward)
     size_t pp_stride;           // distance between the two ping-pong copies of gxT / gmidT / dhpre / dqkv (0 = none)
     size_t total;
 };
@@ -224,6 +225,7 @@ WsLayout ws_layout(const Dims& d) {
     W.dtmp = o; o += (d.tok && d.p_resid > 0.f) ? align256(M * D * es) : 0;
     W.kpart = o; o += d.D == 384 ? align256((size_t)264 * 7 * 12 * 512 * 4) : 0;
     W.utmp = o; o += align256(M * D * es);     // always there (1 / 200 of the workspace): the layout does not depend on which path a call takes
+    W.domax = o; o += d.save ? align256((size_t)d.depth * d.B * d.H * 4) : 0;
     W.total = o;
     return W;
 }
@@ -608,6 +610,17 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     const bool lean_grad = d.dtype == MFVIT_BF16X3 && !d.unfused;   // (the unfused row passes read the f32 residual gradient)
     auto site = [](int l, int which) { return 16u * (unsigned)l + (unsigned)which; };
     const bool rdrop = d.p_resid > 0.f;             // the bias gradients of proj / fc2 then come from the MASKED dY (wgrad column sums)
+    // The attention backward's split-fp16 core scales dO (= the proj data gradient) per (image, head) by a power of two from the pair's largest |dO|.  The
+    // GEMM that produces dO leaves those maxima behind (GemmP::omax: atomicMax of f32 bits, one slice per block, zeroed here for the blocks of this call), and
+    // the attention kernel reads ONE number per pair instead of prefetching the hi parts of all of dO's rows a pair ahead.  MFVIT_DO_MAX=0: the prefetch.
+    static int s_domax = INT_MIN;
+    const int qdt_bwd = attn_qkv_dtype(d.dtype, d.T, d.HD);
+    const bool do_max = env_switch("MFVIT_DO_MAX", 1, s_domax) != 0 && qdt_bwd == MFVIT_X3F16 && (d.HD == 32 || d.HD == 64) && d.T >= 64 && d.D % 128 == 0 && !(d.p_attn > 0.f);
+    auto domax = [&](int l) { return (unsigned*)(ws + W.domax) + (size_t)l * d.B * d.H; };
+    if (do_max) {
+        const int l0 = stage_lo > 0 ? stage_lo : 0, l1 = stage_hi < d.depth - 1 ? stage_hi : d.depth - 1;
+        if (l1 >= l0 && hipMemsetAsync(domax(l0), 0, (size_t)(l1 - l0 + 1) * d.B * d.H * 4, st) != hipSuccess) return MFVIT_ELAUNCH;
+    }
     for (int s = stage_hi; s >= stage_lo; --s) {
         if (s == d.depth) {
             // final LayerNorm backward: dfeatures -> gx (grad of x_depth); dcol = d fc2_b of the last block
@@ -721,14 +734,15 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.A = gyp; p.lda = D * e; p.W = sb + S.proj_t; p.ldw = D * e;
                 p.M = d.M; p.N = d.D; p.K = d.D;
                 p.out0 = ws + W.dattn; p.ldo0 = D * e;
+                if (do_max) { p.omax = domax(l); p.omax_rows = d.T; p.omax_hd = d.HD; }
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_NONE, p, st));
             }
             if (d.p_attn > 0.f)
                 MFVIT_TRY(attn_bwd_tiled_drop(d.dtype, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, d.B, d.T, d.H, d.HD,
                                               make_drop(d.p_attn, d.seed, site(l, 2)), st));
             else
-            MFVIT_TRY(attn_bwd(attn_qkv_dtype(d.dtype, d.T, d.HD), b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, nullptr,
-                               d.B, d.T, d.H, d.HD, st));
+            MFVIT_TRY(attn_bwd(qdt_bwd, b + W.qkv, b + W.attn, ws + W.dattn, (const float*)(b + W.lse), dqkv, nullptr,
+                               d.B, d.T, d.H, d.HD, st, do_max ? domax(l) : nullptr));
             MFVIT_TRY(fork());                                    // dqkv - and with it every input of this block's weight gradients - is ready
             for (int i = 0; i < ndef; ++i) MFVIT_TRY(gemm_tn(d.dtype, def_tn[i], wst));
             {   // dWqkv += dqkv^T y1 ; d qkv_b += column sums of dqkv (ones-fragment MFMA inside the wgrad kernel)

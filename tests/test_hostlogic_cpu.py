@@ -399,6 +399,27 @@ def test_shipped_kernels_with_asm_loads_pass_the_hazard_scan():
     ge.check_asm_load_hazards(objdir, regenerate=False)
 
 
+def test_mfma_asm_hazard_checker_flags_asm_reads_of_accumulators_in_flight(tmp_path):
+    """tools/check_mfma_asm_hazards.py (round 6; run by build() on every device-assembly file): an instruction inside an asm statement that reads an MFMA
+    destination within the MFMA's wait states is a finding - directly behind it or behind a branch; the compiler's own reads (it places the s_nops), a read
+    behind enough wait states, and a register a compiler instruction has overwritten in between are not."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_mfma_asm_hazards.py")
+    head = "_Z4kernv: ; @_Z4kernv\n\tv_mfma_f32_32x32x16_f16 v[46:61], v[0:3], v[4:7], v[46:61]\n"
+    read = "\t;;#ASMSTART\n\tv_max3_f32 v4, v46, v47, v48\n\t;;#ASMEND\n\ts_endpgm\n"
+    cases = [(head + read, 1),                                                                                    # right behind the MFMA
+             (head + "\ts_cbranch_vccnz .LBB0_2\n\tv_mov_b32_e32 v9, v8\n.LBB0_2:\n" + read, 1),               # behind a taken branch
+             (head + "\ts_nop 15\n\ts_nop 3\n" + read, 0),                                                     # 20 wait states later
+             (head + "\ts_nop 10\n\tv_max_f32_e32 v46, v46, v46\n\tv_max_f32_e32 v47, v47, v47\n\tv_max_f32_e32 v48, v48, v48\n" + read, 0),   # rewritten by the compiler
+             (head + "\ts_nop 10\n\tv_max3_f32 v4, v46, v47, v48\n\ts_endpgm\n", 0)]                          # the compiler's own read
+    for i, (text, rc) in enumerate(cases):
+        f = tmp_path / f"k{i}.s"
+        f.write_text(text)
+        r = subprocess.run([sys.executable, tool, str(f)], capture_output=True, text=True)
+        assert r.returncode == rc, (i, rc, r.stdout, r.stderr)
+
+
 def test_shipped_hot_kernels_use_no_scratch():
     """The hot split-bf16 kernels (tile GEMM, tall-tile row kernels, LDS-DMA weight gradients, persistent attention) must compile without scratch
     memory - epilogues included.  Round 5 shipped a LayerNorm-backward row kernel with 148 bytes of spills in its epilogue for most of the round
