@@ -413,6 +413,15 @@ def test_mfma_asm_hazard_checker_flags_asm_reads_of_accumulators_in_flight(tmp_p
              (head + "\ts_nop 15\n\ts_nop 3\n" + read, 0),                                                     # 20 wait states later
              (head + "\ts_nop 10\n\tv_max_f32_e32 v46, v46, v46\n\tv_max_f32_e32 v47, v47, v47\n\tv_max_f32_e32 v48, v48, v48\n" + read, 0),   # rewritten by the compiler
              (head + "\ts_nop 10\n\tv_max3_f32 v4, v46, v47, v48\n\ts_endpgm\n", 0)]                          # the compiler's own read
+    # the two neighbouring hazards: a transcendental result read by asm in the next issue slot; a VALU-written SGPR read by an asm LDS-DMA within 5 wait states
+    k = "_Z4kernv: ; @_Z4kernv\n"
+    cvt = "\t;;#ASMSTART\n\tv_cvt_pk_f16_f32 v6, v5, v7\n\t;;#ASMEND\n\ts_endpgm\n"
+    dma = "\t;;#ASMSTART\n\ts_mov_b32 s9, m0\n\ts_mov_b32 m0, s8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v2, s[4:5]\n\ts_mov_b32 m0, s9\n\t;;#ASMEND\n\ts_endpgm\n"
+    cases += [(k + "\tv_exp_f32_e32 v5, v4\n" + cvt, 1),
+              (k + "\tv_exp_f32_e32 v5, v4\n\tv_add_f32_e32 v9, v9, v5\n" + cvt, 0),
+              (k + "\tv_readfirstlane_b32 s4, v1\n\tv_readfirstlane_b32 s5, v2\n" + dma, 1),          # 3 wait states inside the statement + 1
+              (k + "\tv_readfirstlane_b32 s4, v1\n\tv_readfirstlane_b32 s5, v2\n\ts_nop 1\n" + dma, 0),
+              (k + "\tv_readfirstlane_b32 s4, v1\n\ts_mov_b32 s4, s20\n\ts_mov_b32 s5, s21\n" + dma, 0)]   # rewritten by the scalar unit in between
     for i, (text, rc) in enumerate(cases):
         f = tmp_path / f"k{i}.s"
         f.write_text(text)

@@ -8,6 +8,11 @@ For every MFMA of every kernel in the file this walks forward - through fall-thr
 passed (an instruction = 1, `s_nop N` = N + 1, an MFMA = its passes... counted as 4, the shortest) and reports an instruction between `;;#ASMSTART` and
 `;;#ASMEND` that names one of the MFMA's destination registers as a SOURCE.  Empty asm statements (register launders) contain no instruction and are fine.
 
+Two more hazards of the same kind (software wait states the recogniser places for its own instructions only) are checked on the way:
+  * a transcendental result (v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin / v_cos) read by an asm VALU instruction in the very next issue slot (gfx940+: 1 wait state);
+  * an SGPR written by a VALU instruction (v_readfirstlane / v_readlane / a compare into an SGPR pair) read by an asm vector-memory instruction - the base of an
+    LDS-DMA - within 5 wait states.
+
 usage: python3 tools/check_mfma_asm_hazards.py <file.s> [kernel-name-regex]      (exit status 1 on a finding)"""
 import re
 import sys
@@ -18,6 +23,34 @@ KERNEL = re.compile(r"^(_Z\w+):")
 LABEL = re.compile(r"^(\.LBB\w+):")
 BRANCH = re.compile(r"^s_(c?branch\w*)\s+(\.LBB\w+)")
 NOP = re.compile(r"^s_nop\s+(\d+)")
+SREG = re.compile(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b")
+TRANS = re.compile(r"^v_(exp|log|rcp|rsq|sqrt|sin|cos)_")
+VMEM = re.compile(r"^(global|buffer|flat|scratch)_(load|store|atomic)")
+
+
+def sregs(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def linear_window(code, i, budget):
+    """the instructions that issue within `budget` wait states behind code[i], fall-through only (labels skipped, stops at a branch)"""
+    out, j = [], i + 1
+    while j < len(code) and budget > 0:
+        l, in_asm = code[j]
+        if not LABEL.match(l):
+            out.append((j, l, in_asm))
+            m = NOP.match(l)
+            budget -= int(m.group(1)) + 1 if m else 1
+            if BRANCH.match(l) or l.startswith("s_endpgm"):
+                break
+        j += 1
+    return out
 
 
 def regs(text):
@@ -97,7 +130,25 @@ def main():
     bad = 0
     for name, code in kernels.items():
         labels = {LABEL.match(l).group(1): i for i, (l, _) in enumerate(code) if LABEL.match(l)}
-        for i, (l, _) in enumerate(code):
+        for i, (l, in_asm0) in enumerate(code):
+            ops0 = l.split(None, 1)
+            if TRANS.match(l) and len(ops0) > 1:
+                d = regs(ops0[1].split(",")[0])
+                for j, t, in_asm in linear_window(code, i, 1):
+                    o = t.split(None, 1)
+                    if in_asm and t.startswith("v_") and len(o) > 1 and "," in o[1] and regs(o[1].split(",", 1)[1]) & d:
+                        bad += 1
+                        print(f"{name}: `{t}` (inline asm) reads the result of `{l}` in the next issue slot (transcendental forwarding: 1 wait state)")
+            if l.startswith("v_") and not in_asm0 and len(ops0) > 1:
+                d = sregs(ops0[1].split(",")[0]) if not l.startswith("v_cmpx") else set()
+                if d:
+                    for j, t, in_asm in linear_window(code, i, 5):
+                        if in_asm and VMEM.match(t) and sregs(t) & d:
+                            bad += 1
+                            print(f"{name}: `{t}` (inline asm) reads an SGPR `{l}` wrote {j - i} instruction(s) earlier (VALU -> SGPR -> vector memory: 5 wait states)")
+                        o = t.split(None, 1)
+                        if not in_asm and len(o) > 1 and re.match(r"^(s_|v_readfirstlane|v_readlane|v_cmp)", t) and sregs(o[1].split(",")[0]) & d:
+                            d = d - sregs(o[1].split(",")[0])      # rewritten in between
             if not l.startswith("v_mfma"):
                 continue
             dst = regs(l.split(None, 1)[1].split(",")[0])
@@ -106,7 +157,7 @@ def main():
             for j, t in found:
                 bad += 1
                 print(f"{name}: `{t}` (inline asm) reads a destination of `{l}` {j - i} instruction(s) behind it, inside its {WINDOW} wait states")
-    print(f"check_mfma_asm_hazards: {len(kernels)} kernel(s) of {path} scanned, {bad} inline-asm read(s) of an MFMA result in flight")
+    print(f"check_mfma_asm_hazards: {len(kernels)} kernel(s) of {path} scanned, {bad} inline-asm read(s) of a result in flight")
     return 1 if bad else 0
 
 
