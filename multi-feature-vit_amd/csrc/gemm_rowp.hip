@@ -38,6 +38,10 @@
 #ifndef MFVIT_ROWY_STORE
 #define MFVIT_ROWY_STORE 1
 #endif
+// timing ablations of the forward mode (tools/build_variant_lib.sh; WRONG results): 1 no x_out store, 2 no y store, 4 no main loop, 8 no residual prefetch
+#ifndef MFVIT_RP_ABL
+#define MFVIT_RP_ABL 0
+#endif
 
 namespace mfvit {
 
@@ -211,7 +215,7 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
                 // the epilogue)
                 const int n = 48 * wave + 4 * fq + 16 * j;
                 f32x4v rv = {0.f, 0.f, 0.f, 0.f};
-                if (p.res && ks == 0) rv = *(const f32x4v*)(p.res + (unsigned)(m0 + r0) * (unsigned)p.ldres + n);     // (one split carries the residual)
+                if (p.res && ks == 0 && !(MFVIT_RP_ABL & 8)) rv = *(const f32x4v*)(p.res + (unsigned)(m0 + r0) * (unsigned)p.ldres + n);     // (one split carries the residual)
                 acc[i][j] = rv;
             } else {
 #pragma unroll
@@ -360,7 +364,7 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
         return m0e + (r < rows ? r : rows - 1);
     };
 
-    for (int g = 0; g < G; g += 2) {
+    for (int g = 0; g < ((MFVIT_RP_ABL & 4) && REPI == REPI_RES_LN ? 2 : G); g += 2) {
         constexpr int AN = SPACED ? 0 : 1;                             // MF >= 5: one set (the fragments are dead by the time the next are read)
         stage_body(g, wh[0], wl[0], wh[1], wl[1], a01h[0], a01l[0], a01h[AN], a01l[AN]);
         advance_streams();
@@ -575,7 +579,7 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
                 // (a plain store, like the operand-type output below: the next row kernel starts its accumulators from these rows - fc2 / proj + LN
                 // 79.5 -> 74.3 us per launch in the step; MFVIT_ROWX_STORE=0 (A/B builds): the streaming store)
 #if MFVIT_ROWX_STORE
-                if (xo) *(f32x4v*)(xo + m * (unsigned)p.ldo0 + n) = acc[i][j];
+                if (xo && !(MFVIT_RP_ABL & 1)) *(f32x4v*)(xo + m * (unsigned)p.ldo0 + n) = acc[i][j];
 #else
                 if (xo) store16_stream(xo + m * (unsigned)p.ldo0 + n, __builtin_bit_cast(u32x4_st, acc[i][j]));
 #endif
@@ -585,7 +589,7 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
                 if (p.y_f32) *(f32x4v*)((float*)p.out1 + m * (unsigned)p.ldo1 + n) = acc[i][j];
             }
         }
-        if (!p.y_f32) {
+        if (!p.y_f32 && !(MFVIT_RP_ABL & 2)) {
             __syncthreads();                                           // (red / red2 live outside the ring; the ring itself is free)
             store_split(p.out1, p.ldo1, 0, MF < 4 ? MF : 4);
             if constexpr (MF > 4) store_split(p.out1, p.ldo1, 4, MF);
