@@ -87,6 +87,12 @@ __device__ __forceinline__ void rp_dma16(unsigned voff, const char* sbase, unsig
                  : "memory");
 }
 
+// 16 bytes per lane into registers, issued from asm: the compiler does not know the load is in flight (no s_waitcnt of its own - it would be a vmcnt(0) that
+// also drains the LDS-DMA queue); the caller waits with a counted s_waitcnt and launders the registers behind it (tools/check_vmem_hazards.py scans the window)
+__device__ __forceinline__ void rp_gload16(f32x4v& dst, unsigned voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+
 __device__ __forceinline__ f32x4v rp_mfma(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4v rp_mfma(f16x8 a, f16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
@@ -188,6 +194,35 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
             rp_dma4((ln / lpr) * (unsigned)(p.ldw * 2) + (ln % lpr) * 128u, gW0, __builtin_amdgcn_readfirstlane(lbase + RP_RING + RP_SCR - 256));
         }
     }
+    // Forward epilogue mode: the accumulators START as the residual rows, so that the 39 MB of residual rows are fetched under the latency of the first operand
+    // stages instead of in the epilogue, where nothing overlaps them (116 MB of exposed epilogue streaming became 77).  Sum order: res + products + bias instead
+    // of products + bias + res - one f32 rounding apart.  Round 6: the loads are issued from asm and FIRST - the oldest operations of the workgroup - so that the
+    // counted wait for stage 0 below covers them and nothing younger: as compiler-visible loads behind the prologue they needed a vmcnt(0), which also waited for
+    // W(1) and A(1 .. 3), 90 KB per CU that the first stage does not need (profiles/r06_row_fwd_ablation.txt: 9 us of the launch).
+    f32x4v acc[MF][3];
+    {
+        const bool with_res = REPI == REPI_RES_LN && p.res && ks == 0 && !(MFVIT_RP_ABL & 8);      // (one K split carries the residual)
+        const char* gR = rp_uniform_ptr(p.res);
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        if constexpr (REPI == REPI_RES_LN) {
+            if (with_res) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    int r0 = 16 * i + fr;
+                    r0 = r0 < rows ? r0 : rows - 1;
+                    const unsigned rowoff = (unsigned)(m0 + r0) * (unsigned)p.ldres + (unsigned)(48 * wave + 4 * fq);
+                    // (the load result IS the accumulator: no arithmetic on it - the bias joins in the epilogue)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) rp_gload16(acc[i][j], (rowoff + 16u * (unsigned)j) * 4u, gR);
+                }
+            }
+        }
+    }
     // W stages 0, 1 and A stages 0 .. 3 in flight (clamped to the last stage for very short K), stage 0 landed
     // (requires nk >= 4: checked by the launcher)
 #pragma unroll
@@ -200,42 +235,13 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
     for (int st = 1; st < RP_ASLOTS; ++st)
 #pragma unroll
         for (int i = 0; i < RP_LA; ++i) issue_a(st, st, i);
-    // Forward epilogue mode: the accumulators START as the residual rows.  The 39 MB of residual rows are then fetched here, under the latency of
-    // the first operand stages, instead of in the epilogue, where nothing overlaps them (the epilogue is exposed HBM streaming: 116 MB per launch
-    // became 77).  Sum order: res + products + bias instead of products + bias + res - one f32 rounding apart.
-    f32x4v acc[MF][3];
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        int r0 = 16 * i + fr;
-        r0 = r0 < rows ? r0 : rows - 1;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            if constexpr (REPI == REPI_RES_LN) {
-                // (the load result IS the accumulator: no arithmetic on it here - that would wait for each row's loads in turn; the bias joins in
-                // the epilogue)
-                const int n = 48 * wave + 4 * fq + 16 * j;
-                f32x4v rv = {0.f, 0.f, 0.f, 0.f};
-                if (p.res && ks == 0 && !(MFVIT_RP_ABL & 8)) rv = *(const f32x4v*)(p.res + (unsigned)(m0 + r0) * (unsigned)p.ldres + n);     // (one split carries the residual)
-                acc[i][j] = rv;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-            }
-        }
-    }
-
+    // the touches, W(0), A(0) - and the residual rows, older than all of them - have completed; W(1) and A(1 .. 3) stay in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP_LW + (RP_ASLOTS - 1) * RP_LA) : "memory");
     if constexpr (REPI == REPI_RES_LN) {
-        // The residual loads are the YOUNGEST operations in flight: wait for everything here, once, and make the accumulators visibly
-        // defined.  (Issued in front of the LDS-DMA prologue, the compiler - which cannot count asm loads - placed its own
-        // s_waitcnt vmcnt(0) for them in front of the first MFMA of the LOOP: every second stage waited for the activation pieces
-        // just requested, three stages before their use - the lookahead of the A ring was gone.)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(acc[i][j]));
-    } else {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RP_LW + (RP_ASLOTS - 1) * RP_LA) : "memory");     // the touches, W(0), A(0) have completed
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -528,11 +534,13 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
         float part[MF];
         fresh_lane();
         // v = (residual + products) + bias: the residual rows were the accumulators' initial values
-        f32x4v bj[3];
+        f32x4v bj[3], gj[3], bej[3];                    // (gamma / beta too: requested in front of the x_out stores, or the wait for them waits for the stores)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             bj[j] = f32x4v{0.f, 0.f, 0.f, 0.f};
             if (p.bias) bj[j] = *(const f32x4v*)(p.bias + ncol0 + 16 * j);
+            gj[j] = *(const f32x4v*)(p.gamma + ncol0 + 16 * j);
+            bej[j] = *(const f32x4v*)(p.beta + ncol0 + 16 * j);
         }
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -564,7 +572,10 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
         row_total(part, red2);
         asm volatile("" : "+s"(m0e));
         fresh_lane();
-        float* xo = (float*)p.out0;
+        // (the means are laundered: otherwise the compiler keeps the 12 MF differences acc - mu of the variance pass alive for the normalisation below, beside
+        // the accumulators themselves, which still have to leave as x_out - one register more than the file holds, a spill and its drain of the store queue)
+#pragma unroll
+        for (int i = 0; i < MF; ++i) asm volatile("" : "+v"(mu[i]));
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             const unsigned m = (unsigned)row_of(i);
@@ -576,16 +587,16 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int n = ncol0 + 16 * j;
-                // (a plain store, like the operand-type output below: the next row kernel starts its accumulators from these rows - fc2 / proj + LN
-                // 79.5 -> 74.3 us per launch in the step; MFVIT_ROWX_STORE=0 (A/B builds): the streaming store)
+                // x_out: a plain store, like the operand-type output below - the next row kernel starts its accumulators from these rows (fc2 / proj + LN
+                // 79.5 -> 74.3 us per launch in the step, round 5; MFVIT_ROWX_STORE=0 (A/B builds): the streaming store).  (Issued in front of the row
+                // statistics instead - the rows are complete there - the class ran 1 us SLOWER, round 6: profiles/r06_row_fwd_ablation.txt)
 #if MFVIT_ROWX_STORE
-                if (xo && !(MFVIT_RP_ABL & 1)) *(f32x4v*)(xo + m * (unsigned)p.ldo0 + n) = acc[i][j];
+                if (p.out0 && !(MFVIT_RP_ABL & 1)) *(f32x4v*)((float*)p.out0 + m * (unsigned)p.ldo0 + n) = acc[i][j];
 #else
-                if (xo) store16_stream(xo + m * (unsigned)p.ldo0 + n, __builtin_bit_cast(u32x4_st, acc[i][j]));
+                if (p.out0) store16_stream((float*)p.out0 + m * (unsigned)p.ldo0 + n, __builtin_bit_cast(u32x4_st, acc[i][j]));
 #endif
-                const f32x4v g = *(const f32x4v*)(p.gamma + n), be = *(const f32x4v*)(p.beta + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] - mu[i]) * rs * g[r] + be[r];
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] - mu[i]) * rs * gj[j][r] + bej[j][r];
                 if (p.y_f32) *(f32x4v*)((float*)p.out1 + m * (unsigned)p.ldo1 + n) = acc[i][j];
             }
         }
@@ -959,6 +970,7 @@ bool gemm_nt_rowp_supported(int dtype, int repi, const GemmP& p) {
         return true;
     }
     if (!p.out1 || !p.gamma || !p.beta) return false;
+    if (p.res && (unsigned long long)p.M * p.ldres * 4 >= (1ull << 32)) return false;                                 // 32-bit offsets of the asm residual loads
     if ((unsigned long long)p.M * p.lda * 2 >= (1ull << 32) || (unsigned long long)p.N * p.ldw * 2 >= (1ull << 32)) return false;
     if (p.lda % 8 || p.ldw % 8 || (p.out0 && p.ldo0 % 4) || p.ldo1 % (p.y_f32 ? 4 : 8) || (p.res && p.ldres % 4)) return false;
     if ((size_t)p.A % 16 || (size_t)p.W % 16 || (size_t)p.out1 % 16 || (p.out0 && (size_t)p.out0 % 16) || (p.res && (size_t)p.res % 16) ||
