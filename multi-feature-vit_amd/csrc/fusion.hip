@@ -55,9 +55,15 @@ struct FusWs {  // workspace offsets (floats)
     long z0, st0, qv, kq, u, a, st, o, outp, fus, stc;          // forward (kept for backward)
     long wT;                                                     // [2][4][D*D] transposed wq, wk, wv, wp
     long dout, dqp, dob, du, dkq, dz0p, dqv, dz0q;               // backward scratch
+    // per-sample partials of the small parameter gradients (round 6: plain stores + one fixed-order reduce instead of float atomics - the same bits on every run):
+    //   pa [2][B][3 D]    d post-LN weight | bias | d proj.bias          (x_finish_bwd)
+    //   pb [2][B][2 C D]  d head weight | d backbone-head weight          (x_finish_bwd)
+    //   pc [2][B][2 C]    d head bias | d backbone-head bias              (x_finish_bwd)
+    //   pd [2][2 B][2 D]  d pre-norm weight | bias: rows 0 .. B - 1 from x_stream_bwd (token rows 1 ..), rows B .. 2 B - 1 from x_row0_bwd (the cls row)
+    long pa, pb, pc, pd;
     long total;
 };
-FusWs fus_ws(int B, int T) {
+FusWs fus_ws(int B, int T, int C) {
     FusWs W;
     long o = 0;
     auto take = [&](long n) { long r = o; o += (n + 63) & ~63L; return r; };
@@ -67,6 +73,7 @@ FusWs fus_ws(int B, int T) {
     W.wT = take(2L * 4 * D * D);
     W.dout = take(2L * B * D); W.dqp = take(2L * B * D); W.dob = take(2L * B * D); W.du = take(2L * B * NH * D);
     W.dkq = take(2L * B * NH * D); W.dz0p = take(2L * B * D); W.dqv = take(2L * B * D); W.dz0q = take(2L * B * D);
+    W.pa = take(2L * B * 3 * D); W.pb = take(2L * B * 2 * C * D); W.pc = take(2L * B * 2 * C); W.pd = take(2L * 2 * B * 2 * D);
     W.total = o;
     return W;
 }
@@ -257,17 +264,18 @@ __global__ __launch_bounds__(128) void x_finish_bwd_kernel(const float* __restri
                                                            const float* __restrict__ dx_c, const float* __restrict__ dx_e,
                                                            float* __restrict__ dparams, float* __restrict__ dhw_c,
                                                            float* __restrict__ dhb_c, float* __restrict__ dhw_e,
-                                                           float* __restrict__ dhb_e, float* __restrict__ dout, float* __restrict__ dqp) {
+                                                           float* __restrict__ dhb_e, float* __restrict__ dout, float* __restrict__ dqp,
+                                                           float* __restrict__ pa, float* __restrict__ pb, float* __restrict__ pc) {
     const int b = blockIdx.x, dir = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // this sample's terms of the small parameter gradients: plain stores into its rows of the partial buffers (FusWs::pa / pb / pc), summed over the batch in a
+    // fixed order by fus_reduce_partials
+    float* pa_r = pa + ((long)dir * B + b) * 3 * D;
+    float* pb_r = pb + ((long)dir * B + b) * 2 * C * D;
+    float* pc_r = pc + ((long)dir * B + b) * 2 * C;
     const float* cls = (dir == 0 ? fc : fe) + (long)b * T * D;
     const float* op = outp + ((long)dir * B + b) * D;
     const float* g = params + L.post[dir];
     const float* hw = params + L.head[dir];
-    float* dhw = dparams + L.head[dir];
-    float* dhb = dhw + (long)C * D;
-    float* dg = dparams + L.post[dir];
-    float* dbe = dg + D;
-    float* dbp = dparams + L.ca[dir] + L.bp;
     const float mu = stc[((long)dir * B + b) * 2], rs = stc[((long)dir * B + b) * 2 + 1];
     float e[NPL], c0[NPL], f[NPL];
 #pragma unroll
@@ -277,9 +285,9 @@ __global__ __launch_bounds__(128) void x_finish_bwd_kernel(const float* __restri
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
             e[i] = fmaf(gc, hw[(long)c * D + lane + 64 * i], e[i]);
-            atomicAdd(dhw + (long)c * D + lane + 64 * i, gc * f[i]);
+            pb_r[(long)c * D + lane + 64 * i] = gc * f[i];
         }
-        if (lane == 0) atomicAdd(dhb + c, gc);
+        if (lane == 0) pc_r[c] = gc;
     }
     // post-LN backward: dc = e ; cal = cls + outp
     float xh[NPL], s1 = 0.f, s2 = 0.f;
@@ -288,8 +296,8 @@ __global__ __launch_bounds__(128) void x_finish_bwd_kernel(const float* __restri
         xh[i] = (c0[i] + op[lane + 64 * i] - mu) * rs;
         const float t = e[i] * g[lane + 64 * i];
         s1 += t; s2 += t * xh[i];
-        atomicAdd(dg + lane + 64 * i, e[i] * xh[i]);
-        atomicAdd(dbe + lane + 64 * i, e[i]);
+        pa_r[lane + 64 * i] = e[i] * xh[i];
+        pa_r[D + lane + 64 * i] = e[i];
     }
     const float c1 = wave_sum(s1) * (1.f / D), c2 = wave_sum(s2) * (1.f / D);
     float dq[NPL];
@@ -297,24 +305,20 @@ __global__ __launch_bounds__(128) void x_finish_bwd_kernel(const float* __restri
     for (int i = 0; i < NPL; ++i) {
         const float dcal = rs * (e[i] * g[lane + 64 * i] - c1 - xh[i] * c2);
         dout[((long)dir * B + b) * D + lane + 64 * i] = dcal;
-        atomicAdd(dbp + lane + 64 * i, dcal);
+        pa_r[2 * D + lane + 64 * i] = dcal;
         dq[i] = e[i] + dcal;
     }
     // backbone classifier head on the cls row (x_S = head_S(cls_S)): FUS:131,135
     const float* bw = dir == 0 ? hw_c : hw_e;
     const float* dxs = dir == 0 ? dx_c : dx_e;
-    float* dbw = dir == 0 ? dhw_c : dhw_e;
-    float* dbb = dir == 0 ? dhb_c : dhb_e;
-    if (bw && dxs) {
-        for (int c = 0; c < C; ++c) {
-            const float gc = dxs[(long)b * C + c];
+    for (int c = 0; c < C; ++c) {
+        const float gc = bw && dxs ? dxs[(long)b * C + c] : 0.f;      // (no backbone head: zero rows - the reduce has no destination for them)
 #pragma unroll
-            for (int i = 0; i < NPL; ++i) {
-                dq[i] = fmaf(gc, bw[(long)c * D + lane + 64 * i], dq[i]);
-                if (dbw) atomicAdd(dbw + (long)c * D + lane + 64 * i, gc * c0[i]);
-            }
-            if (dbb && lane == 0) atomicAdd(dbb + c, gc);
+        for (int i = 0; i < NPL; ++i) {
+            if (bw && dxs) dq[i] = fmaf(gc, bw[(long)c * D + lane + 64 * i], dq[i]);
+            pb_r[(long)(C + c) * D + lane + 64 * i] = gc * c0[i];
         }
+        if (lane == 0) pc_r[C + c] = gc;
     }
 #pragma unroll
     for (int i = 0; i < NPL; ++i) dqp[((long)dir * B + b) * D + lane + 64 * i] = dq[i];
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(XW * 64) void x_stream_bwd_kernel(const float* __re
                                                            const float* __restrict__ params, FusLayout L, float scale, int B, int T,
                                                            const float* __restrict__ kq, const float* __restrict__ a_in,
                                                            const float* __restrict__ st_in, const float* __restrict__ du,
-                                                           float* __restrict__ dkq, float* __restrict__ dz0p, float* __restrict__ dparams,
+                                                           float* __restrict__ dkq, float* __restrict__ dz0p, float* __restrict__ pd,
                                                            float* __restrict__ dfc, float* __restrict__ dfe) {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     float* sa = xs;
@@ -421,8 +425,7 @@ __global__ __launch_bounds__(XW * 64) void x_stream_bwd_kernel(const float* __re
         for (int w2 = 0; w2 < XW; ++w2) v += red[w2 * 5 * D + q];
         if (q < NH * D) dkq[((long)dir * B + b) * NH * D + q] = v;
         else if (L.no_norm) continue;
-        else if (q < 4 * D) atomicAdd(dparams + L.ca[dir] + L.n_w + (q - 3 * D), v);
-        else atomicAdd(dparams + L.ca[dir] + L.n_b + (q - 4 * D), v);
+        else pd[((long)dir * 2 * B + b) * 2 * D + (q - 3 * D)] = v;        // this sample's d pre-norm weight | bias over its token rows 1 ..: row b of FusWs::pd
     }
 }
 
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(128) void x_row0_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ params, FusLayout L, int B, int T,
                                                          const float* __restrict__ st0, const float* __restrict__ dz0p,
                                                          const float* __restrict__ dz0q, const float* __restrict__ dqp,
-                                                         float* __restrict__ dparams, float* __restrict__ dfc, float* __restrict__ dfe) {
+                                                         float* __restrict__ pd, float* __restrict__ dfc, float* __restrict__ dfe) {
     const int b = blockIdx.x, dir = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* cls = (dir == 0 ? fc : fe) + (long)b * T * D;
     float* down = dir == 0 ? dfc : dfe;
@@ -446,8 +449,8 @@ __global__ __launch_bounds__(128) void x_row0_bwd_kernel(const float* __restrict
         if (L.no_norm) continue;
         const float t = dz[i] * g[lane + 64 * i];
         s1 += t; s2 += t * xh[i];
-        atomicAdd(dparams + L.ca[dir] + L.n_w + lane + 64 * i, dz[i] * xh[i]);
-        atomicAdd(dparams + L.ca[dir] + L.n_b + lane + 64 * i, dz[i]);
+        pd[((long)dir * 2 * B + B + b) * 2 * D + lane + 64 * i] = dz[i] * xh[i];        // the cls row's terms: row B + b of FusWs::pd
+        pd[((long)dir * 2 * B + B + b) * 2 * D + D + lane + 64 * i] = dz[i];
     }
     if (!down) return;
     if (L.no_norm) {   // (st0 = (0, 1): xh = x; no normalisation to differentiate)
@@ -474,11 +477,12 @@ bool fus_ok(const mfvit_fusion_cfg* c) {
 
 static int xattn_core_backward(int ndir, const FusLayout& L, const FusWs& W, const float* params, const float* f_cxr, const float* f_enh,
                                float* ws, int B, int T, float* dparams, float* df_cxr, float* df_enh, hipStream_t st);
+static int fus_prenorm_job(int dir, const FusLayout& L, const FusWs& W, float* ws, int B, float* dparams, hipStream_t st);
 
 extern "C" {
 
 size_t mfvit_fusion_param_count(const mfvit_fusion_cfg* cfg) { return fus_ok(cfg) ? (size_t)fus_layout(cfg->num_classes).total : 0; }
-size_t mfvit_fusion_workspace_bytes(const mfvit_fusion_cfg* cfg) { return fus_ok(cfg) ? (size_t)fus_ws(cfg->batch, cfg->tokens).total * 4 : 0; }
+size_t mfvit_fusion_workspace_bytes(const mfvit_fusion_cfg* cfg) { return fus_ok(cfg) ? (size_t)fus_ws(cfg->batch, cfg->tokens, cfg->num_classes).total * 4 : 0; }
 
 // PreNorm -> CrossAttention of `ndir` directions up to the projection output outp[dir][b][D] (MOD:20,123-137)
 static int xattn_core_forward(int ndir, const FusLayout& L, const FusWs& W, const float* params, const float* f_cxr, const float* f_enh,
@@ -540,7 +544,7 @@ int mfvit_fusion_forward(const mfvit_fusion_cfg* cfg, const float* params, const
     hipStream_t st = (hipStream_t)stream;
     const int B = cfg->batch, T = cfg->tokens, C = cfg->num_classes;
     const FusLayout L = fus_layout(C);
-    const FusWs W = fus_ws(B, T);
+    const FusWs W = fus_ws(B, T, cfg->num_classes);
     float* ws = (float*)workspace;
     FUS_TRY(xattn_core_forward(2, L, W, params, f_cxr, f_enh, ws, B, T, cfg->eps_pre, st));
     MFVIT_LAUNCH(x_finish_fwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, cfg->eps_post, B, T, C, ws + W.outp,
@@ -558,16 +562,37 @@ int mfvit_fusion_backward(const mfvit_fusion_cfg* cfg, const float* params, cons
     hipStream_t st = (hipStream_t)stream;
     const int B = cfg->batch, T = cfg->tokens, C = cfg->num_classes;
     const FusLayout L = fus_layout(C);
-    const FusWs W = fus_ws(B, T);
+    const FusWs W = fus_ws(B, T, cfg->num_classes);
     float* ws = (float*)workspace;
     MFVIT_LAUNCH(x_finish_bwd_kernel, dim3(B), dim3(128), 0, st, f_cxr, f_enh, params, L, B, T, C, ws + W.outp, ws + W.fus,
                        ws + W.stc, hw_cxr, hw_enh, dfused, dx_cxr, dx_enh, dparams, dhw_cxr, dhb_cxr, dhw_enh, dhb_enh, ws + W.dout,
-                       ws + W.dqp);
+                       ws + W.dqp, ws + W.pa, ws + W.pb, ws + W.pc);
     MFVIT_CHECK_LAUNCH();
-    return xattn_core_backward(2, L, W, params, f_cxr, f_enh, ws, B, T, dparams, df_cxr, df_enh, st);
+    FUS_TRY(xattn_core_backward(2, L, W, params, f_cxr, f_enh, ws, B, T, dparams, df_cxr, df_enh, st));
+    // the batch sums of the small gradients, every one in a fixed order (one launch)
+    ColpartBatch batch;
+    ColpartBatch* prev = colpart_batch_begin(&batch);
+    int rc = MFVIT_OK;
+    for (int dir = 0; dir < 2 && rc == MFVIT_OK; ++dir) {
+        float* dhw = dparams + L.head[dir];
+        float* dg = dparams + L.post[dir];
+        rc = colpart_reduce(ws + W.pa + (long)dir * B * 3 * D, B, D, 3, dg, dg + D, dparams + L.ca[dir] + L.bp, st);
+        if (rc == MFVIT_OK) rc = colpart_reduce(ws + W.pb + (long)dir * B * 2 * C * D, B, C * D, 2, dhw, dir == 0 ? dhw_cxr : dhw_enh, nullptr, st);
+        if (rc == MFVIT_OK) rc = colpart_reduce(ws + W.pc + (long)dir * B * 2 * C, B, C, 2, dhw + (long)C * D, dir == 0 ? dhb_cxr : dhb_enh, nullptr, st);
+        if (rc == MFVIT_OK) rc = fus_prenorm_job(dir, L, W, ws, B, dparams, st);
+    }
+    if (rc == MFVIT_OK) rc = colpart_batch_flush(st);
+    colpart_batch_begin(prev);
+    return rc;
 }
 
 }  // extern "C"
+
+// d pre-norm weight | bias of direction `dir` += the sum over its 2 B partial rows (x_stream_bwd: token rows 1 .., x_row0_bwd: the cls row), fixed order
+static int fus_prenorm_job(int dir, const FusLayout& L, const FusWs& W, float* ws, int B, float* dparams, hipStream_t st) {
+    if (L.no_norm) return MFVIT_OK;
+    return colpart_reduce(ws + W.pd + (long)dir * 2 * B * 2 * D, 2 * B, D, 2, dparams + L.ca[dir] + L.n_w, dparams + L.ca[dir] + L.n_b, nullptr, st);
+}
 
 // backward of xattn_core_forward: consumes ws.dout (= d outp) and ws.dqp (cls gradient that bypasses the attention)
 static int xattn_core_backward(int ndir, const FusLayout& L, const FusWs& W, const float* params, const float* f_cxr, const float* f_enh,
@@ -608,7 +633,7 @@ static int xattn_core_backward(int ndir, const FusLayout& L, const FusWs& W, con
         if (attr.first()) { (void)hipFuncSetAttribute((const void*)x_stream_bwd_kernel<XW_BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
         ProfScope ps(PROF_XATTN_BWD, 0, 2.0 * B * T * D * 4 * 3, st);
         MFVIT_LAUNCH(x_stream_bwd_kernel<XW_BWD>, dim3(B, ndir), dim3(XW_BWD * 64), lds, st, f_cxr, f_enh, params, L, scale, B, T, ws + W.kq, ws + W.a,
-                           ws + W.st, ws + W.du, ws + W.dkq, ws + W.dz0p, dparams, df_cxr, df_enh);
+                           ws + W.st, ws + W.du, ws + W.dkq, ws + W.dz0p, ws + W.pd, df_cxr, df_enh);
         MFVIT_CHECK_LAUNCH();
     }
     {   // dWk_h += qv_h^T dkq_h
@@ -640,7 +665,7 @@ static int xattn_core_backward(int ndir, const FusLayout& L, const FusWs& W, con
         FUS_TRY(gemm_nt_tile(MFVIT_F32, EPI_NONE, p, st));
     }
     MFVIT_LAUNCH(x_row0_bwd_kernel, dim3(B), dim3(64 * ndir), 0, st, f_cxr, f_enh, params, L, B, T, ws + W.st0, ws + W.dz0p, ws + W.dz0q,
-                       ws + W.dqp, dparams, df_cxr, df_enh);
+                       ws + W.dqp, ws + W.pd, df_cxr, df_enh);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -667,7 +692,7 @@ static int xattn_one_forward(const mfvit_fusion_cfg* cfg, bool bare, const float
     hipStream_t st = (hipStream_t)stream;
     const int B = cfg->batch, T = cfg->tokens;
     const FusLayout L = one_block_layout(cfg, bare);
-    const FusWs W = fus_ws(B, T);
+    const FusWs W = fus_ws(B, T, cfg->num_classes);
     float* ws = (float*)workspace;
     FUS_TRY(xattn_core_forward(1, L, W, params, x_own, x_oth, ws, B, T, cfg->eps_pre, st));
     MFVIT_LAUNCH(x_copy_out_kernel, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, st, ws + W.outp, out, (long)B * D);
@@ -682,14 +707,15 @@ static int xattn_one_backward(const mfvit_fusion_cfg* cfg, bool bare, const floa
     hipStream_t st = (hipStream_t)stream;
     const int B = cfg->batch, T = cfg->tokens;
     const FusLayout L = one_block_layout(cfg, bare);
-    const FusWs W = fus_ws(B, T);
+    const FusWs W = fus_ws(B, T, cfg->num_classes);
     float* ws = (float*)workspace;
     MFVIT_LAUNCH(x_copy_out_kernel, dim3((unsigned)(((long)B * D + 255) / 256)), dim3(256), 0, st, dout, ws + W.dout, (long)B * D);
     MFVIT_CHECK_LAUNCH();
     if (hipMemsetAsync(ws + W.dqp, 0, sizeof(float) * B * D, st) != hipSuccess) return MFVIT_ELAUNCH;
     // d proj.bias = column sums of dout (x_finish_bwd does this in the fused model)
     FUS_TRY(colsum_rows(dout, D, dparams + L.ca[0] + L.bp, B, 1, 0, D, st));
-    return xattn_core_backward(1, L, W, params, x_own, x_oth, ws, B, T, dparams, dx_own, dx_oth, st);
+    FUS_TRY(xattn_core_backward(1, L, W, params, x_own, x_oth, ws, B, T, dparams, dx_own, dx_oth, st));
+    return fus_prenorm_job(0, L, W, ws, B, dparams, st);
 }
 
 int mfvit_prenorm_xattn_forward(const mfvit_fusion_cfg* cfg, const float* params, const float* x_own, const float* x_oth,

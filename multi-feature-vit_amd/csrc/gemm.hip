@@ -953,10 +953,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmP p) {
                 }
     }
     if (do_cs && (lane & 31) == 0) {
+        // (one writer per split and row: into the split's row of the bias partials behind the tile partials when the launch has them - summed in a fixed order
+        // by the reduce pass, like gemm_tn2.hip - else a float atomic)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + nw + i * 32 + acc_row(r, lane), bacc[i][r]);
+            for (int r = 0; r < 16; ++r) {
+                const int n = nw + i * 32 + acc_row(r, lane);
+                if (p.kpart) p.kpart[(long)split * p.N + n] = bacc[i][r];
+                else atomicAdd(p.cs0 + n, bacc[i][r]);
+            }
     }
 }
 
@@ -1113,6 +1119,7 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
     }
     // p.cpart (optional, >= splits * N * K floats): split partials go there as plain stores and are summed by a second kernel
     if (p.nb > 1 || p.splits < 2 || p.ldo0 % 4 || (long)tiles * p.splits > 384) p.cpart = nullptr;   // scratch holds 384 tiles
+    p.kpart = p.cpart && p.cs0 && (long)tiles * p.splits + 2 <= 384 && p.N % 4 == 0 && (size_t)p.cs0 % 16 == 0 ? p.cpart + (long)p.splits * p.N * p.K : nullptr;
     ProfScope ps(PROF_GEMM_TN, 2.0 * p.M * p.N * p.K * (p.nb > 1 ? p.nb : 1), 0, st);
     const dim3 grid = xcd1d ? dim3(tiles * p.splits, 1, 1) : dim3(tiles, p.splits, p.nb > 1 ? p.nb : 1);
     if (p.orow_in)
@@ -1121,7 +1128,9 @@ template <typename T> static int launch_tn(GemmP p, hipStream_t st) {
         MFVIT_LAUNCH((gemm_tn_kernel<T, false>), grid, dim3(256), bytes, st, p);
     MFVIT_CHECK_LAUNCH();
     if (p.cpart) {
-        return tn_partial_reduce(p.cpart, p.splits, (long)p.N * p.K, p.N, p.K, (float*)p.out0, p.ldo0, st);
+        const int rc = tn_partial_reduce(p.cpart, p.splits, (long)p.N * p.K, p.N, p.K, (float*)p.out0, p.ldo0, st);
+        if (rc != MFVIT_OK || !p.kpart) return rc;
+        return tn_partial_reduce(p.kpart, p.splits, p.N, 1, p.N, p.cs0, p.N, st);
     }
     return MFVIT_OK;
 }
@@ -1160,22 +1169,31 @@ int tn_partial_reduce(const float* part, int splits, long stride, int N, int K, 
     return MFVIT_OK;
 }
 
-// dst_q[c] += sum_g part[g][q * ncols + c]  for q < nq.  Grid: (column groups of 64) x (chunks of 32 partial rows); every block
-// adds its chunk sum with one atomic per column, so an address sees G / 32 adds instead of G.
-__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, int G, int ncols, int nq, float* d0, float* d1,
-                                                             float* d2) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
-    const int g0 = blockIdx.y * 32;
-    __shared__ float sm[4][64];
+// dst_q[c] += sum_g part[g][q * ncols + c]  for q < nq.  Grid: column groups of 64; ONE block adds all G partial rows of its columns in a fixed order (sixteen
+// interleaved row sequences, combined 0 + 1 + ... + 15) and adds the total to the destination with one atomic per column: the sum is the same bits on every run
+// (round 6; before, chunks of 32 partial rows went to the destination by float atomics in arrival order - G / 32 adds per address, 8 at the bench shape).  The
+// destination itself is zero or holds an earlier launch's total: one or two commutative adds.
+constexpr int CPR_SUB = 16;      // row sequences per block (1,024 threads: G = 396 partial rows of the x act' epilogue are 25 loads per thread)
+__device__ __forceinline__ float colpart_rows(const float* __restrict__ part, int G, long pitch, int c, int sub, float (*sm)[64]) {
     float s = 0.f;
-    if (c < nq * ncols) {
-        const int g1 = g0 + 32 < G ? g0 + 32 : G;
-        for (int g2 = g0 + sub; g2 < g1; g2 += 4) s += part[(long)g2 * nq * ncols + c];
-    }
+#pragma unroll 4
+    for (int g2 = sub; g2 < G; g2 += CPR_SUB) s += part[(long)g2 * pitch + c];
     sm[sub][threadIdx.x & 63] = s;
     __syncthreads();
-    if (sub == 0 && c < nq * ncols) {
-        s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    s = 0.f;
+    if (sub == 0) {
+#pragma unroll
+        for (int i = 0; i < CPR_SUB; ++i) s += sm[i][threadIdx.x];
+    }
+    return s;
+}
+__global__ __launch_bounds__(64 * CPR_SUB) void colpart_reduce_kernel(const float* __restrict__ part, int G, int ncols, int nq, float* d0, float* d1,
+                                                                     float* d2) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    __shared__ float sm[CPR_SUB][64];
+    const bool ok = c < nq * ncols;
+    float s = colpart_rows(part, ok ? G : 0, (long)nq * ncols, c, sub, sm);
+    if (sub == 0 && ok) {
         float* d = c / ncols == 0 ? d0 : (c / ncols == 1 ? d1 : d2);
         if (d) atomicAdd(d + c % ncols, s);
     }
@@ -1184,21 +1202,13 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
 // The same for a BATCH of partial buffers in one launch (blockIdx.z = job): the encoder backward gives every row-kernel launch of a call its
 // own partial buffer and reduces them all at the end of the call - one launch instead of 25 (round 3: 50 launches of 4.4 us + their
 // boundaries per step).
-__global__ __launch_bounds__(256) void colpart_reduce_batch_kernel(ColpartBatch b) {
+__global__ __launch_bounds__(64 * CPR_SUB) void colpart_reduce_batch_kernel(ColpartBatch b) {
     const ColpartJob& j = b.job[blockIdx.z];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
-    const int g0 = blockIdx.y * 32;
-    if (g0 >= j.G) return;
-    __shared__ float sm[4][64];
-    float s = 0.f;
-    if (c < j.nq * j.ncols) {
-        const int g1 = g0 + 32 < j.G ? g0 + 32 : j.G;
-        for (int g2 = g0 + sub; g2 < g1; g2 += 4) s += j.part[(long)g2 * j.nq * j.ncols + c];
-    }
-    sm[sub][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (sub == 0 && c < j.nq * j.ncols) {
-        s = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    __shared__ float sm[CPR_SUB][64];
+    const bool ok = c < j.nq * j.ncols;
+    float s = colpart_rows(j.part, ok ? j.G : 0, (long)j.nq * j.ncols, c, sub, sm);
+    if (sub == 0 && ok) {
         float* d = j.d[c / j.ncols];
         if (d) atomicAdd(d + c % j.ncols, s);
     }
@@ -1213,12 +1223,9 @@ ColpartBatch* colpart_batch_begin(ColpartBatch* b) {
 int colpart_batch_flush(hipStream_t st) {
     ColpartBatch* b = g_colpart_batch;
     if (!b || b->n == 0) return MFVIT_OK;
-    int gmax = 0, cmax = 0;
-    for (int i = 0; i < b->n; ++i) {
-        gmax = b->job[i].G > gmax ? b->job[i].G : gmax;
-        cmax = b->job[i].nq * b->job[i].ncols > cmax ? b->job[i].nq * b->job[i].ncols : cmax;
-    }
-    MFVIT_LAUNCH(colpart_reduce_batch_kernel, dim3((cmax + 63) / 64, (gmax + 31) / 32, b->n), dim3(256), 0, st, *b);
+    int cmax = 0;
+    for (int i = 0; i < b->n; ++i) cmax = b->job[i].nq * b->job[i].ncols > cmax ? b->job[i].nq * b->job[i].ncols : cmax;
+    MFVIT_LAUNCH(colpart_reduce_batch_kernel, dim3((cmax + 63) / 64, 1, b->n), dim3(64 * CPR_SUB), 0, st, *b);
     b->n = 0;
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
@@ -1230,7 +1237,7 @@ int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float
         j.part = part; j.G = G; j.ncols = ncols; j.nq = nq; j.d[0] = d0; j.d[1] = d1; j.d[2] = d2;
         return MFVIT_OK;
     }
-    MFVIT_LAUNCH(colpart_reduce_kernel, dim3((nq * ncols + 63) / 64, (G + 31) / 32), dim3(256), 0, st, part, G, ncols, nq, d0, d1, d2);
+    MFVIT_LAUNCH(colpart_reduce_kernel, dim3((nq * ncols + 63) / 64), dim3(64 * CPR_SUB), 0, st, part, G, ncols, nq, d0, d1, d2);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

@@ -367,7 +367,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
         } else {
             // x act' + column sums: a lane owns column 16 j + (lane & 15) and rows 4 (lane >> 4) .. + 3 of every tile.  The aux rows (in registers since the last load
             // phase) go through the patch, every lane multiplies its accumulators in place; the column sums of the product (the bias gradient of the Linear in front)
-            // leave as float atomics
+            // leave as one row of partials per 64-row block of the tile (p.cpart: [4 x row tile + block][N], plain stores, added in a fixed order by colpart_reduce -
+            // the same bits on every run, round 6) or, without a partial buffer, as float atomics
             float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -387,7 +388,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
                 for (int j = 0; j < 4; ++j) {
                     float c = csum[j] + __shfl_xor(csum[j], 16, 64);
                     c += __shfl_xor(c, 32, 64);
-                    if (lane < 16) atomicAdd(p.cs0 + nw + j * 16 + lane, c);
+                    if (lane < 16) {
+                        if (p.cpart) p.cpart[((long)(tile / ntn) * 4 + grp * 2 + wm) * p.N + nw + j * 16 + lane] = c;
+                        else atomicAdd(p.cs0 + nw + j * 16 + lane, c);
+                    }
                 }
             }
 #pragma unroll
@@ -456,7 +460,6 @@ bool gemm_nt_pp_supported(int dtype, int epi, const GemmP& p) {
     if (epi == EPI_BIAS_X3F16 && dtype != MFVIT_BF16X3) return false;
     const int kps = dtype == MFVIT_BF16X3 ? 32 : 64;
     if (p.nb > 1 || (on != 2 && p.M < env_switch("MFVIT_PP_MINROWS", 2048, c_min)) || p.M < 1 || p.N % PP_BN || p.K % kps || p.K < 2 * kps) return false;
-    if (p.cs0 && p.cpart) return false;                         // per-tile partial column sums: the round-5 kernel's layout
     if (p.omax) return false;                                   // per-(image, head) output maxima: the round-5 kernel's epilogue (proj data gradient)
     if (on != 2) {   // enough tiles to fill the persistent grid's rounds: 256 x 128 tiles on one workgroup per CU quantise coarsely (proj data gradient at the bench shape:
         // 297 tiles = 2 rounds at 58 % - 35.3 us against 31.7 us of the 128 x 128 kernel on two workgroups per CU; qkv 891 tiles = 4 rounds at 87 %)
@@ -472,12 +475,15 @@ bool gemm_nt_pp_supported(int dtype, int epi, const GemmP& p) {
     return true;
 }
 int gemm_nt_pp(int dtype, int epi, const GemmP& p, hipStream_t st) {
+    int rc = MFVIT_EINVAL;
     switch (dtype) {
-        case MFVIT_BF16X3: return pp_by_epi<sbf16>(epi, p, st);
-        case MFVIT_BF16: return pp_by_epi<bf16>(epi, p, st);
-        case MFVIT_F16: return pp_by_epi<f16>(epi, p, st);
+        case MFVIT_BF16X3: rc = pp_by_epi<sbf16>(epi, p, st); break;
+        case MFVIT_BF16: rc = pp_by_epi<bf16>(epi, p, st); break;
+        case MFVIT_F16: rc = pp_by_epi<f16>(epi, p, st); break;
     }
-    return MFVIT_EINVAL;
+    // column-sum partials of the x act' epilogue: [4 x row tiles][N] (p.cpart: room for 4 x ceil(M / 256) rows of N floats) -> cs0, fixed order
+    if (rc == MFVIT_OK && epi == EPI_GELU_BWD && p.cs0 && p.cpart) return colpart_reduce(p.cpart, 4 * ((p.M + PP_BM - 1) / PP_BM), p.N, 1, p.cs0, nullptr, nullptr, st);
+    return rc;
 }
 
 }  // namespace mfvit

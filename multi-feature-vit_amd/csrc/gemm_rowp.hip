@@ -407,7 +407,7 @@ __device__ __forceinline__ void rowp_body(GemmP& p, const int tile, const int m0
         __syncthreads();
         if (!*lastf) return;
         // the sum in a FIXED order, ((p0 + p1) + p2) + p3, whoever arrived last - its own partial comes back from the scratch like the others - so that
-        // the result is the same bits on every run (tests/test_encoder_gpu.py::test_weight_gradients_are_bit_identical_from_run_to_run)
+        // the result is the same bits on every run (tests/test_encoder_gpu.py::test_gradients_are_bit_identical_from_run_to_run)
 #pragma unroll
         for (int i = 0; i < MF; ++i)
 #pragma unroll

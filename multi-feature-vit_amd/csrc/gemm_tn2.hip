@@ -346,6 +346,11 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
         // of the ring: every wave is past its last fragment read and every LDS-DMA has landed)
         __syncthreads();
         float* xch = (float*)lds + (size_t)wq * (NL * NL * 16 * 64) + lane;
+        float* bxch = (float*)lds + (size_t)4 * (NL * NL * 16 * 64) + (size_t)wq * (16 * 64) + lane;     // (behind the four quadrants: the bias column sums)
+        if (CS && do_cs && kh == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bxch[r * 64] = bacc[0][r];
+        }
         if (kh == 1) {
 #pragma unroll
             for (int i = 0; i < NL; ++i)
@@ -362,6 +367,10 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
                 for (int j = 0; j < NL; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * NL + j) * 16 + r) * 64];
+            if (CS && do_cs) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bacc[0][r] += bxch[r * 64];
+            }
         }
     }
     if (!W8 || kh == 0) {
@@ -399,9 +408,16 @@ __global__ __launch_bounds__(W8 ? 512 : 256) void gemm_tn_glds_kernel(GemmP p) {
         }
     }
     if (CS) {
-        if (do_cs && (lane & 31) == 0) {
+        // (the two k halves of a workgroup were added above: ONE value per split and row - into the split's row of the bias partials when the launch has
+        // them (p.kpart: [split][N] behind the tile partials, summed in a fixed order by the same reduce launch as the tiles: the bias gradient is the same bits
+        // on every run, round 6), else one float atomic)
+        if (do_cs && (!W8 || kh == 0) && (lane & 31) == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(p.cs0 + nw + wn * 32 + acc_row(r, lane), bacc[0][r]);
+            for (int r = 0; r < 16; ++r) {
+                const int n = nw + wn * 32 + acc_row(r, lane);
+                if (p.kpart) p.kpart[(long)split * p.N + n] = bacc[0][r];
+                else atomicAdd(p.cs0 + n, bacc[0][r]);
+            }
         }
     }
 }
@@ -447,6 +463,8 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     }
     // p.cpart (optional scratch of >= 384 tiles of 128 x 128 floats): split partials as plain stores + one reduce pass
     if (p.splits < 2 || p.ldo0 % 4 || (p.res_mod && p.ldo1 % 4) || (long)tiles * p.splits > 384) p.cpart = nullptr;
+    // ... and the bias column sums of the splits as [split][N] behind them (at most two more tile units: splits x N <= 256 x 128 floats)
+    p.kpart = p.cpart && p.cs0 && (long)tiles * p.splits + 2 <= 384 && p.N % 4 == 0 && (size_t)p.cs0 % 16 == 0 ? p.cpart + (long)p.splits * (p.N + p.res_mod) * p.K : nullptr;
     constexpr int bytes = (is_split<T>::value ? T2_NSP : T2_NS) * T2_STAGE;   // (the pipelined form's ring; the other split forms use three of the four slots)
     p.rows_per_wg = 0;
     // (eight waves per workgroup and the LDS-DMA issue interleaved with the MFMAs - the W8 / IL template flags of the kernel - are the only forms
@@ -486,7 +504,8 @@ template <typename T> static int launch_t2(GemmP p, hipStream_t st) {
     MFVIT_CHECK_LAUNCH();
     if (p.cpart) {
         const long stride = (long)(p.N + p.res_mod) * p.K;
-        const int rc = tn_partial_reduce(p.cpart, p.splits, stride, p.N, p.K, (float*)p.out0, p.ldo0, st);
+        int rc = tn_partial_reduce(p.cpart, p.splits, stride, p.N, p.K, (float*)p.out0, p.ldo0, st);
+        if (rc == MFVIT_OK && p.kpart) rc = tn_partial_reduce(p.kpart, p.splits, p.N, 1, p.N, p.cs0, p.N, st);
         if (rc != MFVIT_OK || !p.res_mod) return rc;
         return tn_partial_reduce(p.cpart + (long)p.N * p.K, p.splits, stride, p.res_mod, p.K, (float*)p.out1, p.ldo1, st);
     }

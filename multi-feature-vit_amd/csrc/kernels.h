@@ -29,7 +29,7 @@ int colpart_reduce(const float* part, int G, int ncols, int nq, float* d0, float
 // deferred / batched form: between colpart_batch_begin(&batch) and colpart_batch_begin(previous) every colpart_reduce call of this thread
 // is queued (its partial buffer must stay untouched until the flush) and colpart_batch_flush reduces all queued jobs in ONE launch
 struct ColpartJob { const float* part; float* d[3]; int G, ncols, nq; };
-struct ColpartBatch { static constexpr int MAXJ = 32; int n; ColpartJob job[MAXJ]; };
+struct ColpartBatch { static constexpr int MAXJ = 48; int n; ColpartJob job[MAXJ]; };
 ColpartBatch* colpart_batch_begin(ColpartBatch* b);
 int colpart_batch_flush(hipStream_t st);
 bool gemm_tn_pair_supported(int dtype, const GemmP& a, const GemmP& b);   // gemm_tn2.hip: two weight gradients in one launch

@@ -208,10 +208,10 @@ WsLayout ws_layout(const Dims& d) {
             // row kernels: one partial row set [3][D] per workgroup - gemm_rowp launches at most one tile per CU and round (<= max(#CUs, M / 16) tiles),
             // gemm_nt_row full 64-row tiles (the former M / 64 + 256 bound belonged to the removed balanced-rows option)
             const size_t tiles_row = (M + 63) / 64 > 256 ? (M + 63) / 64 : 256;
-            size_t a = tiles_row * 3 * D, b2 = ((M + 127) / 128) * F, c2 = 256 * 3 * D;
+            size_t a = tiles_row * 3 * D, b2 = 4 * ((M + 255) / 256) * F, c2 = 256 * 3 * D;      // (b2: the x act' tile epilogue - one row of F sums per 64-row block of a 256-row tile)
             size_t n = a > b2 ? a : b2;
             n = n > c2 ? n : c2;
-            W.colpart = o; o += (2 * nl + 2) * align256(n * 4);          // one partial buffer per row-kernel launch of a backward call (batched reduce)
+            W.colpart = o; o += (3 * nl + 2) * align256(n * 4);          // one partial buffer per launch of a backward call that leaves column sums (batched reduce)
             W.colpart_stride = align256(n * 4);
         }
         // split partials of the weight-gradient GEMMs: one slot per launch of a BLOCK (at most 4) + 1 for the patch embedding, each tiles * splits <= 384
@@ -546,7 +546,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
     // column-sum partials: every row-kernel launch of this call writes its own buffer, ONE batched launch reduces them (before the embedding
     // stage, which reads a sum, and at the end of the call); with residual dropout (intermediate sums are consumed at once) nothing is deferred
     int colpart_used = 0;
-    auto next_colpart = [&]() { return (float*)(ws + W.colpart + (size_t)(colpart_used++ % (2 * d.depth + 2)) * W.colpart_stride); };
+    auto next_colpart = [&]() { return (float*)(ws + W.colpart + (size_t)(colpart_used++ % (3 * d.depth + 2)) * W.colpart_stride); };
     ColpartBatch cbatch;
     struct BatchScope {
         ColpartBatch* prev; bool on;
@@ -668,7 +668,7 @@ static int encoder_backward(const mfvit_vit_cfg* cfg, const float* params, const
                 p.M = d.M; p.N = d.F; p.K = d.D;
                 p.aux = b + W.hpre; p.ldaux = F;
                 p.out0 = dhpre; p.ldo0 = F * e;
-                if (fc1b_in_tile()) p.cs0 = gb + L.fc1_b;         // d fc1_b += column sums of dhpre from the accumulators of this epilogue (float atomics)
+                if (fc1b_in_tile()) { p.cs0 = gb + L.fc1_b; p.cpart = next_colpart(); }   // d fc1_b += column sums of dhpre from the accumulators of this epilogue (partials, fixed-order reduce)
                 MFVIT_TRY(gemm_nt_tile(d.dtype, EPI_GELU_BWD, p, st));
             }
             {   // dW1 += dhpre^T y2

@@ -693,3 +693,41 @@ def test_persistent_forward_attention_is_the_same_bits_from_run_to_run():
             o, l = ops.attention_fwd(q, H, split=True)
             assert torch.equal(o.view(torch.int16), o0.view(torch.int16)) and torch.equal(l, l0), name
     log(f"attention persistent forward: out / lse bit-identical over 5 runs (B = {B}, split fp16 and split bf16 qkv)")
+
+
+@pytest.mark.parametrize("B", [16, 128])
+def test_ca_train_step_is_the_same_bits_from_run_to_run(B):
+    """Round 6: every sum of the two-stream CA step is taken in a fixed order - forward, loss and all 326 parameter-gradient tensors (two encoders, the
+    cross-attention fusion, the four classifier heads) are bit-identical over three runs on the same weights and inputs; Adam is elementwise, so a training run
+    on one GPU is reproducible bit for bit.  What used float atomics until this round: the column partials of the row kernels and of the x gelu' tile epilogue,
+    the bias sums of the weight-gradient kernels, cls_token / patch-embedding bias (csrc/gemm.hip::colpart_reduce, gemm_tn2.hip, gemm_pp.hip,
+    elementwise.hip::colsum_rows) and the small gradients of the fusion (csrc/fusion.hip: per-sample partial rows + one fixed-order reduce).  B = 128 is
+    BASELINE configs[2]; B = 16 runs the K-split row kernels and the weight-gradient side stream."""
+    import sys
+    import bench
+    argv, sys.argv = sys.argv, sys.argv[:1]              # (bench.parse reads the command line: defaults only)
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    args.batch = B
+    run = bench.CaRun(args, dev(), 0, "bf16x3", "T")
+
+    def once():
+        run.opt.zero_grad(set_to_none=True)
+        fused, x_c, x_e = run.model(run.backs[0], run.backs[1], run.x, run.xe)
+        out = fused + x_c + x_e
+        loss, _ = run._ce(out, run.target)
+        loss.backward()
+        torch.cuda.synchronize()
+        g = [out.detach().clone(), loss.detach().clone()]
+        for mod in (run.model, run.backs[0], run.backs[1]):
+            g += [p.grad.detach().clone() for p in mod.parameters() if p.grad is not None]
+        return g
+
+    once()
+    a, b, c = once(), once(), once()
+    assert len(a) == 328
+    for i, (x, y, z) in enumerate(zip(a, b, c)):
+        assert torch.equal(x, y) and torch.equal(x, z), i
+    log(f"CA train step (B = {B}): logits, loss and {len(a) - 2} gradient tensors bit-identical over three runs")
