@@ -343,7 +343,8 @@ int mfvit_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, flo
 /* out[r * ldo] = scale * (a[r] . b[r])   (l_pos, BLD:183). */
 int mfvit_rowdot(const float* a, const float* b, float* out, int64_t ldo, float scale, int n, int C, mfvit_stream_t stream);
 /* nn.CrossEntropyLoss (mean) over wide rows, e.g. the (n, 1 + 65536) InfoNCE logits (MAIN_MOCO:330,535):
- * loss_mean[1]; optional per-row lse; optional dlogits = (softmax - onehot) / n. */
+ * loss_mean[1]; optional per-row lse (given: the mean is taken over the rows in a fixed order - the same bits on every run; NULL: one float atomic per
+ * row); optional dlogits = (softmax - onehot) / n. */
 int mfvit_cross_entropy_rows(const float* logits, int64_t ld, const int64_t* target, float* loss_mean, float* lse, float* dlogits,
                              int64_t ldd, int n, int C, mfvit_stream_t stream);
 /* momentum update over a flat arena: dst = dst * m + src * (1 - m)   (BLD:83-89, one launch instead of ~157 x 3). */

@@ -561,13 +561,14 @@ int linear_small_bwd(const float* dy, long lddy, const float* x, long ldx, const
 }
 
 // --------------------------------------------------------------------------------------- small-C cross entropy
-// nn.CrossEntropyLoss (mean) over logits [B][C], C <= 64: one thread per sample.  loss_sum must be zeroed by the caller;
-// writes dlogits = (softmax - onehot) / B and preds (argmax, first maximum like torch.max).
-__global__ void ce_small_kernel(const float* __restrict__ logits, const long* __restrict__ target, float* __restrict__ loss_mean,
-                                float* __restrict__ dlogits, long* __restrict__ preds, int B, int C) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+// nn.CrossEntropyLoss (mean) over logits [B][C], C <= 64: one thread per sample, ONE block (samples strided over its 1,024 threads); the mean is a fixed-order
+// sum (per-thread sequences, wave sums, the 16 wave totals in order): the same bits on every run (round 6: one float atomic per wave before).
+// Writes dlogits = (softmax - onehot) / B and preds (argmax, first maximum like torch.max).
+__global__ __launch_bounds__(1024) void ce_small_kernel(const float* __restrict__ logits, const long* __restrict__ target, float* __restrict__ loss_mean,
+                                                        float* __restrict__ dlogits, long* __restrict__ preds, int B, int C) {
+    __shared__ float red[16];
     float li = 0.f;
-    if (b < B) {
+    for (int b = threadIdx.x; b < B; b += 1024) {
         const float* z = logits + (long)b * C;
         float m = z[0];
         int am = 0;
@@ -576,18 +577,24 @@ __global__ void ce_small_kernel(const float* __restrict__ logits, const long* __
         for (int c = 0; c < C; ++c) s += __expf(z[c] - m);
         const float lse = m + __logf(s);
         const int t = (int)target[b];
-        li = (lse - z[t]) / (float)B;
+        li += (lse - z[t]) / (float)B;
         if (dlogits)
             for (int c = 0; c < C; ++c) dlogits[(long)b * C + c] = (__expf(z[c] - lse) - (c == t ? 1.f : 0.f)) / (float)B;
         if (preds) preds[b] = am;
     }
     li = wave_sum(li);
-    if ((threadIdx.x & 63) == 0 && li != 0.f) atomicAdd(loss_mean, li);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = li;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i];
+        *loss_mean = t;
+    }
 }
 int ce_small(const float* logits, const long* target, float* loss_mean, float* dlogits, long* preds, int B, int C, hipStream_t st) {
     if (C > 64 || C < 1) return MFVIT_EINVAL;
-    if (hipMemsetAsync(loss_mean, 0, sizeof(float), st) != hipSuccess) return MFVIT_ELAUNCH;
-    MFVIT_LAUNCH(ce_small_kernel, dim3((B + 255) / 256), dim3(256), 0, st, logits, target, loss_mean, dlogits, preds, B, C);
+    MFVIT_LAUNCH(ce_small_kernel, dim3(1), dim3(1024), 0, st, logits, target, loss_mean, dlogits, preds, B, C);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }

@@ -1287,7 +1287,11 @@ int gemm_nt_row(int dtype, int repi, const GemmP& p, hipStream_t st) {
 }
 int gemm_tn(int dtype, const GemmP& p, hipStream_t st) {
     if (gemm_tn_glds_supported(dtype, p)) return gemm_tn_glds(dtype, p, st);   // gemm_tn2.hip: LDS-DMA ring (16-bit types, large M)
-    if (gemm_tn_small_supported(dtype, p)) return gemm_tn_small(p, st);        // gemm_small.hip: f32, M <= 512
+    {   // gemm_small.hip: f32, M <= 512 - one workgroup per output tile, no splits: it needs no partial scratch (and is deterministic without one)
+        GemmP q = p;
+        q.cpart = nullptr;
+        if (gemm_tn_small_supported(dtype, q)) return gemm_tn_small(q, st);
+    }
     return tn_by_dtype(dtype, p, st);
 }
 

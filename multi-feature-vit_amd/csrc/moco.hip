@@ -256,8 +256,8 @@ __global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__
     const float lse = M + __logf(S);
     const int t = (int)target[r];
     if (tid == 0) {
-        atomicAdd(loss_sum, (lse - z[t]) * gscale);
-        if (lse_out) lse_out[r] = lse;
+        if (lse_out) lse_out[r] = lse;                                  // (with the row log-sum-exps kept, ce_rows_loss_kernel adds the row losses in a fixed order)
+        else atomicAdd(loss_sum, (lse - z[t]) * gscale);
     }
     if (dlogits) {
         float* d = dlogits + (long)r * ldd;
@@ -280,6 +280,21 @@ __global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__
         for (int c = tid; c < head; c += 1024) d[c] = (__expf(z[c] - lse) - (c == t ? 1.f : 0.f)) * gscale;
         for (int c = tail0 + tid; c < C; c += 1024) d[c] = (__expf(z[c] - lse) - (c == t ? 1.f : 0.f)) * gscale;
     }
+}
+
+// mean loss from the row log-sum-exps, one block, rows in a fixed order (256 interleaved sequences + a fixed tree): the same bits on every run
+__global__ __launch_bounds__(256) void ce_rows_loss_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ target,
+                                                           const float* __restrict__ lse, int n, float gscale, float* __restrict__ loss_mean) {
+    __shared__ float sm[256];
+    float s = 0.f;
+    for (int r = threadIdx.x; r < n; r += 256) s += lse[r] - logits[(long)r * ld + target[r]];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_mean = sm[0] * gscale;
 }
 
 // ----------------------------------------------------------------------------------------------- EMA over a flat arena
@@ -402,6 +417,10 @@ int mfvit_cross_entropy_rows(const float* logits, int64_t ld, const int64_t* tar
     MFVIT_LAUNCH(ce_rows_kernel, dim3(n), dim3(1024), 0, st, logits, (long)ld, (const long*)target, loss_mean, lse, dlogits, (long)ldd,
                        1.0f / (float)n, C);
     MFVIT_CHECK_LAUNCH();
+    if (lse) {       // (row log-sum-exps kept: the mean in a fixed order instead of one float atomic per row)
+        MFVIT_LAUNCH(ce_rows_loss_kernel, dim3(1), dim3(256), 0, st, logits, (long)ld, (const long*)target, (const float*)lse, n, 1.0f / (float)n, loss_mean);
+        MFVIT_CHECK_LAUNCH();
+    }
     return MFVIT_OK;
 }
 int mfvit_ema_update(float* dst, const float* src, float m, int64_t n, mfvit_stream_t stream) {

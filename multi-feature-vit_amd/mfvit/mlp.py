@@ -38,7 +38,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.linear_fwd(dy, wt).to(ctx.in_dtype)     # dx = dy @ W  (wt = W^T, [K][N])
         if ctx.needs_input_grad[1]:
-            dw = ops.linear_wgrad(dy, xT)                    # (N, K) f32
+            dw = ops.linear_wgrad(dy, xT, scratch=ops.wgrad_scratch(dy.device))      # (N, K) f32; split partials + fixed-order reduce (no float atomics)
         return dx, dw, None
 
 

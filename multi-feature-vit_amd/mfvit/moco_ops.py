@@ -71,7 +71,7 @@ class _NegLogitFn(torch.autograd.Function):
         pad = (-n) % 128
         if pad:
             dlt = torch.nn.functional.pad(dlt, (0, pad))
-        out = ops.linear_wgrad(queue_t, dlt)                     # (C, n + pad) = queue_t^T @ dl^T
+        out = ops.linear_wgrad(queue_t, dlt, scratch=ops.wgrad_scratch(dlt.device))     # (C, n + pad) = queue_t^T @ dl^T; split partials + fixed-order reduce
         return out[:, :n].t().contiguous(), None
 
 
@@ -90,7 +90,8 @@ class _CERowsFn(torch.autograd.Function):
         n, C = logits.shape
         loss = torch.empty(1, device=logits.device, dtype=torch.float32)
         dlogits = torch.empty_like(logits)
-        check(lib().mfvit_cross_entropy_rows(ptr(logits), C, ptr(target.contiguous().long()), ptr(loss), None, ptr(dlogits), C, n, C,
+        lse = torch.empty(n, device=logits.device, dtype=torch.float32)     # (with the row log-sum-exps kept the library adds the row losses in a fixed order)
+        check(lib().mfvit_cross_entropy_rows(ptr(logits), C, ptr(target.contiguous().long()), ptr(loss), ptr(lse), ptr(dlogits), C, n, C,
                                              stream()), "mfvit_cross_entropy_rows")
         ctx.save_for_backward(dlogits)
         return loss.reshape(())

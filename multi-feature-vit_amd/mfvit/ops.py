@@ -103,6 +103,19 @@ def linear_dgrad_act(dy, wt, act_grad, split=False):
 WGRAD_SCRATCH_FLOATS = 384 * 128 * 128   # include/mfvit.h: MFVIT_WGRAD_SCRATCH_FLOATS
 
 
+_wgrad_scratch = {}
+
+
+def wgrad_scratch(device):
+    """A cached WGRAD_SCRATCH_FLOATS buffer per (device, current stream) for callers that run ONE weight gradient at a time on that stream (the MoCo MLP heads, the
+    InfoNCE dq): with it the split partials are plain stores reduced in a fixed order - the same bits on every run - instead of float atomics."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _wgrad_scratch.get(key)
+    if t is None:
+        t = _wgrad_scratch[key] = torch.empty(WGRAD_SCRATCH_FLOATS, device=device, dtype=torch.float32)
+    return t
+
+
 def linear_wgrad(dy, x, out=None, scratch=None, split=False):
     """dW [N,K] (f32) += dy[M,N].T @ x[M,K].  scratch: optional f32 tensor of WGRAD_SCRATCH_FLOATS elements (split partials
     as plain stores + a reduce pass instead of float atomics).  split=True: dy, x are split-bf16 storage."""

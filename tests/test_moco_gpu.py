@@ -799,3 +799,44 @@ def test_fp16_moco_step_with_grad_scaler():
     log(f"fp16 MoCo step: logits vs f64 oracle {e_lo:.2e}; gradient norm fp16 {n16:.4e} / fp32 HIP {n32:.4e} / oracle {nor:.4e}")
     assert abs(n16 / n32 - 1.0) < 2e-2 and abs(n16 / nor - 1.0) < 2e-2, (n16, n32, nor)
     assert worst < 0.2 and moved == len(before) and scaler.get_scale() == 2.0 ** 14
+
+
+@pytest.mark.parametrize("precision,B", [("bf16x3", 64), ("fp16", 128)])
+def test_moco_training_is_the_same_bits_from_run_to_run(precision, B):
+    """Round 6: two trainings of the same seeded MoCo model (ViT-S encoders, projector / predictor MLPs with batch-statistics BatchNorm, momentum encoder, 65,536-key
+    queue, InfoNCE, AdamW, GradScaler in fp16) on the same two views end, after three steps, with EVERY parameter, buffer (queue, BatchNorm running statistics) and
+    loss value bit-identical.  What used float atomics until this round, beside the encoder's sums (tests/test_encoder_gpu.py): the InfoNCE dq - a reduction over
+    the 65,536 keys run as a split-M weight gradient - and the MLP heads' weight gradients (now split partials + fixed-order reduce through a cached scratch,
+    mfvit/ops.py::wgrad_scratch), and the mean of the row losses (csrc/moco.hip::ce_rows_loss_kernel)."""
+    import moco.builder_vit_mocov3structure_mocov2loss as bld
+    import vits
+    from mfvit.amp import GradScaler
+    from mfvit.moco_ops import cross_entropy_rows
+    from mfvit.optim import AdamW
+    dev = torch.device("cuda:0")
+    x1, x2 = rng_tensor(901, (B, 3, 224, 224)).to(dev), rng_tensor(902, (B, 3, 224, 224)).to(dev)
+
+    def train():
+        torch.manual_seed(7)
+        model = bld.MoCo_ViT(partial(vits.vit_small, stop_grad_conv1=True, precision=precision, depth=4), types.SimpleNamespace(arch="vit_small"), 256, 4096, 0.2).to(dev)
+        opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=1.5e-4, weight_decay=0.1)
+        scaler = GradScaler(enabled=precision == "fp16")
+        losses = []
+        for _ in range(3):
+            logits, labels = model(x1, x2, 0.99)
+            loss = cross_entropy_rows(logits, labels)
+            opt.zero_grad(set_to_none=True)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        state = {n: t.detach().clone() for n, t in list(model.named_parameters()) + list(model.named_buffers())}
+        state.update({f"loss[{i}]": l for i, l in enumerate(losses)})
+        return state
+
+    a, b = train(), train()
+    assert all(torch.isfinite(v.float()).all() for v in a.values())
+    diff = [n for n in a if not torch.equal(a[n], b[n])]
+    assert not diff, diff[:10]
+    log(f"MoCo training reproducibility [{precision}, B = {B}, depth 4]: {len(a)} parameters / buffers / losses bit-identical after 3 steps of two trainings")
