@@ -697,7 +697,7 @@ def test_persistent_forward_attention_is_the_same_bits_from_run_to_run():
 
 @pytest.mark.parametrize("B", [16, 128])
 def test_ca_train_step_is_the_same_bits_from_run_to_run(B):
-    """Round 6: every sum of the two-stream CA step is taken in a fixed order - forward, loss and all 326 parameter-gradient tensors (two encoders, the
+    """Round 6: every sum of the two-stream CA step is taken in a fixed order - forward, loss and all 324 parameter-gradient tensors (two encoders, the
     cross-attention fusion, the four classifier heads) are bit-identical over three runs on the same weights and inputs; Adam is elementwise, so a training run
     on one GPU is reproducible bit for bit.  What used float atomics until this round: the column partials of the row kernels and of the x gelu' tile epilogue,
     the bias sums of the weight-gradient kernels, cls_token / patch-embedding bias (csrc/gemm.hip::colpart_reduce, gemm_tn2.hip, gemm_pp.hip,
@@ -727,7 +727,7 @@ def test_ca_train_step_is_the_same_bits_from_run_to_run(B):
 
     once()
     a, b, c = once(), once(), once()
-    assert len(a) == 328
+    assert len(a) == 326                                  # logits, loss, 324 gradient tensors
     for i, (x, y, z) in enumerate(zip(a, b, c)):
         assert torch.equal(x, y) and torch.equal(x, z), i
     log(f"CA train step (B = {B}): logits, loss and {len(a) - 2} gradient tensors bit-identical over three runs")
