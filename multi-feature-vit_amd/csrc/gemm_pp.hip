@@ -94,7 +94,7 @@ template <typename E> __device__ __forceinline__ void pp_split4(f32x4 v, uint2& 
 
 // T = sbf16 | bf16 | f16
 template <typename T, int EPI>
-__global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles) {
+__global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles, int ntall) {
     constexpr bool SPLIT = is_split<T>::value;
     constexpr int NMF = SPLIT ? 48 : 32;                       // MFMAs per wave and stage (16 cycles each)
     constexpr int KPS = SPLIT ? 32 : 64;                       // logical k per stage
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
     // outputs leave the lane as 8-byte pieces (one ds_write_b64 per part instead of eight ds_write_b16).  Not swapped (x act' + column sums): a lane owns one COLUMN
     // and rows 4 (lane >> 4) .. + 3, so the column sums are in-lane adds + two shuffles.
     constexpr bool SWAP = EPI != EPI_GELU_BWD;
-    // stores of one wave's epilogue that the counted waits of the next tile's first load phase ASSUME (an undercount is safe: the wait only gets stricter)
-    constexpr int NSTORE = SPLIT ? 16 : 8;
+    // stores of one wave's epilogue that the counted waits of the next tile's first load phase ASSUME (an undercount is safe: the wait only gets stricter): those of a
+    // SHORT tile (three row fragments per wave, below) - a tall one has a third more, the oldest of which have long left by then
+    constexpr int NSTORE = SPLIT ? 12 : 6;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, q4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,6 +124,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
     const int my = xcd_remap(blockIdx.x, G);                   // each XCD walks a contiguous run of the tile order (n fastest: its workgroups share the A rows in L2)
     const int ntl = my < ntiles ? (ntiles - my + G - 1) / G : 0;
     if (ntl == 0) return;
+    // MIXED tile heights (round 6, like gemm_rowp's): the first `ntall` row tiles are 256 rows (four 16-row fragments per wave), the others 192 (three) - the launcher
+    // picks the mix that evens out the persistent workgroups' loads (qkv at M = 25,216: 891 tall tiles are 3.5 rounds of 256 workgroups, i.e. four; 57 tall + 56 short row
+    // tiles are 14 of 16 units for every workgroup).  A short tile keeps the LDS layout of a tall one - each wave's 64-row block holds its 48 rows, the last 16 rows of the
+    // block repeat row 47 (same number of LDS-DMA pieces: the counted waits do not change) - and skips the fourth fragment's reads, MFMAs and stores.
+    auto tile_rt = [&](int tile) { return tile / ntn; };
+    auto tile_m0 = [&](int rt) { return rt < ntall ? rt * PP_BM : ntall * PP_BM + (rt - ntall) * (3 * PP_BM / 4); };
     const char* gA = (const char*)p.A;
     const char* gW = (const char*)p.W;
 
@@ -134,11 +141,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
         int ln = tid & 63;                                     // (laundered: the per-lane terms are recomputed once per tile instead of living in registers across the loops)
         asm volatile("" : "+v"(ln));
         const int tile = my + t * G;
-        const int m0 = (tile / ntn) * PP_BM, n0 = (tile % ntn) * PP_BN;
+        const int rt = tile_rt(tile), m0 = tile_m0(rt), n0 = (tile % ntn) * PP_BN;
+        const bool tall = rt < ntall;
 #pragma unroll
         for (int i = 0; i < PP_NDA; ++i) {
             const int row = 8 * (wave + 8 * i) + (ln >> 3);
-            int gm = m0 + row;
+            const int rb = row & 63;
+            int gm = tall ? m0 + row : m0 + (row >> 6) * 48 + (rb < 48 ? rb : 47);      // (short tile: 48 rows per 64-row block, its tail repeats the block's last row)
             gm = gm < p.M ? gm : p.M - 1;                      // rows past the end replicate row M - 1 (finite data; their outputs are identical duplicates)
             va[i] = (unsigned)gm * lda_b + 16u * (unsigned)((ln & 7) ^ ((row >> 1) & 7));
         }
@@ -216,16 +225,20 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
     int slot = 0;
     frag_t af[2][4], bf[2][4];                                 // [part / K step][16-row tile]
     for (int t = 0; t < ntl; ++t) {
+      const int tile = my + t * G;
+      // one tile with MI row fragments per wave (4: 256 rows, 3: 192): main loop + epilogue, instantiated for both heights
+      auto run_tile = [&](auto mi_c) __attribute__((always_inline)) {
+        constexpr int MI = decltype(mi_c)::value;
+        constexpr int NMFI = NMF / 4 * MI;                     // MFMAs per wave and stage of this height
         f32x4 acc[4][4];                                       // [row tile][column tile]
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr (SWAP && HAS_BIAS) acc[i][j] = p.bias ? __builtin_bit_cast(f32x4, bn[j]) : f32x4{0.f, 0.f, 0.f, 0.f};
                 else acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        const int tile = my + t * G;
-        const int mw = (tile / ntn) * PP_BM + grp * 128 + wm * 64;     // first row / first LOGICAL column of this wave's 64 x 64 quadrant
+        const int mw = tile_m0(tile_rt(tile)) + (grp * 2 + wm) * (16 * MI);     // first row / first LOGICAL column of this wave's (16 MI) x 64 quadrant
         const int nw = (tile % ntn) * PP_BN + wn * 64;
         auto stage = [&](auto last_c, bool behind_epilogue) __attribute__((always_inline)) {
             constexpr bool LAST = decltype(last_c)::value;
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    af[c][i] = *(const frag_t*)(sl + (fa[i] ^ (64u * c)));
+                    if (i < MI) af[c][i] = *(const frag_t*)(sl + (fa[i] ^ (64u * c)));
                     bf[c][i] = *(const frag_t*)(sl + (fw[i] ^ (64u * c)));
                 }
             if constexpr (LAST && EPI == EPI_GELU_BWD) {
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
-                        int m = mw + u * 16 + 8 * q + (ln >> 3);
+                        int m = mw + (u < MI ? u : MI - 1) * 16 + 8 * q + (ln >> 3);      // (a short tile repeats its last fragment's rows: the counts stay fixed)
                         m = m < p.M ? m : p.M - 1;
                         pp_gload16(ax[u][q], (const char*)p.aux, (unsigned)m * (unsigned)(p.ldaux * (long)sizeof(AX)) + (unsigned)(nw * (int)sizeof(AX) + 16 * (ln & 7)));
                     }
@@ -264,12 +277,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
             // ---- compute phase: split tensors  acc += a_lo w_hi + a_hi w_lo + a_hi w_hi  per 16 x 16 tile; plain ones the two K steps
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int tt = 0; tt < NMF; ++tt) {
-                const int term = tt >> 4, i = (tt >> 2) & 3, j = tt & 3;
+            for (int tt = 0; tt < NMFI; ++tt) {
+                const int term = tt / (4 * MI), i = (tt >> 2) % MI, j = tt & 3;
                 const frag_t a = af[SPLIT ? (term == 0 ? 1 : 0) : term][i], w = bf[SPLIT ? (term == 1 ? 1 : 0) : term][j];
                 acc[i][j] = SWAP ? PpMma<T>::mma(w, a, acc[i][j]) : PpMma<T>::mma(a, w, acc[i][j]);
                 if constexpr (NC > 0) {
-                    constexpr int GAP = NMF / (NC + 1);
+                    constexpr int GAP = NMFI / (NC + 1);
                     if ((tt + 1) % GAP == 0 && (tt + 1) / GAP <= NC) { dma_piece(PP_NDMA - NC + (tt + 1) / GAP - 1); __builtin_amdgcn_sched_barrier(0); }
                 }
             }
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
             auto pslot = [&](int s4) -> uint2* { return (uint2*)(prow_ + 8 * ((4 * s4 + q4) ^ (2 * (l15 & 7)))); };
             const bool want_grad = p.out0 != nullptr;           // GELU / ReLU epilogues: no-grad forwards pass out0 = NULL and skip the derivative
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 const int row0 = mw + i * 16;
                 if constexpr (ACT) {
                     // out0 = act'(pre) in AX (the four column tiles of the quadrant: 64 x 2 B = one line per row), the activation replaces the accumulators
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
             // the same bits on every run, round 6) or, without a partial buffer, as float atomics
             float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) *(u32x4*)(patch + (8 * q + (lane >> 3)) * 128 + 16 * (lane & 7)) = ax[i][q];
 #pragma unroll
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 const int row0 = mw + i * 16;
                 if constexpr (SPLIT) {
 #pragma unroll
@@ -419,19 +432,59 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_pp_kernel(GemmP p, int ntiles)
             }
         }
         if (grp == 1) __builtin_amdgcn_s_barrier();
+      };
+      if (tile_rt(tile) < ntall) run_tile(std::integral_constant<int, 4>());
+      else run_tile(std::integral_constant<int, 3>());
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
     pp_wait_vm<0>();
 }
 
+// The mix of tall (256-row) and short (192-row) row tiles of a launch: workgroup w of `cus` walks tiles w, w + cus, ... of the order [row tile][column tile], tall row
+// tiles first; a tall tile costs 4 units, a short one 3.4 (measured: three of four fragments' MFMAs and stores, but the same LDS-DMA pieces, barriers and tile set-up).  Picks the number of tall row tiles with
+// the smallest maximum load (ties: more tall tiles = fewer tiles).  MFVIT_PP_MIX=0: tall tiles only (round-6 first form).
+struct PpPlan { int ntall, nrt; double load, ideal; };
+static PpPlan pp_plan(int M, int ntn, int cus) {
+    static int sw = INT_MIN;
+    const bool mix = env_switch("MFVIT_PP_MIX", 1, sw) != 0;
+    const int nt_all = (M + PP_BM - 1) / PP_BM;
+    // (the search is ~nt_all x cus steps: cached per thread for the last shapes - an encoder step asks for the same four or five over and over)
+    struct Key { int M, ntn, cus, mix; PpPlan plan; };
+    static thread_local Key cache[8];
+    static thread_local int cache_n = 0, cache_next = 0;
+    for (int i = 0; i < cache_n; ++i)
+        if (cache[i].M == M && cache[i].ntn == ntn && cache[i].cus == cus && cache[i].mix == (int)mix) return cache[i].plan;
+    PpPlan best{nt_all, nt_all, 1e30, 0.0};
+    for (int na = nt_all; na >= (mix ? 0 : nt_all); --na) {
+        const int rest = M - na * PP_BM;
+        const int nb = rest > 0 ? (rest + 191) / 192 : 0;
+        if (na < nt_all && nb == 0) continue;
+        const long ntile = (long)(na + nb) * ntn, ntall_t = (long)na * ntn;
+        double worst = 0.0;
+        for (int w = 0; w < cus && w < ntile; ++w) {
+            // tiles w, w + cus, ...: those below ntall_t are tall
+            const long n_all = (ntile - w + cus - 1) / cus;
+            const long n_tall = ntall_t > w ? (ntall_t - w + cus - 1) / cus : 0;
+            const double l = 4.0 * n_tall + 3.4 * (n_all - n_tall);
+            worst = l > worst ? l : worst;
+        }
+        if (worst < best.load - 1e-9) best = PpPlan{na, na + nb, worst, 0.0};
+    }
+    best.ideal = (double)M / 64.0 * ntn / cus;
+    cache[cache_next] = Key{M, ntn, cus, (int)mix, best};
+    cache_next = (cache_next + 1) & 7;
+    if (cache_n < 8) ++cache_n;
+    return best;
+}
 template <typename T, int EPI> int launch_pp(const GemmP& p, hipStream_t st) {
-    const int ntiles = (p.N / PP_BN) * ((p.M + PP_BM - 1) / PP_BM);
+    const PpPlan plan = pp_plan(p.M, p.N / PP_BN, device_cus());
+    const int ntiles = (p.N / PP_BN) * plan.nrt;
     int grid = device_cus();
     if (grid > ntiles) grid = ntiles;
     static PerDeviceOnce attr_set;
     if (attr_set.first()) (void)hipFuncSetAttribute((const void*)gemm_nt_pp_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
     ProfScope ps(PROF_GEMM_TILE, 2.0 * p.M * p.N * p.K, 0, st);
-    MFVIT_LAUNCH((gemm_nt_pp_kernel<T, EPI>), dim3(grid), dim3(512), PP_LDS, st, p, ntiles);
+    MFVIT_LAUNCH((gemm_nt_pp_kernel<T, EPI>), dim3(grid), dim3(512), PP_LDS, st, p, ntiles, plan.ntall);
     MFVIT_CHECK_LAUNCH();
     return MFVIT_OK;
 }
@@ -463,10 +516,10 @@ bool gemm_nt_pp_supported(int dtype, int epi, const GemmP& p) {
     if (p.omax) return false;                                   // per-(image, head) output maxima: the round-5 kernel's epilogue (proj data gradient)
     if (on != 2) {   // enough tiles to fill the persistent grid's rounds: 256 x 128 tiles on one workgroup per CU quantise coarsely (proj data gradient at the bench shape:
         // 297 tiles = 2 rounds at 58 % - 35.3 us against 31.7 us of the 128 x 128 kernel on two workgroups per CU; qkv 891 tiles = 4 rounds at 87 %)
+        // (with mixed tile heights: the ideal load per workgroup against the plan's largest)
         const int cus = device_cus();
-        const long ntiles = (long)(p.N / PP_BN) * ((p.M + PP_BM - 1) / PP_BM);
-        const long rounds = (ntiles + cus - 1) / cus;
-        if (ntiles < cus || ntiles * 100 < rounds * cus * 75) return false;
+        const PpPlan plan = pp_plan(p.M, p.N / PP_BN, cus);
+        if ((long)plan.nrt * (p.N / PP_BN) < cus || plan.ideal < 0.75 * plan.load) return false;
     }
     if ((p.lda * 2) % 16 || (p.ldw * 2) % 16) return false;
     // 32-bit byte offsets inside both operands
@@ -481,8 +534,9 @@ int gemm_nt_pp(int dtype, int epi, const GemmP& p, hipStream_t st) {
         case MFVIT_BF16: rc = pp_by_epi<bf16>(epi, p, st); break;
         case MFVIT_F16: rc = pp_by_epi<f16>(epi, p, st); break;
     }
-    // column-sum partials of the x act' epilogue: [4 x row tiles][N] (p.cpart: room for 4 x ceil(M / 256) rows of N floats) -> cs0, fixed order
-    if (rc == MFVIT_OK && epi == EPI_GELU_BWD && p.cs0 && p.cpart) return colpart_reduce(p.cpart, 4 * ((p.M + PP_BM - 1) / PP_BM), p.N, 1, p.cs0, nullptr, nullptr, st);
+    // column-sum partials of the x act' epilogue: [4 x row tiles][N] (p.cpart: room for 4 x ceil(M / 192) rows of N floats) -> cs0, fixed order
+    if (rc == MFVIT_OK && epi == EPI_GELU_BWD && p.cs0 && p.cpart)
+        return colpart_reduce(p.cpart, 4 * pp_plan(p.M, p.N / PP_BN, device_cus()).nrt, p.N, 1, p.cs0, nullptr, nullptr, st);
     return rc;
 }
 

@@ -208,7 +208,7 @@ WsLayout ws_layout(const Dims& d) {
             // row kernels: one partial row set [3][D] per workgroup - gemm_rowp launches at most one tile per CU and round (<= max(#CUs, M / 16) tiles),
             // gemm_nt_row full 64-row tiles (the former M / 64 + 256 bound belonged to the removed balanced-rows option)
             const size_t tiles_row = (M + 63) / 64 > 256 ? (M + 63) / 64 : 256;
-            size_t a = tiles_row * 3 * D, b2 = 4 * ((M + 255) / 256) * F, c2 = 256 * 3 * D;      // (b2: the x act' tile epilogue - one row of F sums per 64-row block of a 256-row tile)
+            size_t a = tiles_row * 3 * D, b2 = 4 * ((M + 191) / 192) * F, c2 = 256 * 3 * D;      // (b2: the x act' tile epilogue - one row of F sums per wave-row block of a tile; tiles are 256 or 192 rows)
             size_t n = a > b2 ? a : b2;
             n = n > c2 ? n : c2;
             W.colpart = o; o += (3 * nl + 2) * align256(n * 4);          // one partial buffer per launch of a backward call that leaves column sums (batched reduce)
