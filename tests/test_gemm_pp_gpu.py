@@ -125,3 +125,26 @@ def test_results_are_the_same_bits_from_run_to_run():
     a1 = ops.linear_fwd(x, w, b, gelu=True, split=True)
     a2 = ops.linear_fwd(x, w, b, gelu=True, split=True)
     assert torch.equal(a1[0], a2[0]) and torch.equal(a1[1].view(torch.int16), a2[1].view(torch.int16))
+
+
+@pytest.mark.parametrize("M,N,K,tag", [(128 * 197, 1152, 384, "qkv: 56 tall + 57 short row tiles"), (128 * 197 - 57, 1536, 384, "fc1, ragged M"),
+                                       (64 * 197, 1536, 384, "B = 64"), (6 * 256 + 130, 256, 64, "two stages, 14 tiles")])
+def test_mixed_tile_heights_give_the_same_bits_as_tall_tiles_only(monkeypatch, M, N, K, tag):
+    """Second half of round 6: a launch mixes 256-row and 192-row tiles so that every persistent workgroup carries the same load (MFVIT_PP_MIX, default 1).  The k order
+    of every output element does not depend on the tile it falls into, so every epilogue's outputs must be BIT-identical with MFVIT_PP_MIX=0 (256-row tiles only) - a row
+    mapped to the wrong place of a short tile's LDS image, a skipped fragment or a miscounted wait would show as wrong bits, not as a rounding."""
+    g = gen(300 + N + K + M % 97)
+    x, w = ops.split_pack(torch.randn(M, K, device=DEV, generator=g)), ops.split_pack(torch.randn(N, K, device=DEV, generator=g) * 0.05)
+    b = torch.randn(N, device=DEV, generator=g)
+    dy, wt = ops.split_pack(torch.randn(M, K, device=DEV, generator=g) * 0.1), ops.split_pack(torch.randn(N, K, device=DEV, generator=g) * 0.05)
+    ag = (torch.rand(M, N, device=DEV, generator=g) * 1.2 - 0.1).to(torch.float16)
+    monkeypatch.setenv("MFVIT_PP", "2")
+    res = {}
+    for mix in ("1", "0"):
+        monkeypatch.setenv("MFVIT_PP_MIX", mix)
+        dact, act = ops.linear_fwd(x, w, b, gelu=True, split=True)
+        res[mix] = [ops.linear_fwd(x, w, b, split=True), ops.linear_fwd(x, w, None, split=True), dact, act, ops.linear_fwd(x, w, b, split=True, qkv_f16=True),
+                    ops.linear_dgrad_act(dy, wt, ag, split=True)]
+    for i, (a, c) in enumerate(zip(res["1"], res["0"])):
+        assert torch.equal(a.view(torch.int16), c.view(torch.int16)), (tag, i)
+    log(f"gemm_pp mixed tile heights[M={M}, N={N}, K={K}: {tag}] bias / none / gelu' / gelu / qkv_f16 / dgrad x act' bit-identical with 256-row tiles only")
